@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+Imports the *reference's own code* from /root/reference (vendored diffusers 0.17.0.dev0 and the
+vendored ddpm_exp/torch_pruning) through the compatibility shim of SURVEY.md App. C, runs the hot
+path on seeded inputs and writes small data fixtures into tests/golden/.  Only DATA is written:
+inputs are regenerated from `numpy.random.default_rng` seeds by `golden_common.py`, so no reference
+source text ends up in this repository.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            # all fixtures
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py tiny ddim  # a subset
+
+Fixtures:
+  schedule.npz      G6 alphas_cumprod table + add_noise outputs; G8 timestep embeddings
+  ddim.npz          G7 DDIM timestep lists (uniform/quad) + 5 consecutive step() outputs
+  tiny_unet.npz     G1 tiny UNet forward output, loss, per-parameter gradient statistics + a few full grads
+  tiny_prune.json   G3/G4 for the tiny UNet: group tables, scores, pruned indices (ratio 0.3), early-exit step count
+  cifar_groups.json G3 group table for the CIFAR-10 UNet (50 groups) and the bedroom-256 topology
+  cifar_c1.npz/json G2/G4/G5 config C1: CIFAR UNet, B=4, 8 timesteps, Taylor, ratio 0.3
+"""
+import os, sys, json, time, base64, io
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import numpy as np
+import torch
+import golden_common as gc
+
+# ---------------------------------------------------------------------------------------------
+# reference import shim
+# ---------------------------------------------------------------------------------------------
+import huggingface_hub, huggingface_hub.constants as _c, importlib.util as _iu
+_c.hf_cache_home = getattr(_c, 'hf_cache_home', os.path.expanduser('~/.cache/huggingface'))
+class _HfFolder:
+    get_token = staticmethod(lambda: None)
+for _n, _v in (('HfFolder', _HfFolder), ('cached_download', lambda *a, **k: (_ for _ in ()).throw(RuntimeError('offline')))):
+    if not hasattr(huggingface_hub, _n):
+        setattr(huggingface_hub, _n, _v)
+_orig = _iu.find_spec
+_iu.find_spec = lambda name, package=None: None if name.split('.')[0] in {
+    'transformers', 'flax', 'jax', 'onnxruntime', 'k_diffusion', 'xformers', 'tensorflow'} else _orig(name, package)
+sys.path[:0] = ['/root/reference', '/root/reference/ddpm_exp']
+os.makedirs('/tmp/golden_scratch', exist_ok=True)
+os.chdir('/tmp/golden_scratch')          # vendored MetaPruner writes run/pruning_logs/*.png into cwd
+
+import diffusers                                                    # noqa: E402  (reference)
+import torch_pruning as tp                                          # noqa: E402  (reference, vendored)
+from diffusers import UNet2DModel, DDPMScheduler, DDIMScheduler     # noqa: E402
+from diffusers.models.attention_processor import Attention, AttnProcessor  # noqa: E402
+from diffusers.models.embeddings import get_timestep_embedding      # noqa: E402
+from diffusers.models.resnet import Upsample2D, Downsample2D        # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def build_ref_unet(cfg, seed):
+    m = UNet2DModel(**cfg).eval()
+    gc.det_init_(m, seed)
+    return m
+
+
+def name_of(model):
+    return {mod: n for n, mod in model.named_modules()}
+
+
+def compress(idxs):
+    """list of ints -> list of [start, stop) ranges (order preserved for sorted input)."""
+    out = []
+    for i in idxs:
+        if out and out[-1][1] == i:
+            out[-1][1] = i + 1
+        else:
+            out.append([i, i + 1])
+    return out
+
+
+def kind_of(dep):
+    h = dep.handler
+    f = tp.function
+    if h in (f.prune_conv_out_channels, f.prune_linear_out_channels):
+        return 'out'
+    if h in (f.prune_conv_in_channels, f.prune_linear_in_channels):
+        return 'in'
+    if h == f.prune_groupnorm_out_channels:
+        return 'gn'
+    return 'other'
+
+
+def dump_group(group, names):
+    mem = []
+    for dep, idxs in group:
+        mod = dep.target.module
+        if mod not in names:
+            continue          # elementwise / concat / reshape pseudo-ops
+        mem.append([names[mod], kind_of(dep), compress(sorted(idxs))])
+    return mem
+
+
+def make_pruner(model, H, ratio=0.3):
+    ex = {'sample': torch.randn(1, model.config.in_channels, H, H), 'timestep': torch.ones((1,)).long()}
+    imp = tp.importance.TaylorImportance()
+    return tp.pruner.MagnitudePruner(model, ex, importance=imp, iterative_steps=1, channel_groups={},
+                                     ch_sparsity=ratio, ignored_layers=[model.conv_out]), ex
+
+
+def sweep(model, sched, clean, noise, steps, thr=None):
+    """ddpm_prune.py:94-106 loop, verbatim semantics."""
+    model.zero_grad()
+    model.eval()
+    losses = []
+    loss_max = 0
+    B = clean.shape[0]
+    for step_k in range(steps):
+        timesteps = (step_k * torch.ones((B,))).long()
+        noisy = sched.add_noise(clean, noise, timesteps)
+        out = model(noisy, timesteps).sample
+        loss = torch.nn.functional.mse_loss(out, noise)
+        loss.backward()
+        losses.append(float(loss))
+        if thr is not None:
+            if loss > loss_max:
+                loss_max = loss
+            if loss < loss_max * thr:
+                break
+    return losses
+
+
+def grad_stats(model):
+    st = {}
+    for n, p in model.named_parameters():
+        g = p.grad.detach().double()
+        st[n] = [float(g.sum()), float(g.abs().sum()), float((g * g).sum())]
+    return st
+
+
+def prune_run(model, H, ratio=0.3):
+    """pruner.step(interactive=True) loop of ddpm_prune.py:108-116, recording every group."""
+    pruner, ex = make_pruner(model, H, ratio)
+    pruner.current_step += 1          # what MetaPruner.step() does first (metapruner.py:155)
+    names = name_of(model)
+    rec = []
+    # re-implement prune_local's bookkeeping around the reference calls so that scores can be recorded
+    for group in pruner.DG.get_all_groups(ignored_layers=pruner.ignored_layers,
+                                          root_module_types=pruner.root_module_types):
+        if not pruner._check_sparsity(group):
+            continue
+        module = group[0][0].target.module
+        fn = group[0][0].handler
+        ch_groups = pruner.get_channel_groups(group)
+        imp = pruner.estimate_importance(group, ch_groups=ch_groups)
+        if imp is None:
+            continue
+        cur = pruner.DG.get_out_channels(module)
+        n_pruned = cur - int(pruner.layer_init_out_ch[module] * (1 - pruner.get_target_sparsity(module)))
+        if n_pruned <= 0:
+            continue
+        if ch_groups > 1:
+            gs = cur // ch_groups
+            per = n_pruned // ch_groups
+            idxs = []
+            for chg in range(ch_groups):
+                sub = imp[chg * gs:(chg + 1) * gs]
+                idxs.append(torch.argsort(sub)[:per] + chg * gs)
+            idxs = torch.cat(idxs, 0)
+        else:
+            idxs = torch.argsort(imp)[:(n_pruned // ch_groups)]
+        members = dump_group(group, names)
+        g2 = pruner.DG.get_pruning_group(module, fn, idxs.tolist())
+        ok = pruner.DG.check_pruning_group(g2)
+        rec.append(dict(root=names[module], ch_groups=int(ch_groups), cur=int(cur), n_pruned=int(n_pruned),
+                        pruned=sorted(int(i) for i in idxs.tolist()), members=members,
+                        score=gc.f32_to_b64(imp.detach().float().numpy()), ok=bool(ok)))
+        if ok:
+            g2.prune()
+    for m in model.modules():
+        if isinstance(m, (Upsample2D, Downsample2D)):
+            m.channels = m.conv.in_channels
+    return rec
+
+
+def group_table(model, H):
+    pruner, ex = make_pruner(model, H)
+    names = name_of(model)
+    table = []
+    for group in pruner.DG.get_all_groups(ignored_layers=pruner.ignored_layers,
+                                          root_module_types=pruner.root_module_types):
+        table.append(dict(ch_groups=int(pruner.get_channel_groups(group)), members=dump_group(group, names)))
+    return table
+
+
+# ---------------------------------------------------------------------------------------------
+def do_schedule():
+    s = DDPMScheduler(num_train_timesteps=1000)
+    x0 = torch.from_numpy(gc.det_clean((2, 3, 4, 4), 11))
+    eps = torch.from_numpy(gc.det_noise((2, 3, 4, 4), 12))
+    ts = [0, 1, 7, 500, 999]
+    outs = [s.add_noise(x0, eps, torch.tensor([t, t])).numpy() for t in ts]
+    emb = get_timestep_embedding(torch.tensor([0, 1, 999]), 128, flip_sin_to_cos=False, downscale_freq_shift=1).numpy()
+    emb_f = get_timestep_embedding(torch.tensor([0.0, 1.0, 999.0]), 32, flip_sin_to_cos=True, downscale_freq_shift=0).numpy()
+    np.savez(os.path.join(HERE, 'schedule.npz'), alphas_cumprod=s.alphas_cumprod.numpy(), ts=np.array(ts),
+             add_noise=np.stack(outs), temb_128=emb, temb_32_flip=emb_f)
+    print('schedule.npz ok')
+
+
+def do_ddim():
+    cfg = gc.TINY_CFG
+    model = build_ref_unet(cfg, 5)
+    out = {}
+    for skip in ('uniform', 'quad'):
+        sch = DDIMScheduler(num_train_timesteps=1000)
+        sch.skip_type = skip
+        sch.set_timesteps(100)
+        out['timesteps_' + skip] = sch.timesteps.numpy().copy()
+    sch = DDIMScheduler(num_train_timesteps=1000)
+    sch.skip_type = 'uniform'
+    sch.set_timesteps(100)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 21))
+    xs = []
+    with torch.no_grad():
+        for t in sch.timesteps[:5]:
+            eps = model(x, t).sample
+            x = sch.step(eps, t, x, eta=0.0).prev_sample
+            xs.append(x.numpy().copy())
+    out['x_steps'] = np.stack(xs)
+    # a 10-step full chain + final image post-processing (pipeline_ddim.py:103-117)
+    sch.set_timesteps(10)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 22))
+    with torch.no_grad():
+        for t in sch.timesteps:
+            x = sch.step(model(x, t).sample, t, x, eta=0.0).prev_sample
+    out['chain10_image'] = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    np.savez(os.path.join(HERE, 'ddim.npz'), **out)
+    print('ddim.npz ok')
+
+
+def do_tiny():
+    cfg = gc.TINY_CFG
+    H = cfg['sample_size']
+    model = build_ref_unet(cfg, 5)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    B = 2
+    clean = torch.from_numpy(gc.det_clean((B, 3, H, H), 1))
+    noise = torch.from_numpy(gc.det_noise((B, 3, H, H), 2))
+    t = torch.tensor([3, 500])
+    with torch.no_grad():
+        y = model(sched.add_noise(clean, noise, t), t).sample.numpy()
+    losses = sweep(model, sched, clean, noise, 4)
+    st = grad_stats(model)
+    full = {}
+    for n in ['conv_in.weight', 'down_blocks.1.attentions.0.to_q.weight', 'mid_block.resnets.0.conv1.weight',
+              'up_blocks.2.resnets.0.conv_shortcut.weight', 'up_blocks.0.upsamplers.0.conv.weight',
+              'down_blocks.0.downsamplers.0.conv.weight', 'time_embedding.linear_1.weight', 'conv_norm_out.weight',
+              'down_blocks.1.attentions.0.group_norm.bias', 'conv_out.bias']:
+        full['grad::' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
+    np.savez(os.path.join(HERE, 'tiny_unet.npz'), fwd_out=y, losses=np.array(losses), **full)
+    table = group_table(model, H)
+    rec = prune_run(model, H, 0.3)
+    nparams = sum(p.numel() for p in model.parameters())
+    for m in model.modules():
+        if isinstance(m, Attention):
+            m.set_processor(AttnProcessor())
+    with torch.no_grad():
+        y2 = model(sched.add_noise(clean, noise, t), t).sample.numpy()
+    # diff-pruning early exit on a fresh model
+    model2 = build_ref_unet(cfg, 5)
+    losses2 = sweep(model2, sched, clean, noise, 1000, thr=0.99)
+    json.dump(dict(grad_stats=st, groups=table, prune=rec, params_after=int(nparams),
+                   shapes_after={n: list(p.shape) for n, p in model.named_parameters()},
+                   fwd_after=gc.f32_to_b64(y2), early_exit=dict(thr=0.99, steps=len(losses2), losses=losses2)),
+              open(os.path.join(HERE, 'tiny_prune.json'), 'w'))
+    print('tiny ok: groups', len(table), 'pruned groups', len(rec), 'params', nparams, 'early steps', len(losses2))
+
+
+def do_groups():
+    out = {}
+    cfg = gc.CIFAR_CFG
+    model = build_ref_unet(cfg, 0)
+    out['cifar'] = group_table(model, 32)
+    print('cifar groups', len(out['cifar']))
+    # bedroom topology at reduced width and resolution (same block types / layer counts => same graph)
+    cfgb = dict(gc.BEDROOM_CFG)
+    cfgb['block_out_channels'] = [32, 32, 64, 64, 128, 128]
+    cfgb['sample_size'] = 64
+    model = build_ref_unet(cfgb, 0)
+    out['bedroom_topology'] = group_table(model, 64)
+    print('bedroom groups', len(out['bedroom_topology']))
+    json.dump(out, open(os.path.join(HERE, 'groups.json'), 'w'))
+
+
+def do_c1():
+    cfg = gc.CIFAR_CFG
+    model = build_ref_unet(cfg, 0)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    B = 4
+    clean = torch.from_numpy(gc.det_clean((B, 3, 32, 32), 1))
+    noise = torch.from_numpy(gc.det_noise((B, 3, 32, 32), 2))
+    t0 = time.time()
+    losses = sweep(model, sched, clean, noise, 8)
+    print('C1 sweep %.1fs' % (time.time() - t0), losses)
+    st = grad_stats(model)
+    base_macs, base_params = tp.utils.count_ops_and_params(
+        model, {'sample': torch.randn(1, 3, 32, 32), 'timestep': torch.ones((1,)).long()})
+    rec = prune_run(model, 32, 0.3)
+    for m in model.modules():
+        if isinstance(m, Attention):
+            m.set_processor(AttnProcessor())
+    macs, params = tp.utils.count_ops_and_params(
+        model, {'sample': torch.randn(1, 3, 32, 32), 'timestep': torch.ones((1,)).long()})
+    print('params %d -> %d, macs %.4fG -> %.4fG' % (base_params, params, base_macs / 1e9, macs / 1e9))
+    json.dump(dict(losses=losses, grad_stats=st, prune=rec, base_params=int(base_params), params_after=int(params),
+                   base_macs=float(base_macs), macs_after=float(macs),
+                   shapes_after={n: list(p.shape) for n, p in model.named_parameters()}),
+              open(os.path.join(HERE, 'cifar_c1.json'), 'w'))
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1']
+    for w in what:
+        globals()['do_' + w]()
