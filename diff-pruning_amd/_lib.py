@@ -1,0 +1,105 @@
+"""ctypes binding of libdp_hip.so (the C-ABI declared in include/dp_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol does not resolve, importing the
+compute path raises.  Device pointers are taken from torch tensors (`data_ptr()`), the stream from
+`torch.cuda.current_stream()`; torch is plumbing (memory + streams), every FLOP runs in the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdp_hip.so')
+
+c_float_p = C.c_void_p
+LL = C.c_longlong
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('Ho', 'Wo', 'Hs', 'Ws', 'Hv', 'Wv', 'kw', 'stride', 'sden', 'pad_t', 'pad_l',
+                                       'ups', 'c_split', '_pad')] + [('x1_img_stride', LL), ('x2_img_stride', LL)]
+
+
+class ConvGemmParams(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('a_bs', LL), ('lda', C.c_int), ('a_kc', C.c_int),
+                ('X1', C.c_void_p), ('X2', C.c_void_p), ('x_bs', LL),
+                ('g', ConvGeom),
+                ('M', C.c_int), ('C', C.c_int), ('NPIX', C.c_int), ('ntaps', C.c_int), ('batches', C.c_int),
+                ('tile', C.c_int),
+                ('out', C.c_void_p), ('o_img_stride', LL), ('o_bs', LL),
+                ('alpha', C.c_float), ('post_scale', C.c_float),
+                ('bias', C.c_void_p), ('tadd', C.c_void_p), ('tadd_stride', LL),
+                ('res', C.c_void_p), ('r_img_stride', LL),
+                ('accumulate', C.c_int), ('_pad', C.c_int)]
+
+
+class NtGemmParams(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('a_bs', LL), ('a_img_stride', LL),
+                ('X1', C.c_void_p), ('X2', C.c_void_p), ('x_bs', LL),
+                ('g', ConvGeom),
+                ('M', C.c_int), ('C', C.c_int), ('NCOLS', C.c_int), ('ntaps', C.c_int), ('P', C.c_int),
+                ('batches', C.c_int), ('splits', C.c_int), ('p_per_split', C.c_int), ('tile', C.c_int),
+                ('batched', C.c_int),
+                ('out', C.c_void_p), ('o_bs', LL), ('ldo', C.c_int), ('accumulate', C.c_int),
+                ('alpha', C.c_float), ('_pad', C.c_int)]
+
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL
+
+# name -> argtypes (restype is always int); this table is also what the CPU test-suite checks against
+# include/dp_hip.h (every declared symbol must resolve).
+SIGNATURES = {
+    'dp_conv_gemm': [C.POINTER(ConvGemmParams), _vp],
+    'dp_nt_gemm': [C.POINTER(NtGemmParams), _vp],
+    'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
+    'dp_pack_weight': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _vp],
+    'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
+                              _vp, _ll, _vp, _vp],
+    'dp_colsum_accum': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    'dp_rowsum_nc': [_vp, _ll, _i, _i, _i, _vp, _vp],
+    'dp_silu_fwd': [_vp, _vp, _ll, _vp],
+    'dp_silu_bwd': [_vp, _vp, _vp, _ll, _i, _vp],
+    'dp_axpby': [_vp, _f, _vp, _f, _ll, _vp],
+    'dp_copy_strided': [_vp, _ll, _vp, _ll, _i, _ll, _i, _vp],
+    'dp_softmax_fwd': [_vp, _vp, _ll, _i, _vp],
+    'dp_softmax_bwd': [_vp, _vp, _vp, _ll, _i, _f, _vp],
+    'dp_timestep_embedding': [_vp, _i, _i, _i, _f, _f, _vp, _vp],
+    'dp_add_noise': [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
+    'dp_mse_fwd_bwd': [_vp, _vp, _ll, _f, _vp, _vp, _i, _vp],
+    'dp_sum_partials': [_vp, _i, _f, _vp, _vp],
+    'dp_downsum2x2': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],
+    'dp_wg_reduce': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    'dp_sumsq_partials': [_vp, _ll, _vp, _i, _vp],
+    'dp_clip_coef': [_vp, _i, _f, _vp, _vp, _vp],
+    'dp_adam_ema': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
+    'dp_ddim_step': [_vp, _vp, _vp, _f, _f, _f, _i, _vp, _ll, _vp],
+    'dp_version': [],
+}
+
+_lib = None
+
+
+class DpHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdp_hip.so and bind every symbol.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpHipError('libdp_hip.so not found at %s -- run ./build.sh (or __graft_entry__.build()); '
+                         'there is no CPU / PyTorch fallback for the hot path' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        raise DpHipError('%s failed with hipError %d' % (what, err))

@@ -1,0 +1,284 @@
+// HBM-bound elementwise / small-reduction kernels of the sweep: SiLU, softmax, timestep embedding,
+// add_noise, eps-loss (+gradient), nearest-upsample backward, strided copies, DDIM update.
+// All are grid-stride, coalesced (consecutive lanes -> consecutive floats), wave-shuffle reductions.
+#include "dp_common.h"
+
+static inline unsigned dp_grid(long long n, int per_block = 256, unsigned cap = 8192) {
+    long long nb = (n + per_block - 1) / per_block;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+#define GS_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    GS_LOOP(i, n) y[i] = dp_silu(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long long n,
+                                int accumulate) {
+    GS_LOOP(i, n) {
+        const float v = dy[i] * dp_silu_grad(x[i]);
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+extern "C" int dp_silu_fwd(const float* x, float* y, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return DP_LAUNCH_CHECK();
+}
+extern "C" int dp_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, accumulate);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, float a, float* __restrict__ y, float b, long long n) {
+    GS_LOOP(i, n) y[i] = (b == 0.f) ? a * x[i] : a * x[i] + b * y[i];
+}
+extern "C" int dp_axpby(const float* x, float a, float* y, float b, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, n);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ void copy_strided_kernel(const float* __restrict__ src, long long s_stride, float* __restrict__ dst,
+                                    long long d_stride, int N, long long per_img, int accumulate) {
+    const long long total = (long long)N * per_img;
+    GS_LOOP(i, total) {
+        const long long img = i / per_img;
+        const long long r = i - img * per_img;
+        const float v = src[img * s_stride + r];
+        float* d = dst + img * d_stride + r;
+        *d = accumulate ? *d + v : v;
+    }
+}
+extern "C" int dp_copy_strided(const float* src, long long s_stride, float* dst, long long d_stride, int N,
+                               long long per_img, int accumulate, void* stream) {
+    if ((long long)N * per_img <= 0) return 0;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, src,
+                       s_stride, dst, d_stride, N, per_img, accumulate);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over the last dimension, one wavefront per row (cols = 16 ... 1024 in this model family)
+// ---------------------------------------------------------------------------------------------
+#define SM_CACHE 16
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, float* __restrict__ p, long long rows,
+                                                          int cols) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = s + row * cols;
+    float* pr = p + row * cols;
+    if (cols <= 64 * SM_CACHE) {
+        float v[SM_CACHE];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_CACHE; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = (j < cols) ? sr[j] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = dp_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_CACHE; ++i) {
+            const int j = lane + 64 * i;
+            v[i] = (j < cols) ? expf(v[i] - mx) : 0.f;
+            sum += v[i];
+        }
+        sum = dp_wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < SM_CACHE; ++i) {
+            const int j = lane + 64 * i;
+            if (j < cols) pr[j] = v[i] * inv;
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, sr[j]);
+        mx = dp_wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < cols; j += 64) sum += expf(sr[j] - mx);
+        sum = dp_wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < cols; j += 64) pr[j] = expf(sr[j] - mx) * inv;
+    }
+}
+extern "C" int dp_softmax_fwd(const float* s, float* p, long long rows, int cols, void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, rows,
+                       cols);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                          float* __restrict__ ds, long long rows, int cols, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* pr = p + row * cols;
+    const float* dr = dp + row * cols;
+    float* o = ds + row * cols;
+    float dot = 0.f;
+    for (int j = lane; j < cols; j += 64) dot += pr[j] * dr[j];
+    dot = dp_wave_sum(dot);
+    for (int j = lane; j < cols; j += 64) o[j] = scale * pr[j] * (dr[j] - dot);
+}
+extern "C" int dp_softmax_bwd(const float* p, const float* dp, float* ds, long long rows, int cols, float scale,
+                              void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds,
+                       rows, cols, scale);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// timestep embedding (embeddings.py:22-62): out[b][i] = sin/cos(t_b * exp(-ln(P) * k / (half - shift)))
+// ---------------------------------------------------------------------------------------------
+__global__ void temb_kernel(const float* __restrict__ t, int B, int dim, int flip, float freq_shift, float log_period,
+                            float* __restrict__ out) {
+    const int half = dim / 2;
+    const long long total = (long long)B * dim;
+    GS_LOOP(i, total) {
+        const int b = (int)(i / dim);
+        const int j = (int)(i - (long long)b * dim);
+        float v = 0.f;
+        if (j < 2 * half) {
+            const bool second = j >= half;
+            const int k = second ? j - half : j;
+            float e = -log_period * (float)k;
+            e = e / ((float)half - freq_shift);
+            const float arg = t[b] * expf(e);
+            const bool use_cos = flip ? !second : second;
+            v = use_cos ? cosf(arg) : sinf(arg);
+        }
+        out[i] = v;
+    }
+}
+extern "C" int dp_timestep_embedding(const float* t, int B, int dim, int flip_sin_to_cos, float freq_shift, float max_period,
+                                     float* out, void* stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(temb_kernel, dim3(dp_grid((long long)B * dim)), dim3(256), 0, (hipStream_t)stream, t, B, dim,
+                       flip_sin_to_cos, freq_shift, logf(max_period), out);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// add_noise (scheduling_ddpm.py:408-429)
+// ---------------------------------------------------------------------------------------------
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ acp,
+                                 const int64_t* __restrict__ t, int B, long long per_img, float* __restrict__ out) {
+    const long long total = (long long)B * per_img;
+    GS_LOOP(i, total) {
+        const int b = (int)(i / per_img);
+        const float a = acp[t[b]];
+        const float sa = sqrtf(a);
+        const float sb = sqrtf(1.0f - a);
+        out[i] = sa * x0[i] + sb * noise[i];
+    }
+}
+extern "C" int dp_add_noise(const float* x0, const float* noise, const float* acp, const int64_t* t, int B,
+                            long long per_img, float* out, void* stream) {
+    if ((long long)B * per_img <= 0) return 0;
+    hipLaunchKernelGGL(add_noise_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
+                       acp, t, B, per_img, out);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// eps-loss: partial[blk] = sum (out-noise)^2 over a fixed contiguous slice, dout = gscale*(out-noise)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ noise, long long n,
+                                                  float gscale, float* __restrict__ dout, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    long long hi = lo + per;
+    if (hi > n) hi = n;
+    float s = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float d = out[i] - noise[i];
+        s += d * d;
+        if (dout) dout[i] = gscale * d;
+    }
+    s = dp_block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial,
+                              int nblocks, void* stream) {
+    if (n <= 0 || nblocks <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mse_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, noise, n, gscale, dout, partial);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float scale,
+                                                           float* __restrict__ dst) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = dp_block_sum_256(s, red);
+    if (threadIdx.x == 0) dst[0] = s * scale;
+}
+extern "C" int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, dst);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of nearest x2 upsampling: dx[h][w] = sum of the 2x2 block of dy
+// ---------------------------------------------------------------------------------------------
+__global__ void downsum_kernel(const float* __restrict__ dy, long long dy_img_stride, int N, int C, int H, int W,
+                               float* __restrict__ dx, long long dx_img_stride) {
+    const long long per = (long long)C * H * W;
+    const long long total = (long long)N * per;
+    GS_LOOP(i, total) {
+        const long long n = i / per;
+        const long long r = i - n * per;
+        const int w = (int)(r % W);
+        const long long ch = r / W;             // c*H + h
+        const int h = (int)(ch % H);
+        const long long c = ch / H;
+        const float* s = dy + n * dy_img_stride + (c * (2 * H) + 2 * h) * (long long)(2 * W) + 2 * w;
+        dx[n * dx_img_stride + r] = (s[0] + s[1]) + (s[2 * W] + s[2 * W + 1]);
+    }
+}
+extern "C" int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H, int W, float* dx,
+                             long long dx_img_stride, void* stream) {
+    const long long total = (long long)N * C * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(downsum_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_img_stride, N, C, H, W,
+                       dx, dx_img_stride);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDIM update (scheduling_ddim.py:324-370)
+// ---------------------------------------------------------------------------------------------
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ vn,
+                                 float sqrt_a_t, float sqrt_b_t, float sqrt_a_prev, float dir_coef, float stdv, int clip,
+                                 float* __restrict__ out, long long n) {
+    GS_LOOP(i, n) {
+        const float e = eps[i];
+        float x0 = (x[i] - sqrt_b_t * e) / sqrt_a_t;
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float v = sqrt_a_prev * x0 + dir_coef * e;
+        if (vn) v += stdv * vn[i];
+        out[i] = v;
+    }
+}
+extern "C" int dp_ddim_step(const float* x, const float* eps, const float* vnoise, float a_t, float a_prev, float stdv,
+                            int clip, float* out, long long n, void* stream) {
+    if (n <= 0) return 0;
+    // coefficient arithmetic in fp32, in the reference's operation order (0-d fp32 tensors there)
+    const float b_t = 1.0f - a_t;
+    const float sqrt_a_t = powf(a_t, 0.5f);
+    const float sqrt_b_t = powf(b_t, 0.5f);
+    const float sqrt_a_prev = powf(a_prev, 0.5f);
+    const float dir_coef = powf(1.0f - a_prev - stdv * stdv, 0.5f);
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
+                       sqrt_b_t, sqrt_a_prev, dir_coef, stdv, clip, out, n);
+    return DP_LAUNCH_CHECK();
+}

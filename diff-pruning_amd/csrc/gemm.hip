@@ -1,0 +1,453 @@
+// Implicit-GEMM contractions on the CDNA4 matrix cores in exact fp32
+// (v_mfma_f32_32x32x2_f32: one rounding per product, bitwise an fmaf chain; 157 TFLOP/s dense peak).
+//
+//   conv_gemm : D[m][pix] = sum_{tap,c} A(tap,c,m) * X(pix,tap,c)        (forward / dgrad / linear / QK^T / dP)
+//   nt_gemm   : D[m][n]   = sum_{pix}   A[m][pix]  * X(pix, n=(c,tap))   (wgrad / P.V / dQ), split over pix
+//
+// 256-thread workgroups (4 wavefronts, 2x2), 32x32x2 MFMA tiles, LDS double buffering with one
+// barrier per K-tile: global loads for tile i+1 are issued before the MFMAs of tile i and committed
+// to the other LDS buffer afterwards.  LDS images are laid out so that every ds_read_b32 /
+// ds_write_b32 lane group touches 32 distinct banks ([k][m] for m-contiguous operands, [m][BK+1]
+// for k-contiguous ones).
+#include "dp_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// MFMA core: acc[TM][TN] += A_tile * B_tile for one LDS-resident K-tile.
+// A_KC: As[m*(BK+1) + k]  else As[k*BM + m];   B_KC: Bs[n*(BK+1) + k]  else Bs[k*BN + n].
+// mfma_f32_32x32x2f32 operand map: a = A[i = lane&31][k = lane>>5], b = B[k = lane>>5][j = lane&31].
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int TM, int TN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int li = lane & 31;
+    const int lk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+        const int kk = ks * 2 + lk;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m = wm0 + tm * 32 + li;
+            a[tm] = A_KC ? As[m * (BK + 1) + kk] : As[kk * BM + m];
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = wn0 + tn * 32 + li;
+            b[tn] = B_KC ? Bs[n * (BK + 1) + kk] : Bs[kk * BN + n];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool A_KC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_params p) {
+    constexpr int BK = 16;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_SZ = A_KC ? BM * (BK + 1) : BK * BM;
+    constexpr int B_SZ = BK * BN;
+    constexpr int STAGE = A_SZ + B_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+
+    const ConvGeom& g = p.g;
+    const int HoWo = g.Ho * g.Wo;
+    const int HsWs = g.Hs * g.Ws;
+    const int C = p.C;
+    const int nch = (C + BK - 1) / BK;
+    const int nIter = p.ntaps * nch;
+
+    const float* __restrict__ Ab = p.A + (long long)z * p.a_bs;
+    const float* __restrict__ X1 = p.X1 + (long long)z * p.x_bs;
+    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)z * p.x_bs : nullptr;
+
+    // ---- B loader: this thread owns pixel column bn of the tile for the whole K loop
+    constexpr int NB = BK * BN / 256;
+    constexpr int BROWS = 256 / BN;            // k rows covered per pass
+    const int bn = tid % BN;
+    const int bk0 = tid / BN;
+    const int bpix = n0 + bn;
+    const bool bpv = bpix < p.NPIX;
+    int b_ho = 0, b_wo = 0;
+    long long b_img1 = 0, b_img2 = 0;
+    {
+        const int pp = bpv ? bpix : 0;
+        const int img = pp / HoWo;
+        const int r = pp - img * HoWo;
+        b_ho = r / g.Wo;
+        b_wo = r - b_ho * g.Wo;
+        b_img1 = (long long)img * g.x1_img_stride;
+        b_img2 = (long long)img * g.x2_img_stride;
+    }
+
+    // ---- A loader
+    constexpr int NA4 = A_KC ? 1 : (BK * BM / 4 / 256);      // float4 per thread (m-contiguous)
+    constexpr int NAS = A_KC ? (BM * BK / 256) : 1;          // scalars per thread (k-contiguous)
+    float4 ra4[NA4];
+    float ras[NAS];
+    float rb[NB];
+
+    auto load_tile = [&](int it) {
+        const int tap = it / nch;
+        const int c0 = (it - tap * nch) * BK;
+        // A
+        if constexpr (!A_KC) {
+#pragma unroll
+            for (int j = 0; j < NA4; ++j) {
+                const int e = tid + 256 * j;
+                const int k = e / (BM / 4);
+                const int m = m0 + 4 * (e % (BM / 4));
+                const bool v = (c0 + k < C) && (m < p.lda);
+                ra4[j] = v ? *reinterpret_cast<const float4*>(Ab + (long long)(tap * C + c0 + k) * p.lda + m)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NAS; ++j) {
+                const int k = tid & (BK - 1);
+                const int m = m0 + (tid / BK) + (256 / BK) * j;
+                const bool v = (m < p.M) && (c0 + k < C);
+                ras[j] = v ? Ab[(long long)m * p.lda + c0 + k] : 0.f;
+            }
+        }
+        // B
+        const int ky = tap / g.kw;
+        const int kx = tap - ky * g.kw;
+        int off;
+        const bool tv = dp_gather(g, b_ho, b_wo, ky, kx, off) && bpv;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int c = c0 + bk0 + BROWS * j;
+            const bool v = tv && (c < C);
+            float val = 0.f;
+            if (v) {
+                if (c < g.c_split) val = X1[b_img1 + (long long)c * HsWs + off];
+                else               val = X2[b_img2 + (long long)(c - g.c_split) * HsWs + off];
+            }
+            rb[j] = val;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_SZ;
+        if constexpr (!A_KC) {
+#pragma unroll
+            for (int j = 0; j < NA4; ++j) {
+                const int e = tid + 256 * j;
+                const int k = e / (BM / 4);
+                const int m = 4 * (e % (BM / 4));
+                *reinterpret_cast<float4*>(As + k * BM + m) = ra4[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NAS; ++j) {
+                const int k = tid & (BK - 1);
+                const int m = (tid / BK) + (256 / BK) * j;
+                As[m * (BK + 1) + k] = ras[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Bs[(bk0 + BROWS * j) * BN + bn] = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < nIter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIter) load_tile(it + 1);
+        const float* As = smem + buf * STAGE;
+        mfma_tile<BM, BN, BK, TM, TN, A_KC, false>(As, As + A_SZ, wm0, wn0, lane, acc);
+        if (it + 1 < nIter) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 tile: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* __restrict__ outb = p.out + (long long)z * p.o_bs;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pix = n0 + wn0 + tn * 32 + (lane & 31);
+        if (pix >= p.NPIX) continue;
+        const int img = pix / HoWo;
+        const int r_in = pix - img * HoWo;
+        const long long obase = (long long)img * p.o_img_stride + r_in;
+        const long long rbase = (long long)img * p.r_img_stride + r_in;
+        const long long tbase = (long long)img * p.tadd_stride;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[tm][tn][r];
+                if (p.bias) v += p.bias[m];
+                if (p.tadd) v += p.tadd[tbase + m];
+                if (p.res) v += p.res[rbase + (long long)m * HoWo];
+                v *= p.post_scale;
+                float* o = outb + obase + (long long)m * HoWo;
+                if (p.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
+    dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.batches > 0 ? p.batches : 1);
+    if (p.a_kc) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, p);
+    else        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, p);
+    return DP_LAUNCH_CHECK();
+}
+
+extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
+    const dp_conv_gemm_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.M <= 0 || p.NPIX <= 0) return 0;
+    if (!p.a_kc && (p.lda & 3)) return (int)hipErrorInvalidValue;
+    if (p.a_kc && p.ntaps != 1) return (int)hipErrorInvalidValue;
+    switch (p.tile) {
+        case 0: return launch_conv_gemm<128, 128>(p, st);
+        case 1: return launch_conv_gemm<64, 128>(p, st);
+        case 2: return launch_conv_gemm<64, 64>(p, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// nt_gemm
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p) {
+    constexpr int BK = 32;
+    constexpr int LD = BK + 1;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_SZ = BM * LD;
+    constexpr int B_SZ = BN * LD;
+    constexpr int STAGE = A_SZ + B_SZ;
+    __shared__ float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+
+    const ConvGeom& g = p.g;
+    const int HoWo = g.Ho * g.Wo;
+    const int HsWs = g.Hs * g.Ws;
+    const int batch = p.batched ? z : 0;
+    const int p_begin = p.batched ? 0 : z * p.p_per_split;
+    int p_end = p.batched ? p.P : (p_begin + p.p_per_split);
+    if (p_end > p.P) p_end = p.P;
+    const int nIter = (p_end > p_begin) ? (p_end - p_begin + BK - 1) / BK : 0;
+
+    const float* __restrict__ Ab = p.A + (long long)batch * p.a_bs;
+    const float* __restrict__ X1 = p.X1 + (long long)batch * p.x_bs;
+    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)batch * p.x_bs : nullptr;
+
+    constexpr int NA = BM / 8;
+    constexpr int NB = BN / 8;
+    const int lk = tid & 31;       // this thread's k (pixel) within the K-tile
+    const int r0 = tid >> 5;       // first row; rows r0 + 8*j
+    float ra[NA], rb[NB];
+
+    // column decode (fixed per thread): n -> (c, ky, kx), packed as c*16 + ky*4 + kx (-1 = out of range)
+    int bcode[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = n0 + r0 + 8 * j;
+        const int c = col / p.ntaps;
+        const int tap = col - c * p.ntaps;
+        const int ky = tap / g.kw;
+        const int kx = tap - ky * g.kw;
+        bcode[j] = (col < p.NCOLS) ? (c * 16 + ky * 4 + kx) : -1;
+    }
+
+    auto load_tile = [&](int it) {
+        const int pp = p_begin + it * BK + lk;
+        const bool pv = pp < p_end;
+        const int pq = pv ? pp : 0;
+        const int img = pq / HoWo;
+        const int r = pq - img * HoWo;
+        const int ho = r / g.Wo;
+        const int wo = r - ho * g.Wo;
+        const long long abase = (long long)img * p.a_img_stride + r;
+        const long long i1 = (long long)img * g.x1_img_stride;
+        const long long i2 = (long long)img * g.x2_img_stride;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + r0 + 8 * j;
+            ra[j] = (pv && m < p.M) ? Ab[abase + (long long)m * HoWo] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int off;
+            const int code = bcode[j];
+            const bool v = pv && (code >= 0) && dp_gather(g, ho, wo, (code >> 2) & 3, code & 3, off);
+            float val = 0.f;
+            if (v) {
+                const int c = code >> 4;
+                if (c < g.c_split) val = X1[i1 + (long long)c * HsWs + off];
+                else               val = X2[i2 + (long long)(c - g.c_split) * HsWs + off];
+            }
+            rb[j] = val;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_SZ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) As[(r0 + 8 * j) * LD + lk] = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Bs[(r0 + 8 * j) * LD + lk] = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (nIter > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nIter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIter) load_tile(it + 1);
+        const float* As = smem + buf * STAGE;
+        mfma_tile<BM, BN, BK, TM, TN, true, true>(As, As + A_SZ, wm0, wn0, lane, acc);
+        if (it + 1 < nIter) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* __restrict__ outb = p.out + (long long)z * p.o_bs;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn0 + tn * 32 + (lane & 31);
+        if (col >= p.NCOLS) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float* o = outb + (long long)m * p.ldo + col;
+                float v = p.alpha * acc[tm][tn][r];
+                if (p.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
+    const int gz = p.batched ? p.batches : p.splits;
+    dim3 grid((p.NCOLS + BN - 1) / BN, (p.M + BM - 1) / BM, gz > 0 ? gz : 1);
+    hipLaunchKernelGGL((nt_gemm_kernel<BM, BN>), grid, dim3(256), 0, st, p);
+    return DP_LAUNCH_CHECK();
+}
+
+extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
+    const dp_nt_gemm_params& p = *pp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.M <= 0 || p.NCOLS <= 0) return 0;
+    if (!p.batched && (p.p_per_split <= 0 || (p.p_per_split & 31))) return (int)hipErrorInvalidValue;
+    switch (p.tile) {
+        case 0: return launch_nt_gemm<128, 128>(p, st);
+        case 1: return launch_nt_gemm<64, 128>(p, st);
+        case 2: return launch_nt_gemm<64, 64>(p, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K epilogue: out[i] (+)= sum_s ws[s*stride + i]  in ascending s (deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, long long stride, int splits,
+                                                            float* __restrict__ out, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(long long)k * stride + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+extern "C" int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate,
+                                void* stream) {
+    if (n <= 0) return 0;
+    long long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits, out,
+                       n, accumulate);
+    return DP_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (A operand of conv_gemm)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ W, int Co, int Ci, int taps, int mode,
+                                                          float* __restrict__ dst, int ld) {
+    // one thread per destination element; destination is [taps][K][ld]
+    const int K = mode == 0 ? Ci : Co;     // reduction rows per tap
+    const int Mv = mode == 0 ? Co : Ci;    // valid columns
+    const long long total = (long long)taps * K * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i % ld);
+        const long long rk = i / ld;
+        const int k = (int)(rk % K);
+        const int tap = (int)(rk / K);
+        float v = 0.f;
+        if (m < Mv) {
+            if (mode == 0) v = W[((long long)m * Ci + k) * taps + tap];
+            else           v = W[((long long)k * Ci + m) * taps + (taps - 1 - tap)];
+        }
+        dst[i] = v;
+    }
+}
+
+extern "C" int dp_pack_weight(const float* W, int Co, int Ci, int taps, int mode, float* dst, int ld, void* stream) {
+    const int K = mode == 0 ? Ci : Co;
+    const long long total = (long long)taps * K * ld;
+    if (total <= 0) return 0;
+    long long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, taps, mode, dst,
+                       ld);
+    return DP_LAUNCH_CHECK();
+}
+
+extern "C" int dp_version(void) { return 100; }

@@ -1,0 +1,240 @@
+// GroupNorm (+SiLU) forward / backward over channel-major (NCHW, explicit image stride) activations.
+// HBM-bound: one workgroup per (image, group); the group's chunk (cpg*HW contiguous floats per source)
+// is held in registers when it fits (<= 8192 elements: every CIFAR-32 shape), otherwise streamed
+// three times (mean, variance, apply) with the re-reads served by L2.  Reductions: wave shuffles then
+// a fixed-order 4-way LDS combine, so results are run-to-run deterministic.
+// The input may be a *virtual concat* of two tensors along channels (up-block torch.cat, unet_2d_blocks.py:2035).
+#include "dp_common.h"
+
+#define GN_CACHE 32          // elements per thread kept in registers (256 threads -> 8192 per chunk)
+#define GN_MAXCPG 64
+
+struct GnSrc {
+    const float* x1; const float* x2; int c_split; long long s1, s2;
+};
+
+__device__ __forceinline__ const float* gn_chan_ptr(const GnSrc& s, int n, int c, int HW) {
+    return (c < s.c_split) ? s.x1 + (long long)n * s.s1 + (long long)c * HW
+                           : s.x2 + (long long)n * s.s2 + (long long)(c - s.c_split) * HW;
+}
+
+__global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int C, int HW, int G, float eps, int silu, float* __restrict__ y,
+                                                     long long y_img_stride, float* __restrict__ stats) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / G;
+    const int g = blockIdx.x - n * G;
+    const int cpg = C / G;
+    const int cnt = cpg * HW;
+    const int tid = threadIdx.x;
+    const bool cached = cnt <= 256 * GN_CACHE;
+    const int c_base = g * cpg;
+
+    float xr[GN_CACHE];
+    float s = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE; ++i) {
+            const int e = tid + 256 * i;
+            float v = 0.f;
+            if (e < cnt) {
+                const int cl = e / HW;
+                v = gn_chan_ptr(src, n, c_base + cl, HW)[e - cl * HW];
+            }
+            xr[i] = v;
+            s += v;
+        }
+    } else {
+        for (int e = tid; e < cnt; e += 256) {
+            const int cl = e / HW;
+            s += gn_chan_ptr(src, n, c_base + cl, HW)[e - cl * HW];
+        }
+    }
+    const float mean = dp_block_sum_256(s, red) / (float)cnt;
+    float q = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE; ++i) {
+            const int e = tid + 256 * i;
+            const float d = xr[i] - mean;
+            if (e < cnt) q += d * d;
+        }
+    } else {
+        for (int e = tid; e < cnt; e += 256) {
+            const int cl = e / HW;
+            const float d = gn_chan_ptr(src, n, c_base + cl, HW)[e - cl * HW] - mean;
+            q += d * d;
+        }
+    }
+    const float var = dp_block_sum_256(q, red) / (float)cnt;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (tid == 0) {
+        stats[(long long)blockIdx.x * 2 + 0] = mean;
+        stats[(long long)blockIdx.x * 2 + 1] = rstd;
+    }
+    float* yb = y + (long long)n * y_img_stride + (long long)c_base * HW;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE; ++i) {
+            const int e = tid + 256 * i;
+            if (e < cnt) {
+                const int c = c_base + e / HW;
+                float v = (xr[i] - mean) * rstd * gamma[c] + beta[c];
+                if (silu) v = dp_silu(v);
+                yb[e] = v;
+            }
+        }
+    } else {
+        for (int e = tid; e < cnt; e += 256) {
+            const int cl = e / HW;
+            const int c = c_base + cl;
+            float v = (gn_chan_ptr(src, n, c, HW)[e - cl * HW] - mean) * rstd * gamma[c] + beta[c];
+            if (silu) v = dp_silu(v);
+            yb[e] = v;
+        }
+    }
+}
+
+extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
+                                     long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
+                                     int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
+                                     void* stream) {
+    if (N <= 0 || C <= 0) return 0;
+    if (C % G) return (int)hipErrorInvalidValue;
+    GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
+    hipLaunchKernelGGL(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu, y,
+                       y_img_stride, stats);
+    return DP_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+//   yhat = xhat*gamma + beta;  dy = silu ? dz * silu'(yhat) : dz
+//   S1_c = sum_hw dy, S2_c = sum_hw dy*xhat          -> pws (per image, reduced over images later)
+//   a = sum_c gamma_c S1_c, b = sum_c gamma_c S2_c, M = cpg*HW
+//   dx = rstd * (gamma_c*dy - a/M - xhat*b/M)  (+ add1) (+ add2)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ stats, const float* __restrict__ dz,
+                                                     long long dz_img_stride, int C, int HW, int G, int silu,
+                                                     float* __restrict__ dx, long long dx_img_stride,
+                                                     const float* __restrict__ add1, long long add1_s,
+                                                     const float* __restrict__ add2, long long add2_s,
+                                                     float* __restrict__ pws) {
+    __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
+    const int n = blockIdx.x / G;
+    const int g = blockIdx.x - n * G;
+    const int cpg = C / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c_base = g * cpg;
+    const float mean = stats[(long long)blockIdx.x * 2 + 0];
+    const float rstd = stats[(long long)blockIdx.x * 2 + 1];
+    const float* dzb = dz + (long long)n * dz_img_stride;
+
+    // pass 1: per-channel sums, one wavefront per channel
+    for (int cl = wave; cl < cpg; cl += 4) {
+        const int c = c_base + cl;
+        const float* xp = gn_chan_ptr(src, n, c, HW);
+        const float* dp = dzb + (long long)c * HW;
+        const float ga = gamma[c], be = beta[c];
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = lane; i < HW; i += 64) {
+            const float xh = (xp[i] - mean) * rstd;
+            float d = dp[i];
+            if (silu) d *= dp_silu_grad(xh * ga + be);
+            a1 += d;
+            a2 += d * xh;
+        }
+        a1 = dp_wave_sum(a1);
+        a2 = dp_wave_sum(a2);
+        if (lane == 0) {
+            s1[cl] = a1;
+            s2[cl] = a2;
+            pws[((long long)n * C + c) * 2 + 0] = a1;
+            pws[((long long)n * C + c) * 2 + 1] = a2;
+        }
+    }
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga = gamma[c_base + cl];
+        a += ga * s1[cl];
+        b += ga * s2[cl];
+    }
+    const float invM = 1.0f / (float)(cpg * HW);
+    a *= invM;
+    b *= invM;
+
+    // pass 2
+    const int cnt = cpg * HW;
+    float* dxb = dx + (long long)n * dx_img_stride + (long long)c_base * HW;
+    const float* a1b = add1 ? add1 + (long long)n * add1_s + (long long)c_base * HW : nullptr;
+    const float* a2b = add2 ? add2 + (long long)n * add2_s + (long long)c_base * HW : nullptr;
+    for (int e = tid; e < cnt; e += 256) {
+        const int cl = e / HW;
+        const int c = c_base + cl;
+        const float xh = (gn_chan_ptr(src, n, c, HW)[e - cl * HW] - mean) * rstd;
+        const float ga = gamma[c];
+        float d = dzb[(long long)c_base * HW + e];
+        if (silu) d *= dp_silu_grad(xh * ga + beta[c]);
+        float v = rstd * (ga * d - a - xh * b);
+        if (a1b) v += a1b[e];
+        if (a2b) v += a2b[e];
+        dxb[e] = v;
+    }
+}
+
+extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
+                                     long long x2_img_stride, const float* gamma, const float* beta, const float* stats,
+                                     const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
+                                     float* dx, long long dx_img_stride, const float* add1, long long add1_img_stride,
+                                     const float* add2, long long add2_img_stride, float* pws, void* stream) {
+    if (N <= 0 || C <= 0) return 0;
+    if (C % G || C / G > GN_MAXCPG) return (int)hipErrorInvalidValue;
+    GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                       dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, pws);
+    return DP_LAUNCH_CHECK();
+}
+
+// out[c*1] (+)= sum_n ws[(n*C + c)*wstride + woff]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, int N, int C, int wstride, int woff,
+                                                     float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += ws[((long long)n * C + c) * wstride + woff];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate,
+                               void* stream) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, N, C, wstride, woff, out,
+                       accumulate);
+    return DP_LAUNCH_CHECK();
+}
+
+// rows[n*C + c] = sum_hw x[n*img_stride + c*HW + hw]   (one wavefront per (n,c) plane)
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, long long img_stride, int N, int C, int HW,
+                                                     float* __restrict__ rows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)N * C) return;
+    const int n = (int)(row / C);
+    const int c = (int)(row - (long long)n * C);
+    const float* p = x + (long long)n * img_stride + (long long)c * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x & 63; i < HW; i += 64) s += p[i];
+    s = dp_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) rows[row] = s;
+}
+
+extern "C" int dp_rowsum_nc(const float* x, long long img_stride, int N, int C, int HW, float* rows, void* stream) {
+    const long long nrows = (long long)N * C;
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, img_stride, N,
+                       C, HW, rows);
+    return DP_LAUNCH_CHECK();
+}

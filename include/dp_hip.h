@@ -1,0 +1,158 @@
+/* dp_hip.h -- C-ABI of the MI355X-native Diff-Pruning hot path (libdp_hip.so).
+ *
+ * The reference (VainF/Diff-Pruning) is pure Python on top of ATen; it has no FFI of its own.  The
+ * boundary a maintainer would bind is therefore the set of ATen calls its hot path makes; each entry
+ * point below names the reference call site it replaces (paths relative to the reference root).
+ * All pointers are DEVICE pointers owned by the caller (PyTorch owns every allocation); `stream` is a
+ * hipStream_t passed as void*; every function only enqueues work on `stream` and returns a
+ * hipError_t-style int (0 = success).  Nothing here throws, allocates or synchronises.
+ *
+ * Activation layout everywhere: channel-major planes, element (img, c, h, w) at
+ *     base + img*img_stride + c*H*W + h*W + w          (NCHW with an explicit image stride)
+ * Linear layers on [B, C] vectors use the same convention with H = W = 1.
+ */
+#ifndef DP_HIP_H
+#define DP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Gather geometry shared by the implicit-GEMM kernels (see csrc/dp_common.h ConvGeom). */
+typedef struct dp_conv_geom {
+    int Ho, Wo, Hs, Ws, Hv, Wv, kw, stride, sden, pad_t, pad_l, ups, c_split, _pad;
+    long long x1_img_stride, x2_img_stride;
+} dp_conv_geom;
+
+/* D[m][pix] = sum_{tap,c} A(tap,c,m) * X(pix,tap,c)  -- conv3x3 / conv1x1 / linear forward and dgrad,
+ * attention QK^T and dP (batched).  Replaces F.conv2d / F.linear / torch.baddbmm forward and the
+ * input-gradient half of ConvolutionBackward / AddmmBackward:
+ *   diffusers/models/resnet.py:606,630,633 (conv1, conv2, conv_shortcut), :612 (time_emb_proj),
+ *   diffusers/models/resnet.py:166,218 (Upsample2D/Downsample2D conv), unet_2d.py:273,304 (conv_in/out),
+ *   diffusers/models/attention_processor.py:438-445 (to_q/k/v), :339-345 (baddbmm), :455 (to_out).
+ * a_kc = 0: A is a packed weight  A[(tap*C + c)*lda + m]  (m contiguous, lda % 4 == 0, zero padded)
+ * a_kc = 1: A[m*lda + c]  (c contiguous; taps must be 1)
+ * Epilogue: v = alpha*acc (+bias[m]) (+tadd[img*tadd_stride + m]) (+res[img*r_img_stride + m*HoWo + r]);
+ *           v *= post_scale; out = accumulate ? out + v : v. */
+typedef struct dp_conv_gemm_params {
+    const float* A; long long a_bs; int lda; int a_kc;
+    const float* X1; const float* X2; long long x_bs;
+    dp_conv_geom g;
+    int M, C, NPIX, ntaps, batches, tile;      /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
+    float* out; long long o_img_stride; long long o_bs;
+    float alpha; float post_scale;
+    const float* bias; const float* tadd; long long tadd_stride;
+    const float* res; long long r_img_stride;
+    int accumulate; int _pad;
+} dp_conv_gemm_params;
+int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
+
+/* D[m][n] = alpha * sum_pix A[m][pix] * X(pix, n=(c,tap))  -- weight gradients (split over pixels) and the
+ * k-contiguous batched products of attention (P.V, dQ).  Replaces the weight-gradient half of
+ * ConvolutionBackward / AddmmBackward reached from loss.backward() (ddpm_prune.py:102) and torch.bmm
+ * (attention_processor.py:446).
+ * A element (m, pix=(img,r)) at A + z*a_bs + img*a_img_stride + m*HoWo + r.
+ * batched = 1: blockIdx.z = batch, output out[z*o_bs + m*ldo + n];
+ * batched = 0: blockIdx.z = split over pixels, partial sums to out[split*o_bs + m*ldo + n]
+ *              (reduce with dp_splitk_reduce), or direct (+accumulate) when splits == 1. */
+typedef struct dp_nt_gemm_params {
+    const float* A; long long a_bs; long long a_img_stride;
+    const float* X1; const float* X2; long long x_bs;
+    dp_conv_geom g;
+    int M, C, NCOLS, ntaps, P, batches, splits, p_per_split, tile, batched;   /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
+    float* out; long long o_bs; int ldo; int accumulate;
+    float alpha; int _pad;
+} dp_nt_gemm_params;
+int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
+
+/* out[i] (+)= sum_s ws[s*stride + i], fixed summation order (deterministic split-K epilogue). */
+int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate, void* stream);
+
+/* Weight packing for dp_conv_gemm's A operand.  W is a torch Conv2d/Linear weight [Co][Ci][taps].
+ * mode 0 (forward): dst[(tap*Ci + ci)*ld + co] = W[co][ci][tap],            ld = roundup4(Co)
+ * mode 1 (dgrad)  : dst[(tap*Co + co)*ld + ci] = W[co][ci][taps-1-tap],     ld = roundup4(Ci)
+ * dst must hold taps*K*ld floats; padding columns are written as zeros. */
+int dp_pack_weight(const float* W, int Co, int Ci, int taps, int mode, float* dst, int ld, void* stream);
+
+/* GroupNorm (+ optional SiLU) forward over a (virtually concatenated) NCHW tensor.
+ * Replaces F.group_norm + F.silu: resnet.py:596-598,622-628, unet_2d.py:302-303, attention_processor.py:433.
+ * Channel c < c_split is read from x1 (image stride x1_img_stride), else from x2.  y is contiguous
+ * [N][C][HW] with image stride y_img_stride.  stats[(n*G+g)*2 + {0,1}] = {mean, rstd}. */
+int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
+                          const float* gamma, const float* beta, int N, int C, int HW, int G, float eps, int silu,
+                          float* y, long long y_img_stride, float* stats, void* stream);
+
+/* Backward of the above.  dz = gradient w.r.t. the (SiLU'd) output, image stride dz_img_stride.
+ * dx (image stride dx_img_stride) = gn_backward(dz) (+ add1) (+ add2); add tensors carry their own image
+ * strides.  pws[(n*C + c)*2 + {0,1}] = per-image sums {sum dy, sum dy*xhat} (reduce over n with
+ * dp_colsum_accum to obtain dbeta / dgamma).  Replaces NativeGroupNormBackward + SiluBackward. */
+int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
+                          const float* gamma, const float* beta, const float* stats, const float* dz, long long dz_img_stride,
+                          int N, int C, int HW, int G, int silu,
+                          float* dx, long long dx_img_stride,
+                          const float* add1, long long add1_img_stride, const float* add2, long long add2_img_stride,
+                          float* pws, void* stream);
+
+/* out[c*ostride] (+)= sum_n ws[(n*C + c)*wstride + woff]   (deterministic, n ascending) */
+int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate, void* stream);
+
+/* rows[n*C + c] = sum_hw x[n*img_stride + c*HW + hw]  (bias / time-embedding-projection gradients) */
+int dp_rowsum_nc(const float* x, long long img_stride, int N, int C, int HW, float* rows, void* stream);
+
+/* y = silu(x) ; dx = dy * silu'(x)   (resnet.py:611 nonlinearity(temb), embeddings.py:206 act) */
+int dp_silu_fwd(const float* x, float* y, long long n, void* stream);
+int dp_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream);
+
+/* y = a*x + b*y  (elementwise) */
+int dp_axpby(const float* x, float a, float* y, float b, long long n, void* stream);
+/* strided plane copy / add: dst[img*d_stride + i] (+)= src[img*s_stride + i], i < per_img */
+int dp_copy_strided(const float* src, long long s_stride, float* dst, long long d_stride, int N, long long per_img, int accumulate, void* stream);
+
+/* Row softmax over the last dim (in place allowed).  attention_processor.py:350-353. */
+int dp_softmax_fwd(const float* s, float* p, long long rows, int cols, void* stream);
+/* ds = scale * p * (dp - sum_j p_j dp_j)   (SoftmaxBackward followed by the baddbmm alpha) */
+int dp_softmax_bwd(const float* p, const float* dp, float* ds, long long rows, int cols, float scale, void* stream);
+
+/* Sinusoidal timestep embedding, out[b][dim] (embeddings.py:22-62).  t given as float (timesteps.float()). */
+int dp_timestep_embedding(const float* t, int B, int dim, int flip_sin_to_cos, float freq_shift, float max_period, float* out, void* stream);
+
+/* noisy = sqrt(acp[t_b]) * x0 + sqrt(1 - acp[t_b]) * noise   (scheduling_ddpm.py:408-429) */
+int dp_add_noise(const float* x0, const float* noise, const float* acp, const int64_t* t, int B, long long per_img, float* out, void* stream);
+
+/* loss partial sums + dOut for the eps-prediction loss.
+ * dout = gscale * (out - noise);  partial[block] = sum (out-noise)^2 over the block's slice.
+ * F.mse_loss (ddpm_prune.py:101): gscale = 2/numel;  sum-CHW/mean-B loss (ddpm_train.py:459): gscale = 2/B. */
+int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial, int nblocks, void* stream);
+/* dst[0] = scale * sum_i partial[i]  (single block, fixed order) */
+int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* stream);
+
+/* dx[n][c][h][w] = sum of the 2x2 block of dy (backward of nearest x2 upsampling, resnet.py:155) */
+int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H, int W, float* dx, long long dx_img_stride, void* stream);
+
+/* Taylor-importance reductions  (ddpm_exp/torch_pruning/importance.py:375-434).
+ * Weight viewed as [R][C][T]; dim = 0: out[r] = sum_{c,t} f(w*g); dim = 1: out[c] = sum_{r,t} f(w*g);
+ * mode 0: f = (w g)^2 (vendored), mode 1: f = |w g| (sum_abs), mode 2: signed sum then |.| (abs_sum),
+ * mode 3: out[i] = |w_i g_i| (GroupNorm member; R = channels, C = T = 1).
+ * out[i] = (accumulate ? out[i] : 0) + value.  `scratch` (>= C*T floats) is required for dim == 1. */
+int dp_wg_reduce(const float* w, const float* g, int R, int C, int T, int dim, int mode, float* out, int accumulate,
+                 float* scratch, void* stream);
+
+/* Fused finetune update over flat buffers (ddpm_train.py:462-469, training_utils.py:201-216):
+ *   g *= clip_coef (clip_coef read from device: min(1, max_norm/(norm+1e-6)));  Adam;  EMA with constant decay. */
+int dp_sumsq_partials(const float* x, long long n, float* partial, int nblocks, void* stream);
+int dp_clip_coef(const float* partial, int n, float max_norm, float* norm_out, float* coef_out, void* stream);
+int dp_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* clip_coef,
+                float lr, float b1, float b2, float eps, float bc1, float bc2, float ema_decay, void* stream);
+
+/* DDIM update (scheduling_ddim.py:324-370, eta = 0 or with supplied noise):
+ *   x0 = clamp((x - sqrt(1-a_t) eps)/sqrt(a_t));  prev = sqrt(a_prev) x0 + sqrt(1-a_prev-std^2) eps (+ std*noise) */
+int dp_ddim_step(const float* x, const float* eps, const float* vnoise, float a_t, float a_prev, float std, int clip,
+                 float* out, long long n, void* stream);
+
+/* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
+int dp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,318 @@
+"""GPU parity tests of every HIP kernel against a float64 PyTorch reference of the same op.
+
+Tolerances are stated per test: fp32 kernels vs an fp64 reference, so the bound is a small multiple of
+fp32 rounding on the accumulated magnitude (1e-5 relative to the output scale unless noted)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    dp = importlib.import_module('diff-pruning_amd')
+    from importlib import import_module
+    o = import_module('diff-pruning_amd.ops')
+    o._lib()
+    return o
+
+
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def relerr(a, ref):
+    ref = ref.double().cpu()
+    a = a.double().cpu()
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def ref_conv(x, w, b, stride, pad, ups, asym):
+    x = x.double().cpu()
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+    if asym:
+        x = F.pad(x, (0, 1, 0, 1))
+    return F.conv2d(x, w.double().cpu(), None if b is None else b.double().cpu(), stride=stride, padding=pad)
+
+
+CONV_CASES = [
+    # name, N, C1, C2, Cout, H, k, stride, pad, ups
+    ('3x3_small', 2, 8, 0, 16, 8, 3, 1, 1, 0),
+    ('3x3_odd', 3, 37, 0, 70, 8, 3, 1, 1, 0),
+    ('3x3_cat', 2, 40, 29, 130, 16, 3, 1, 1, 0),
+    ('3x3_wide', 2, 128, 0, 256, 16, 3, 1, 1, 0),
+    ('3x3_in3', 2, 3, 0, 128, 32, 3, 1, 1, 0),
+    ('3x3_out3', 2, 128, 0, 3, 32, 3, 1, 1, 0),
+    ('1x1_cat', 2, 64, 31, 96, 8, 1, 1, 0, 0),
+    ('1x1_4x4', 16, 179, 0, 192, 4, 1, 1, 0, 0),
+    ('s2_asym', 2, 24, 0, 40, 16, 3, 2, 0, 0),
+    ('s2_sym', 2, 24, 0, 40, 16, 3, 2, 1, 0),
+    ('ups', 2, 24, 0, 40, 8, 3, 1, 1, 1),
+    ('linear', 7, 100, 0, 90, 1, 1, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_dgrad_wgrad(ops, report, case):
+    name, N, C1, C2, Cout, H, k, stride, pad, ups = case
+    Cin = C1 + C2
+    xa = rnd(N, C1, H, H, seed=1)
+    xb = rnd(N, C2, H, H, seed=2) if C2 else None
+    w = rnd(Cout, Cin, k, k, seed=3, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=4)
+    spec = ops.ConvSpec(k, stride, pad, ups)
+    asym = (stride == 2 and pad == 0)
+    xcat = xa if xb is None else torch.cat([xa, xb], 1)
+    ref = ref_conv(xcat, w, b, stride, pad, ups, asym)
+    wp, ld = ops.pack_weight(w, 0)
+    y = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b)
+    e_f = relerr(y, ref)
+    # epilogue: tadd + res + post_scale
+    tadd = rnd(N, Cout, seed=5)
+    res = rnd(*y.shape, seed=6)
+    y2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.5)
+    ref2 = (ref + tadd.double().cpu()[:, :, None, None] + res.double().cpu()) * 0.5
+    e_ep = relerr(y2, ref2)
+    # accumulate into a channel slice of a bigger buffer (free image stride)
+    big = rnd(N, Cout + 5, y.shape[2], y.shape[3], seed=7)
+    big0 = big.clone()
+    ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, out=big[:, 2:2 + Cout], accumulate=True)
+    e_acc = relerr(big[:, 2:2 + Cout], ref + big0[:, 2:2 + Cout].double().cpu())
+    assert torch.equal(big[:, :2], big0[:, :2]) and torch.equal(big[:, 2 + Cout:], big0[:, 2 + Cout:])
+
+    # gradients via fp64 autograd
+    xr = xcat.double().cpu().requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    xin = xr
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode='nearest')
+    if asym:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    yr = F.conv2d(xin, wr, None, stride=stride, padding=pad)
+    dy = rnd(*yr.shape, seed=8)
+    yr.backward(dy.double().cpu())
+    wd, ldd = ops.pack_weight(w, 1)
+    Hv = H << ups
+    dxv = ops.conv_dgrad(dy, wd, ldd, Cin, spec, (Hv, Hv))
+    if ups:
+        dx = ops.downsum2x2(dxv)
+    else:
+        dx = dxv
+    e_d = relerr(dx, xr.grad)
+    gw = torch.zeros_like(w)
+    ops.conv_wgrad(dy, xa, xb, gw, spec, accumulate=False)
+    e_w = relerr(gw, wr.grad)
+    gw2 = w.clone()
+    ops.conv_wgrad(dy, xa, xb, gw2, spec, accumulate=True, alpha=0.5)
+    e_w2 = relerr(gw2, w.double().cpu() + 0.5 * wr.grad)
+    report['conv/' + name] = dict(fwd=e_f, epilogue=e_ep, acc=e_acc, dgrad=e_d, wgrad=e_w, wgrad_acc=e_w2)
+    assert max(e_f, e_ep, e_acc, e_d, e_w, e_w2) < 2e-5, report['conv/' + name]
+
+
+def test_conv_wgrad_splitk_large(ops, report):
+    """Split-K path (many pixels): B*HW = 16384 pixels, deterministic across runs."""
+    N, Cin, Cout, H = 16, 64, 96, 32
+    x = rnd(N, Cin, H, H, seed=11)
+    dy = rnd(N, Cout, H, H, seed=12)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    gw = torch.zeros(Cout, Cin, 3, 3, device=DEV)
+    ops.conv_wgrad(dy, x, None, gw, spec, accumulate=False)
+    gw_b = torch.zeros_like(gw)
+    ops.conv_wgrad(dy, x, None, gw_b, spec, accumulate=False)
+    assert torch.equal(gw, gw_b), 'split-K wgrad must be run-to-run deterministic'
+    xr = x.double().cpu()
+    ref = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, 3, 3), dy.double().cpu(), padding=1)
+    e = relerr(gw, ref)
+    report['conv/wgrad_splitk'] = e
+    assert e < 2e-5
+
+
+@pytest.mark.parametrize('Z,M,K,N', [(3, 64, 40, 64), (2, 256, 256, 256), (5, 16, 179, 16), (2, 256, 179, 256)])
+def test_bmm_variants(ops, report, Z, M, K, N):
+    a_km = rnd(Z, K, M, seed=1)
+    b_kn = rnd(Z, K, N, seed=2)
+    o = ops.bmm_tn(a_km, b_kn, alpha=0.25)
+    e1 = relerr(o, 0.25 * torch.bmm(a_km.double().cpu().transpose(1, 2), b_kn.double().cpu()))
+    a_mk = rnd(Z, M, K, seed=3)
+    o = ops.bmm_nn(a_mk, b_kn)
+    e2 = relerr(o, torch.bmm(a_mk.double().cpu(), b_kn.double().cpu()))
+    b_nk = rnd(Z, N, K, seed=4)
+    o = ops.bmm_nt(a_mk, b_nk)
+    e3 = relerr(o, torch.bmm(a_mk.double().cpu(), b_nk.double().cpu().transpose(1, 2)))
+    report['bmm/%d_%d_%d_%d' % (Z, M, K, N)] = dict(tn=e1, nn=e2, nt=e3)
+    assert max(e1, e2, e3) < 1e-5
+
+
+@pytest.mark.parametrize('N,C1,C2,H,G,silu', [(2, 32, 0, 8, 8, True), (3, 128, 0, 32, 32, True), (2, 100, 92, 4, 32, True),
+                                             (2, 64, 0, 16, 32, False), (1, 128, 0, 128, 32, True)])
+def test_groupnorm(ops, report, N, C1, C2, H, G, silu):
+    xa = rnd(N, C1, H, H, seed=1) + 0.3
+    xb = rnd(N, C2, H, H, seed=2) if C2 else None
+    Cc = C1 + C2
+    gamma = 1 + 0.2 * rnd(Cc, seed=3)
+    beta = 0.1 * rnd(Cc, seed=4)
+    eps = 1e-6
+    y, stats = ops.groupnorm_fwd(xa, xb, gamma, beta, G, eps, silu)
+    xr = (xa if xb is None else torch.cat([xa, xb], 1)).double().cpu().requires_grad_(True)
+    gr = gamma.double().cpu().requires_grad_(True)
+    br = beta.double().cpu().requires_grad_(True)
+    yr = F.group_norm(xr, G, gr, br, eps)
+    if silu:
+        yr = F.silu(yr)
+    e_f = relerr(y, yr.detach())
+    dz = rnd(*y.shape, seed=5)
+    yr.backward(dz.double().cpu())
+    add1 = rnd(*y.shape, seed=6)
+    dx, pws = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, silu, add1=add1)
+    e_dx = relerr(dx, xr.grad + add1.double().cpu())
+    dg = torch.zeros(Cc, device=DEV)
+    db = torch.ones(Cc, device=DEV)
+    ops.colsum_accum(pws, N, Cc, 2, 1, dg, accumulate=False)
+    ops.colsum_accum(pws, N, Cc, 2, 0, db, accumulate=True)
+    e_g = relerr(dg, gr.grad)
+    e_b = relerr(db, br.grad + 1.0)
+    report['gn/%d_%d_%d_%d_%d' % (N, C1, C2, H, int(silu))] = dict(fwd=e_f, dx=e_dx, dgamma=e_g, dbeta=e_b)
+    assert max(e_f, e_dx, e_g, e_b) < 2e-5
+
+
+def test_softmax_silu_misc(ops, report):
+    s = rnd(6, 256, 256, seed=1, scale=3.0)
+    p = ops.softmax_fwd(s)
+    pr = s.double().cpu().softmax(-1)
+    e1 = relerr(p, pr)
+    dp_ = rnd(6, 256, 256, seed=2)
+    sr = s.double().cpu().requires_grad_(True)
+    (sr * 0.125).softmax(-1).backward(dp_.double().cpu())
+    p2 = ops.softmax_fwd(s * 0.125)
+    ds = ops.softmax_bwd(p2, dp_, 0.125)
+    e2 = relerr(ds, sr.grad)
+    s16 = rnd(5, 16, 16, seed=3)
+    e3 = relerr(ops.softmax_fwd(s16), s16.double().cpu().softmax(-1))
+    s2k = rnd(3, 4, 1500, seed=4)
+    e3b = relerr(ops.softmax_fwd(s2k), s2k.double().cpu().softmax(-1))
+    x = rnd(1000, seed=5, scale=3.0)
+    e4 = relerr(ops.silu_fwd(x), F.silu(x.double().cpu()))
+    xr = x.double().cpu().requires_grad_(True)
+    dy = rnd(1000, seed=6)
+    F.silu(xr).backward(dy.double().cpu())
+    e5 = relerr(ops.silu_bwd(x, dy), xr.grad)
+    a = rnd(4, 6, 8, 8, seed=7)
+    rows = ops.rowsum_nc(a[:, 1:5])
+    e6 = relerr(rows, a[:, 1:5].double().cpu().sum((2, 3)))
+    up = rnd(2, 3, 8, 8, seed=8)
+    e7 = relerr(ops.downsum2x2(up), F.avg_pool2d(up.double().cpu(), 2) * 4)
+    y = rnd(300, seed=9)
+    y0 = y.clone()
+    ops.axpby(x[:300].contiguous(), 2.0, y, -0.5)
+    e8 = relerr(y, 2.0 * x[:300].double().cpu() - 0.5 * y0.double().cpu())
+    dst = rnd(3, 10, 4, 4, seed=10)
+    d0 = dst.clone()
+    src = rnd(3, 4, 4, 4, seed=11)
+    ops.copy_strided(src, dst[:, 3:7], accumulate=True)
+    e9 = relerr(dst[:, 3:7], d0[:, 3:7].double().cpu() + src.double().cpu())
+    assert torch.equal(dst[:, :3], d0[:, :3])
+    report['misc'] = dict(softmax=e1, softmax_bwd=e2, softmax16=e3, softmax1500=e3b, silu=e4, silu_bwd=e5, rowsum=e6,
+                          downsum=e7, axpby=e8, copy=e9)
+    assert max(e1, e2, e3, e3b, e4, e5, e6, e7, e8, e9) < 1e-5
+
+
+def test_schedule_kernels_vs_golden(ops, report):
+    import golden_common as gc
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'schedule.npz'))
+    acp = torch.from_numpy(g['alphas_cumprod']).to(DEV)
+    x0 = torch.from_numpy(gc.det_clean((2, 3, 4, 4), 11)).to(DEV)
+    eps = torch.from_numpy(gc.det_noise((2, 3, 4, 4), 12)).to(DEV)
+    worst = 0.0
+    for i, t in enumerate(g['ts']):
+        tt = torch.tensor([int(t), int(t)], dtype=torch.long, device=DEV)
+        out = ops.add_noise(x0, eps, acp, tt)
+        worst = max(worst, float((out.cpu() - torch.from_numpy(g['add_noise'][i])).abs().max()))
+    emb = ops.timestep_embedding(torch.tensor([0.0, 1.0, 999.0], device=DEV), 128, False, 1.0)
+    e_t = float((emb.cpu() - torch.from_numpy(g['temb_128'])).abs().max())
+    emb2 = ops.timestep_embedding(torch.tensor([0.0, 1.0, 999.0], device=DEV), 32, True, 0.0)
+    e_t2 = float((emb2.cpu() - torch.from_numpy(g['temb_32_flip'])).abs().max())
+    report['schedule'] = dict(add_noise_abs=worst, temb_abs=e_t, temb_flip_abs=e_t2)
+    # tolerance: add_noise is 2 mults + 1 add (<= 2 ulp of |x| <= 4); sin/cos of arguments up to 999 rad: 2e-5 abs
+    assert worst < 1e-6 and e_t < 5e-5 and e_t2 < 5e-5
+
+
+def test_mse_wg_adam_ddim(ops, report):
+    out = rnd(8, 3, 32, 32, seed=1)
+    noise = rnd(8, 3, 32, 32, seed=2)
+    n = out.numel()
+    loss, dout = ops.mse_fwd_bwd(out, noise, 2.0 / n, 1.0 / n)
+    ref = F.mse_loss(out.double().cpu(), noise.double().cpu())
+    e1 = abs(float(loss) - float(ref)) / float(ref)
+    e2 = relerr(dout, 2.0 / n * (out.double().cpu() - noise.double().cpu()))
+    # importance reductions
+    w = rnd(70, 37, 3, 3, seed=3)
+    g = rnd(70, 37, 3, 3, seed=4)
+    wg = (w.double().cpu() * g.double().cpu())
+    res = {}
+    for mode, f in ((0, lambda t: t.abs().pow(2)), (1, lambda t: t.abs())):
+        o = torch.zeros(70, device=DEV)
+        ops.wg_reduce(w, g, 0, mode, o, False)
+        res['rows%d' % mode] = relerr(o, f(wg).flatten(1).sum(1))
+        o = torch.ones(37, device=DEV)
+        ops.wg_reduce(w, g, 1, mode, o, True)
+        res['cols%d' % mode] = relerr(o, f(wg).transpose(0, 1).flatten(1).sum(1) + 1.0)
+    o = torch.zeros(70, device=DEV)
+    ops.wg_reduce(w, g, 0, 2, o, False)
+    res['rows2'] = relerr(o, wg.flatten(1).sum(1).abs())
+    o = torch.zeros(37, device=DEV)
+    ops.wg_reduce(w, g, 1, 2, o, False)
+    res['cols2'] = relerr(o, wg.transpose(0, 1).flatten(1).sum(1).abs())
+    wl = rnd(50, 64, seed=5)
+    gl = rnd(50, 64, seed=6)
+    o = torch.zeros(64, device=DEV)
+    ops.wg_reduce(wl, gl, 1, 0, o, False)
+    res['lin_cols'] = relerr(o, (wl.double().cpu() * gl.double().cpu()).pow(2).sum(0))
+    gn_w, gn_g = rnd(96, seed=7), rnd(96, seed=8)
+    o = torch.zeros(96, device=DEV)
+    ops.wg_reduce(gn_w, gn_g, 0, 3, o, False)
+    res['gn'] = relerr(o, (gn_w.double().cpu() * gn_g.double().cpu()).abs())
+    # adam + ema + clip
+    n = 10000
+    p = rnd(n, seed=9)
+    gr = rnd(n, seed=10)
+    m = 0.1 * rnd(n, seed=11)
+    v = (0.1 * rnd(n, seed=12)).abs()
+    ema = rnd(n, seed=13)
+    pr, gd, mr, vr, er = [t.double().cpu().clone() for t in (p, gr, m, v, ema)]
+    partial = ops.sumsq_partials(gr)
+    nc = ops.clip_coef(partial, 1.0)
+    ops.adam_ema(p, gr, m, v, ema, nc[1:2], 2e-4, 0.9, 0.999, 1e-8, 3, 0.9999)
+    tot = gd.pow(2).sum().sqrt()
+    coef = min(1.0, 1.0 / (float(tot) + 1e-6))
+    gd = gd * coef
+    mr = 0.9 * mr + 0.1 * gd
+    vr = 0.999 * vr + 0.001 * gd * gd
+    pr = pr - (2e-4 / (1 - 0.9 ** 3)) * mr / (vr.sqrt() / math.sqrt(1 - 0.999 ** 3) + 1e-8)
+    er = 0.0001 * pr + 0.9999 * er
+    res['adam_p'] = relerr(p, pr)
+    res['adam_m'] = relerr(m, mr)
+    res['adam_v'] = relerr(v, vr)
+    res['ema'] = relerr(ema, er)
+    res['gnorm'] = abs(float(nc[0]) - float(tot)) / float(tot)
+    # ddim
+    x = rnd(2, 3, 8, 8, seed=14)
+    e = rnd(2, 3, 8, 8, seed=15)
+    a_t, a_prev = 0.37, 0.52
+    o = ops.ddim_step(x, e, a_t, a_prev)
+    x0 = ((x.double().cpu() - (1 - a_t) ** 0.5 * e.double().cpu()) / a_t ** 0.5).clamp(-1, 1)
+    res['ddim'] = relerr(o, a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * e.double().cpu())
+    res['mse'] = e1
+    res['mse_grad'] = e2
+    report['scalar_kernels'] = res
+    assert max(res.values()) < 1e-5, res
