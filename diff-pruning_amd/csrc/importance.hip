@@ -84,3 +84,14 @@ extern "C" int dp_wg_reduce(const float* w, const float* g, int R, int C, int T,
     hipLaunchKernelGGL(wg_fold_taps_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, T, mode, out, accumulate);
     return DP_LAUNCH_CHECK();
 }
+
+// dst[i] += src[idx[i]]   (member sums are folded into the group score at the member's channel positions)
+__global__ void gather_add_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[idx[i]];
+}
+extern "C" int dp_gather_add(const float* src, const int64_t* idx, int n, float* dst, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, n, dst);
+    return DP_LAUNCH_CHECK();
+}

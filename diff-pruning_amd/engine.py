@@ -1,0 +1,323 @@
+"""Forward + hand-written backward of UNet2DModel on the HIP kernels (no autograd, no ATen compute).
+
+The engine is *functional* over a flat {diffusers_state_dict_key: device tensor} dictionary -- channel
+counts are read off the tensors, so the same code runs un-pruned and pruned networks -- and mirrors
+`UNet2DModel.forward` of the reference (diffusers/models/unet_2d.py:219-316, resnet.py:589-639,
+attention_processor.py:415-470).  Gradients are *accumulated* (+=) straight into caller-provided
+buffers (normally `param.grad`), which is what the Taylor sweep needs (ddpm_prune.py:102: grads are
+never zeroed between timesteps), fusing the reference's separate `add_` pass into the wgrad epilogue.
+
+Layout: activations are channel-major planes [N, C, H, W] with a free image stride.  `torch.cat`
+(unet_2d_blocks.py:2035) is never materialised: GroupNorm and the 1x1 shortcut read both halves in
+place (two-source gather), and the concat gradient is handed to its two producers as channel-slice views.
+"""
+import torch
+
+from . import ops
+
+_SPEC3 = ops.ConvSpec(3, 1, 1, 0)
+_SPEC1 = ops.ConvSpec(1, 1, 0, 0)
+_SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
+
+
+class _Packs:
+    """Cache of packed (m-contiguous) weight operands, keyed by the identity + version of the source tensor."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, name, w, mode):
+        key = (name, mode)
+        tag = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1], hit[2]
+        buf, ld = ops.pack_weight(w, mode)
+        self._c[key] = (tag, buf, ld)
+        return buf, ld
+
+    def clear(self):
+        self._c.clear()
+
+
+class UNetEngine:
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        self.packs = _Packs()
+        self.P = None      # name -> parameter tensor (device)
+        self.G = None      # name -> gradient accumulation buffer (device), same shapes
+        self.ctx = None
+
+    # ------------------------------------------------------------------------------------------
+    def bind(self, params, grads=None):
+        self.P = params
+        self.G = grads
+
+    def attn_scale(self, channels):
+        hd = self.cfg.get('attention_head_dim')
+        return float(hd if hd is not None else channels) ** -0.5
+
+    # ---- primitive layers ---------------------------------------------------------------------
+    def _conv(self, name, x, x2, spec, **kw):
+        w = self.P[name + '.weight']
+        wp, ld = self.packs.get(name, w, 0)
+        return ops.conv_forward(x, x2, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), **kw)
+
+    def _linear(self, name, x2d, **kw):
+        y = self._conv(name, ops.as4d(x2d), None, _SPEC1, **kw)
+        return y.view(y.shape[0], y.shape[1])
+
+    def _conv_bwd(self, name, dy, x, x2, spec, in_hw, *, need_dx=True, rows=None, dx_out=None, dx_accumulate=False,
+                  alpha=1.0):
+        """Accumulate weight / bias gradients of conv `name`; return gradient w.r.t. its (virtual) input."""
+        w = self.P[name + '.weight']
+        ops.conv_wgrad(dy, x, x2, self.G[name + '.weight'], spec, alpha=alpha, accumulate=True)
+        if (name + '.bias') in self.P:
+            if rows is None:
+                rows = ops.rowsum_nc(dy)
+            if alpha != 1.0:
+                rows = ops.axpby(rows, alpha, torch.empty_like(rows), 0.0)
+            ops.colsum_accum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'], True)
+        if not need_dx:
+            return None
+        wd, ldd = self.packs.get(name, w, 1)
+        return ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
+
+    def _gn_param_grads(self, name, pws):
+        N, C = pws.shape[0], pws.shape[1]
+        ops.colsum_accum(pws, N, C, 2, 1, self.G[name + '.weight'], True)
+        ops.colsum_accum(pws, N, C, 2, 0, self.G[name + '.bias'], True)
+
+    # ---- ResnetBlock2D (resnet.py:589-639) -----------------------------------------------------
+    def resnet_fwd(self, pre, xa, xb, semb, out_scale, save):
+        P, cfg = self.P, self.cfg
+        G, eps = cfg['norm_num_groups'], cfg['norm_eps']
+        n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + '.norm1.weight'], P[pre + '.norm1.bias'], G, eps, True)
+        tproj = self._linear(pre + '.time_emb_proj', semb)
+        h = self._conv(pre + '.conv1', n1, None, _SPEC3, tadd=tproj)
+        n2, st2 = ops.groupnorm_fwd(h, None, P[pre + '.norm2.weight'], P[pre + '.norm2.bias'], G, eps, True)
+        has_sc = (pre + '.conv_shortcut.weight') in P
+        if has_sc:
+            res = self._conv(pre + '.conv_shortcut', xa, xb, _SPEC1)
+        else:
+            if xb is not None:       # identity shortcut over a concat: materialise it (not reached by UNet2DModel configs)
+                res = torch.cat([xa, xb], 1)
+            else:
+                res = xa
+        out = self._conv(pre + '.conv2', n2, None, _SPEC3, res=res, post_scale=1.0 / out_scale)
+        if save is not None:
+            save[pre] = (xa, xb, st1, n1, h, st2, n2, has_sc, out_scale)
+        return out
+
+    def resnet_bwd(self, pre, dout, semb, d_semb, extra=None):
+        """Returns d(input) over the (virtually concatenated) input channels."""
+        xa, xb, st1, n1, h, st2, n2, has_sc, out_scale = self.ctx.pop(pre)
+        P, cfg = self.P, self.cfg
+        G = cfg['norm_num_groups']
+        hw = tuple(h.shape[2:])
+        d = dout
+        if out_scale != 1.0:
+            d = ops.axpby(dout.contiguous(), 1.0 / out_scale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
+        rows_d = ops.rowsum_nc(d)
+        dn2 = self._conv_bwd(pre + '.conv2', d, n2, None, _SPEC3, hw, rows=rows_d)
+        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + '.norm2.weight'], P[pre + '.norm2.bias'], st2, dn2, G, True)
+        self._gn_param_grads(pre + '.norm2', pws2)
+        del dn2
+        # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
+        rows_h = ops.rowsum_nc(dh)
+        self._conv_bwd(pre + '.time_emb_proj', ops.as4d(rows_h), ops.as4d(semb), None, _SPEC1, (1, 1), rows=rows_h,
+                       dx_out=ops.as4d(d_semb), dx_accumulate=True)
+        dn1 = self._conv_bwd(pre + '.conv1', dh, n1, None, _SPEC3, hw, rows=rows_h)
+        del dh
+        if has_sc:
+            add1 = self._conv_bwd(pre + '.conv_shortcut', d, xa, xb, _SPEC1, hw, rows=rows_d)
+        else:
+            add1 = d
+        dx, pws1 = ops.groupnorm_bwd(xa, xb, P[pre + '.norm1.weight'], P[pre + '.norm1.bias'], st1, dn1, G, True,
+                                     add1=add1, add2=extra)
+        self._gn_param_grads(pre + '.norm1', pws1)
+        return dx
+
+    # ---- Attention (attention_processor.py:415-470, heads == 1) ---------------------------------
+    def attn_fwd(self, pre, x, scale, rescale, save):
+        P, cfg = self.P, self.cfg
+        G, eps = cfg['norm_num_groups'], cfg['norm_eps']
+        N, C, H, W = x.shape
+        T = H * W
+        n, st = ops.groupnorm_fwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], G, eps, False)
+        q = self._conv(pre + '.to_q', n, None, _SPEC1)
+        k = self._conv(pre + '.to_k', n, None, _SPEC1)
+        v = self._conv(pre + '.to_v', n, None, _SPEC1)
+        inner = q.shape[1]
+        s = ops.bmm_tn(q.view(N, inner, T), k.view(N, inner, T), alpha=scale)
+        p = ops.softmax_fwd(s, out=s)
+        o = ops.bmm_nt(v.view(N, inner, T), p)
+        out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
+        if save is not None:
+            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale)
+        return out
+
+    def attn_bwd(self, pre, dout, extra=None):
+        x, st, n, q, k, v, p, o, scale, rescale = self.ctx.pop(pre)
+        P, cfg = self.P, self.cfg
+        G = cfg['norm_num_groups']
+        N, C, H, W = x.shape
+        T = H * W
+        inner = q.shape[1]
+        hw = (H, W)
+        d = dout
+        if rescale != 1.0:
+            d = ops.axpby(dout.contiguous(), 1.0 / rescale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
+        do = self._conv_bwd(pre + '.to_out.0', d, o.view(N, inner, H, W), None, _SPEC1, hw)
+        do3 = do.view(N, inner, T)
+        dv = ops.bmm_nn(do3, p)
+        dp = ops.bmm_tn(do3, v.view(N, inner, T))
+        ds = ops.softmax_bwd(p, dp, scale, out=dp)
+        dq = ops.bmm_nt(k.view(N, inner, T), ds)
+        dk = ops.bmm_nn(q.view(N, inner, T), ds)
+        dn = torch.empty_like(n)
+        first = True
+        for dproj, name in ((dq, '.to_q'), (dk, '.to_k'), (dv, '.to_v')):
+            self._conv_bwd(pre + name, dproj.view(N, inner, H, W), n, None, _SPEC1, hw, dx_out=dn, dx_accumulate=not first)
+            first = False
+        dx, pws = ops.groupnorm_bwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], st, dn, G, False,
+                                    add1=d, add2=extra)
+        self._gn_param_grads(pre + '.group_norm', pws)
+        return dx
+
+    # ---- whole network ------------------------------------------------------------------------
+    def forward(self, sample, timesteps, save=False):
+        """sample [B, Cin, H, W] fp32 device tensor, timesteps [B] (int64 or float) device tensor."""
+        P, cfg = self.P, self.cfg
+        boc = list(cfg['block_out_channels'])
+        Lr = cfg['layers_per_block']
+        nb = len(boc)
+        ctx = {} if save else None
+        if cfg.get('center_input_sample', False):
+            sample = 2 * sample - 1.0
+        sample = sample.contiguous()
+        t_emb = ops.timestep_embedding(timesteps.to(torch.float32), boc[0], cfg['flip_sin_to_cos'], cfg['freq_shift'])
+        h1 = self._linear('time_embedding.linear_1', t_emb)
+        a1 = ops.silu_fwd(h1)
+        emb = self._linear('time_embedding.linear_2', a1)
+        semb = ops.silu_fwd(emb)
+        x = self._conv('conv_in', sample, None, _SPEC3)
+        skips = [x]
+        for i, bt in enumerate(cfg['down_block_types']):
+            pre = 'down_blocks.%d' % i
+            for j in range(Lr):
+                x = self.resnet_fwd('%s.resnets.%d' % (pre, j), x, None, semb, 1.0, ctx)
+                if bt == 'AttnDownBlock2D':
+                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(boc[i]), 1.0, ctx)
+                skips.append(x)
+            if i != nb - 1:
+                spec = ops.ConvSpec(3, 2, cfg['downsample_padding'], 0)
+                xin = x
+                x = self._conv(pre + '.downsamplers.0.conv', xin, None, spec)
+                if ctx is not None:
+                    ctx[pre + '.down'] = (xin, spec)
+                skips.append(x)
+        msf = float(cfg.get('mid_block_scale_factor', 1))
+        x = self.resnet_fwd('mid_block.resnets.0', x, None, semb, msf, ctx)
+        if cfg.get('add_attention', True):
+            x = self.attn_fwd('mid_block.attentions.0', x, self.attn_scale(boc[-1]), msf, ctx)
+        x = self.resnet_fwd('mid_block.resnets.1', x, None, semb, msf, ctx)
+        rev = list(reversed(boc))
+        n_skips = len(skips)
+        for i, bt in enumerate(cfg['up_block_types']):
+            pre = 'up_blocks.%d' % i
+            for j in range(Lr + 1):
+                skip = skips.pop()
+                x = self.resnet_fwd('%s.resnets.%d' % (pre, j), x, skip, semb, 1.0, ctx)
+                if bt == 'AttnUpBlock2D':
+                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(rev[i]), 1.0, ctx)
+            if i != nb - 1:
+                xin = x
+                x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC_UP)
+                if ctx is not None:
+                    ctx[pre + '.up'] = xin
+        G, eps = cfg['norm_num_groups'], cfg['norm_eps']
+        xo = x
+        no, sto = ops.groupnorm_fwd(xo, None, P['conv_norm_out.weight'], P['conv_norm_out.bias'], G, eps, True)
+        out = self._conv('conv_out', no, None, _SPEC3)
+        if ctx is not None:
+            ctx['_head'] = (sample, t_emb, h1, a1, emb, semb, xo, no, sto, n_skips)
+            self.ctx = ctx
+        return out
+
+    def backward(self, dout):
+        """Accumulate d(loss)/d(param) into self.G given d(loss)/d(output).  Consumes the saved context."""
+        P, cfg, ctx = self.P, self.cfg, self.ctx
+        assert ctx is not None, 'forward(save=True) must precede backward()'
+        boc = list(cfg['block_out_channels'])
+        Lr = cfg['layers_per_block']
+        nb = len(boc)
+        G = cfg['norm_num_groups']
+        sample, t_emb, h1, a1, emb, semb, xo, no, sto, n_skips = ctx.pop('_head')
+        d_semb = torch.zeros_like(semb)
+        hw = tuple(xo.shape[2:])
+        dno = self._conv_bwd('conv_out', dout, no, None, _SPEC3, hw)
+        dx, pws = ops.groupnorm_bwd(xo, None, P['conv_norm_out.weight'], P['conv_norm_out.bias'], sto, dno, G, True)
+        self._gn_param_grads('conv_norm_out', pws)
+        del dno
+        skip_grads = []          # filled in pop order: skip_grads[k] is the gradient of skips[n_skips-1-k]
+        for i in reversed(range(nb)):
+            bt = cfg['up_block_types'][i]
+            pre = 'up_blocks.%d' % i
+            if i != nb - 1:
+                xin = ctx.pop(pre + '.up')
+                dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC_UP,
+                                     (2 * xin.shape[2], 2 * xin.shape[3]))
+                dx = ops.downsum2x2(dxv)
+                del dxv
+            local = []
+            for j in reversed(range(Lr + 1)):
+                if bt == 'AttnUpBlock2D':
+                    dx = self.attn_bwd('%s.attentions.%d' % (pre, j), dx)
+                rp = '%s.resnets.%d' % (pre, j)
+                c1 = self.ctx[rp][0].shape[1]
+                dcat = self.resnet_bwd(rp, dx, semb, d_semb)
+                dx = dcat[:, :c1]
+                local.append(dcat[:, c1:])
+            skip_grads.append(local)
+        # skip k (forward push order) was popped by up block i at resnet j; rebuild index -> gradient view
+        order = []
+        for i in range(nb):          # forward pop order: up block 0 first, resnet 0 first
+            blk = skip_grads[nb - 1 - i]           # skip_grads was filled for i = nb-1 .. 0
+            for j in range(Lr + 1):
+                order.append(blk[Lr - j])          # local was filled for j = Lr .. 0
+        sg = {n_skips - 1 - k: g for k, g in enumerate(order)}     # skips index -> grad view
+
+        msf = float(cfg.get('mid_block_scale_factor', 1))
+        dx = self.resnet_bwd('mid_block.resnets.1', dx, semb, d_semb)
+        if cfg.get('add_attention', True):
+            dx = self.attn_bwd('mid_block.attentions.0', dx)
+        # mid resnet 0 consumes skips[-1] (the last down output) together with the up path
+        idx = n_skips - 1
+        dx = self.resnet_bwd('mid_block.resnets.0', dx, semb, d_semb, extra=sg.pop(idx))
+        for i in reversed(range(nb)):
+            bt = cfg['down_block_types'][i]
+            pre = 'down_blocks.%d' % i
+            if i != nb - 1:
+                # dx is the full gradient of the downsampler output (skips[idx]); its input is skips[idx-1]
+                xin, spec = ctx.pop(pre + '.down')
+                dxd = self._conv_bwd(pre + '.downsamplers.0.conv', dx, xin, None, spec, tuple(xin.shape[2:]))
+                idx -= 1
+                ops.copy_strided(sg.pop(idx), dxd, accumulate=True)
+                dx = dxd
+            for j in reversed(range(Lr)):
+                # dx = full gradient of skips[idx] (output of resnet j / its attention)
+                if bt == 'AttnDownBlock2D':
+                    dx = self.attn_bwd('%s.attentions.%d' % (pre, j), dx)
+                idx -= 1
+                dx = self.resnet_bwd('%s.resnets.%d' % (pre, j), dx, semb, d_semb, extra=sg.pop(idx))
+        assert idx == 0 and not sg
+        self._conv_bwd('conv_in', dx, sample, None, _SPEC3, None, need_dx=False)
+        # time embedding MLP (embeddings.py:200-212)
+        d_emb = ops.silu_bwd(emb, d_semb)
+        d_a1 = self._conv_bwd('time_embedding.linear_2', ops.as4d(d_emb), ops.as4d(a1), None, _SPEC1, (1, 1), rows=d_emb)
+        d_h1 = ops.silu_bwd(h1, d_a1.view(d_a1.shape[0], d_a1.shape[1]))
+        self._conv_bwd('time_embedding.linear_1', ops.as4d(d_h1), ops.as4d(t_emb), None, _SPEC1, None, need_dx=False,
+                       rows=d_h1)
+        assert not ctx, 'unconsumed context: %s' % list(ctx)
+        self.ctx = None

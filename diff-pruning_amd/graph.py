@@ -1,0 +1,265 @@
+"""Channel-coupling graph of UNet2DModel and the enumeration of pruning groups.
+
+Host logic (pure Python, no tensors).  It reproduces what the reference obtains from
+`torch_pruning.DependencyGraph` (ddpm_exp/torch_pruning/dependency.py) for this model family:
+
+  * which layers' channel dimensions are coupled (dependency.py:433-496: propagation through
+    element-wise ops, GroupNorm, and `torch.cat` with its index offsets, _helpers.py:34-52), and
+  * the ORDER in which root layers are visited (dependency.py:498-527 iterates `module2node`, whose
+    insertion order is the stack-DFS over the autograd graph of dependency.py:761-806).  The order matters:
+    pruning is interleaved with scoring (metapruner.py:205-254), so later groups are scored on tensors
+    already sliced by earlier ones.
+
+Instead of tracing autograd, the graph is built symbolically from the model configuration, listing for
+every op its inputs in the order autograd's `next_functions` lists them for the reference forward
+(unet_2d.py:219-316, resnet.py:589-639, attention_processor.py:870-935).  Pinned against group tables
+recorded from the reference (tests/golden/groups.json, tiny_prune.json, cifar_c1.json).
+"""
+
+
+class GNode:
+    __slots__ = ('kind', 'name', 'inputs', 'outputs', 'uid')
+
+    def __init__(self, kind, name, inputs, uid):
+        self.kind, self.name, self.uid = kind, name, uid
+        self.inputs = [i for i in inputs if i is not None]
+        self.outputs = []
+        for i in self.inputs:
+            if self not in i.outputs:
+                i.outputs.append(self)
+
+    def __repr__(self):
+        return '%s(%s)' % (self.kind, self.name or self.uid)
+
+
+class UNetGraph:
+    """Symbolic op graph of UNet2DModel.forward for a given config."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._n = 0
+        self.layers = {}
+        self.out = self._build()
+        self.order = self._trace_order(self.out)
+
+    # ---- builders --------------------------------------------------------------------------------
+    def _node(self, kind, name, inputs):
+        self._n += 1
+        n = GNode(kind, name, inputs, self._n)
+        if name is not None:
+            self.layers[name] = n
+        return n
+
+    def ew(self, *inputs):
+        return self._node('ew', None, list(inputs))
+
+    def conv(self, name, x):
+        return self._node('conv', name, [x])
+
+    def gn(self, name, x):
+        return self._node('gn', name, [x])
+
+    def linear(self, name, x):
+        # AddmmBackward0.next_functions = (bias [AccumulateGrad, skipped], input, TBackward0(weight))
+        return self._node('linear', name, [x, self.ew()])
+
+    def resnet(self, pre, x, emb, has_shortcut):
+        h = self.ew(self.gn(pre + '.norm1', x))                 # silu(norm1(x))
+        h = self.conv(pre + '.conv1', h)
+        t = self.linear(pre + '.time_emb_proj', self.ew(emb))   # nonlinearity(temb) is re-evaluated per block
+        t = self.ew(self.ew(t))                                 # [:, :, None, None]
+        h = self.ew(h, t)                                       # hidden_states + temb
+        h = self.ew(self.gn(pre + '.norm2', h))
+        h = self.conv(pre + '.conv2', h)                        # dropout is the identity in eval mode
+        if has_shortcut:
+            x = self.conv(pre + '.conv_shortcut', x)
+        return self.ew(self.ew(x, h))                           # (input_tensor + hidden_states) / scale
+
+    def attention(self, pre, x):
+        h = self.ew(self.ew(x))                                 # view, transpose
+        h = self.ew(self.gn(pre + '.group_norm', self.ew(h)))   # transpose, group_norm, transpose
+        q = self.ew(self.ew(self.linear(pre + '.to_q', h)))     # view + transpose
+        k = self.ew(self.ew(self.linear(pre + '.to_k', h)))
+        v = self.ew(self.ew(self.linear(pre + '.to_v', h)))
+        a = self.ew(q, k, v)                                    # scaled_dot_product_attention(q, k, v)
+        o = self.ew(self.ew(a))                                 # transpose, reshape
+        o = self.linear(pre + '.to_out.0', o)
+        o = self.ew(self.ew(o))                                 # transpose, reshape
+        return self.ew(self.ew(o, x))                           # (hidden_states + residual) / rescale
+
+    def _build(self):
+        cfg = self.cfg
+        boc = list(cfg['block_out_channels'])
+        L = cfg['layers_per_block']
+        nb = len(boc)
+        emb = self.linear('time_embedding.linear_2', self.ew(self.linear('time_embedding.linear_1', None)))
+        x = self.conv('conv_in', None)
+        skips = [x]
+        out_c = boc[0]
+        for i, bt in enumerate(cfg['down_block_types']):
+            in_c, out_c = out_c, boc[i]
+            pre = 'down_blocks.%d' % i
+            for j in range(L):
+                x = self.resnet('%s.resnets.%d' % (pre, j), x, emb, (in_c if j == 0 else out_c) != out_c)
+                if bt == 'AttnDownBlock2D':
+                    x = self.attention('%s.attentions.%d' % (pre, j), x)
+                skips.append(x)
+            if i != nb - 1:
+                if cfg['downsample_padding'] == 0:
+                    x = self.ew(x)                              # F.pad
+                x = self.conv(pre + '.downsamplers.0.conv', x)
+                skips.append(x)
+        x = self.resnet('mid_block.resnets.0', x, emb, False)
+        if cfg.get('add_attention', True):
+            x = self.attention('mid_block.attentions.0', x)
+        x = self.resnet('mid_block.resnets.1', x, emb, False)
+        for i, bt in enumerate(cfg['up_block_types']):
+            pre = 'up_blocks.%d' % i
+            for j in range(L + 1):
+                x = self._node('cat', None, [x, skips.pop()])
+                x = self.resnet('%s.resnets.%d' % (pre, j), x, emb, True)
+                if bt == 'AttnUpBlock2D':
+                    x = self.attention('%s.attentions.%d' % (pre, j), x)
+            if i != nb - 1:
+                x = self.conv(pre + '.upsamplers.0.conv', self.ew(x))      # F.interpolate
+        x = self.ew(self.gn('conv_norm_out', x))
+        return self.conv('conv_out', x)
+
+    # ---- dependency.py:761-806 -------------------------------------------------------------------
+    @staticmethod
+    def _trace_order(root):
+        order, seen_nodes = [], set()
+
+        def create(n):
+            if n.uid not in seen_nodes:
+                seen_nodes.add(n.uid)
+                order.append(n)
+
+        stack, visited = [root], set()
+        while stack:
+            f = stack.pop()
+            if f.uid in visited:
+                continue
+            create(f)
+            for inp in f.inputs:
+                create(inp)
+                stack.append(inp)
+            visited.add(f.uid)
+        return order
+
+
+# ---------------------------------------------------------------------------------------------------
+class ChannelView:
+    """Current channel counts, read off the live parameter shapes ({name: shape})."""
+
+    def __init__(self, shapes):
+        self.shapes = shapes
+
+    def out_channels(self, node):
+        if node.kind in ('conv', 'linear', 'gn'):
+            return self.shapes[node.name + '.weight'][0]
+        if node.kind == 'cat':
+            return sum(self.out_channels(i) for i in node.inputs)
+        for i in node.inputs:           # element-wise: same as (any) input
+            c = self.out_channels(i)
+            if c is not None:
+                return c
+        return None
+
+
+class Member:
+    __slots__ = ('name', 'kind', 'idxs')
+
+    def __init__(self, name, kind, idxs):
+        self.name, self.kind, self.idxs = name, kind, idxs
+
+    def __iter__(self):          # unpack like the fixture triples
+        return iter((self.name, self.kind, self.idxs))
+
+    def __repr__(self):
+        return 'Member(%s, %s, %d idxs)' % (self.name, self.kind, len(self.idxs))
+
+
+def coupled_members(graph, chan, root_name, idxs):
+    """dependency.py:433-496.  Propagate the out-channel set `idxs` of layer `root_name` through the graph;
+    returns an ordered list of Members (root first).  Index sets reaching the same (layer, kind) are merged
+    (Group.add_and_merge, dependency.py:492-494).
+
+    A channel set S living on the output tensor of node n implies
+      producer side: conv/linear -> member (n, 'out', S), stop;  GroupNorm -> member (n, 'gn', S) and S on its input;
+                     element-wise -> S on every input;  cat -> S split over the inputs by their channel offsets;
+      consumer side: conv/linear -> member (c, 'in', S), stop;  GroupNorm / element-wise -> S on c's output;
+                     cat -> S shifted by the input's offset on c's output."""
+    root = graph.layers[root_name]
+    members, order = {}, []
+
+    def add(name, kind, ii):
+        key = (name, kind)
+        if key not in members:
+            members[key] = set()
+            order.append(key)
+        members[key].update(ii)
+
+    seen = {}
+    stack = [(root, list(idxs))]
+    while stack:
+        node, ii = stack.pop()
+        s = seen.setdefault(node.uid, set())
+        ii = [i for i in ii if i not in s]
+        if not ii:
+            continue
+        s.update(ii)
+        # ---- producer side
+        if node.kind in ('conv', 'linear'):
+            add(node.name, 'out', ii)
+        elif node.kind == 'gn':
+            add(node.name, 'gn', ii)
+            for inp in node.inputs:
+                stack.append((inp, ii))
+        elif node.kind == 'cat':
+            off = 0
+            for inp in node.inputs:
+                n_in = chan.out_channels(inp)
+                sub = [i - off for i in ii if off <= i < off + n_in]
+                if sub:
+                    stack.append((inp, sub))
+                off += n_in
+        else:
+            for inp in node.inputs:
+                stack.append((inp, ii))
+        # ---- consumer side
+        for c in node.outputs:
+            if c.kind in ('conv', 'linear'):
+                add(c.name, 'in', ii)
+            elif c.kind == 'cat':
+                off = 0
+                for inp in c.inputs:
+                    if inp is node:
+                        break
+                    off += chan.out_channels(inp)
+                stack.append((c, [i + off for i in ii]))
+            else:
+                stack.append((c, ii))
+    return [Member(n, k, sorted(members[(n, k)])) for (n, k) in order]
+
+
+def all_groups(graph, chan_fn, ignored=('conv_out',)):
+    """dependency.py:498-527 as a lazy generator: yields (root_name, members) for full out-channel sets.
+    `chan_fn()` returns a fresh ChannelView (channel counts change while the caller prunes between yields)."""
+    visited = set()
+    for node in graph.order:
+        if node.kind not in ('conv', 'linear'):
+            continue
+        if node.name in ignored or node.name in visited:
+            continue
+        chan = chan_fn()
+        n_out = chan.shapes[node.name + '.weight'][0]
+        members = coupled_members(graph, chan, node.name, list(range(n_out)))
+        prunable = True
+        for m in members:
+            if m.kind == 'out':
+                visited.add(m.name)
+                if m.name in ignored:
+                    prunable = False
+        if prunable:
+            yield node.name, members

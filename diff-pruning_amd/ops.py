@@ -439,6 +439,13 @@ def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
     return out
 
 
+def gather_add(src, idx_long, dst):
+    """dst[i] += src[idx[i]]"""
+    assert idx_long.dtype == torch.int64 and idx_long.numel() == dst.numel()
+    L.check(_lib().dp_gather_add(_p(src), _p(idx_long), dst.numel(), _p(dst), _stream()), 'dp_gather_add')
+    return dst
+
+
 def sumsq_partials(x, nblocks=512):
     partial = torch.empty(nblocks, dtype=_f32, device=x.device)
     L.check(_lib().dp_sumsq_partials(_p(x), x.numel(), _p(partial), nblocks, _stream()), 'dp_sumsq_partials')

@@ -1,0 +1,121 @@
+"""Taylor / Diff-Pruning gradient sweep (ddpm_prune.py:94-106) on the HIP engine, batch-sharded over ranks.
+
+For t = 0, 1, 2, ...: noisy = add_noise(clean, noise, t); out = UNet(noisy, t); L_t = mse(out, noise);
+d L_t / d w is ACCUMULATED into the parameter gradients (never zeroed inside the sweep).  Diff-Pruning stops
+once L_t < thr * max_s L_s -- after accumulating the breaking step, exactly as the reference does.
+
+Data parallelism (new w.r.t. the reference): every rank walks the same timestep sequence on
+its own slice of the image batch.  L_t is a mean over the *global* batch, hence linear in per-image terms:
+each rank scales its loss / gradient by 1/numel_global, the early-exit test uses the all-reduced scalar loss
+(so every rank stops at the same t), and the gradients are summed ONCE at the end of the sweep with a single
+all-reduce of the flat gradient buffer (RCCL over xGMI when the process group is 'nccl').  Importance is
+non-linear in the gradient, so scores are only ever computed from the reduced gradients.
+"""
+import torch
+
+from . import ops
+
+
+def flatten_grads(model):
+    """Point every parameter's .grad at a slice of one zero-initialised flat fp32 buffer; returns the buffer."""
+    params = [p for p in model.parameters()]
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p)
+        off += n
+    return flat
+
+
+class HipSweepStep:
+    """One timestep of the sweep on the local image shard (forward + loss + backward on the HIP kernels)."""
+
+    def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
+        if clean.device.type != 'cuda':
+            raise RuntimeError('the sweep runs on the MI355X HIP kernels only (no CPU fallback)')
+        self.model, self.scheduler = model, scheduler
+        self.clean, self.noise = clean.contiguous().float(), noise.contiguous().float()
+        self.B = clean.shape[0]
+        if loss_kind == 'mse':                       # F.mse_loss: mean over every element of the global batch
+            self.gscale, self.lscale = 2.0 / global_numel, 1.0 / global_numel
+        else:                                        # sum over C,H,W then mean over the global batch
+            gb = global_batch if global_batch is not None else self.B
+            self.gscale, self.lscale = 2.0 / gb, 1.0 / gb
+        self.eng = model.engine()
+        self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+        self.acp = scheduler._acp_on(clean.device)
+
+    def __call__(self, k):
+        t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+        noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
+        out = self.eng.forward(noisy, t, save=True)
+        loss, dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
+        self.eng.backward(dout)
+        return loss          # [1] device tensor: this rank's share of L_t
+
+
+def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
+                 step_fn=None, flat_grads=None, reduce_grads=True):
+    """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
+
+    clean_images / noise: this rank's shard.  `group`: torch.distributed process group (None = default group if
+    torch.distributed is initialised, single process otherwise).  `step_fn(k) -> local loss tensor` lets the
+    multi-process CPU tests drive the same control flow with a different per-step engine."""
+    import torch.distributed as dist
+    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    B_local = clean_images.shape[0]
+    per_img = clean_images[0].numel()
+    if use_dist:
+        cnt = torch.tensor([float(B_local)], device=clean_images.device)
+        dist.all_reduce(cnt, group=group)
+        B_global = int(round(float(cnt)))
+    else:
+        B_global = B_local
+    if flat_grads is None and step_fn is None:
+        flat_grads = flatten_grads(model)
+    if step_fn is None:
+        step_fn = HipSweepStep(model, scheduler, clean_images, noise, B_global * per_img, loss_kind, B_global)
+    losses = []
+    pending = []
+    loss_max = 0.0
+    steps = 0
+    for k in range(num_steps):
+        l = step_fn(k)
+        steps += 1
+        if use_dist and (thr is not None):
+            dist.all_reduce(l, group=group)
+        if thr is not None:
+            lv = float(l)                       # host sync: the reference's `if loss > loss_max` (ddpm_prune.py:104-106)
+            losses.append(lv)
+            if lv > loss_max:
+                loss_max = lv
+            if lv < loss_max * thr:
+                break
+        else:
+            pending.append(l)
+    if pending:
+        stacked = torch.cat([p.reshape(1) for p in pending])
+        if use_dist:
+            dist.all_reduce(stacked, group=group)
+        losses = [float(v) for v in stacked.cpu()]
+    if use_dist and reduce_grads and flat_grads is not None:
+        dist.all_reduce(flat_grads, group=group)      # the one exchange step of the sweep (sum of per-shard grads)
+    return dict(losses=losses, steps=steps, global_batch=B_global)
+
+
+def prune_model(model, pruning_ratio=0.3, importance=None, ignored_layers=None, channel_groups=None):
+    """ddpm_prune.py:79-116: build the pruner, run `pruner.step(interactive=True)` pruning every yielded group,
+    then fix the static `channels` attributes.  Returns the pruner (its `.records` hold scores and masks)."""
+    from . import pruning
+    imp = importance if importance is not None else pruning.TaylorImportance()
+    pr = pruning.MagnitudePruner(model, None, importance=imp, iterative_steps=1, channel_groups=channel_groups or {},
+                                 ch_sparsity=pruning_ratio,
+                                 ignored_layers=ignored_layers if ignored_layers is not None else [model.conv_out])
+    for g in pr.step(interactive=True):
+        g.prune()
+    pruning.fix_static_attributes(model)
+    if getattr(model, '_engine', None) is not None:
+        model._engine.packs.clear()
+    return pr

@@ -1,0 +1,265 @@
+"""UNet2DModel with the Diffusers interface, executed by the HIP engine.
+
+Mirrors the public surface of the reference's `diffusers.models.UNet2DModel` (unet_2d.py:38-316) that the
+hot path touches: constructor arguments / `.config`, `forward(sample, timestep, class_labels=None,
+return_dict=True) -> UNet2DOutput`, `.dtype`, `.device`, and -- crucially -- the exact `state_dict`
+key names, with every weight held by a real `nn.Conv2d` / `nn.Linear` / `nn.GroupNorm` so that
+`torch_pruning`'s pruning functions, `EMAModel`, optimizers and `torch.save(model)` keep working.
+Those layer objects are *parameter holders only*: their own `forward` is never called; all arithmetic
+runs in the HIP kernels through `UNetEngine`.  There is no PyTorch fallback.
+"""
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .engine import UNetEngine
+
+
+@dataclass
+class UNet2DOutput:
+    sample: torch.Tensor
+
+
+class FrozenConfig(dict):
+    """dict with attribute access (Diffusers' FrozenDict behaviour: `unet.config.sample_size`)."""
+    __getattr__ = dict.__getitem__
+
+
+# ---- parameter-holder modules, named as in Diffusers so that state_dict keys match ----------------
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift):
+        super().__init__()
+        self.num_channels, self.flip_sin_to_cos, self.downscale_freq_shift = num_channels, flip_sin_to_cos, downscale_freq_shift
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, temb_channels, groups, eps, output_scale_factor=1.0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.output_scale_factor = in_channels, out_channels, output_scale_factor
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0) if in_channels != out_channels else None
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, heads, dim_head, groups, eps, rescale_output_factor=1.0):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5          # fixed at construction, like attention_processor.py:85-86
+        self.rescale_output_factor = rescale_output_factor
+        self.residual_connection = True
+        self.group_norm = nn.GroupNorm(groups, query_dim, eps=eps, affine=True)
+        self.to_q = nn.Linear(query_dim, inner, bias=True)
+        self.to_k = nn.Linear(query_dim, inner, bias=True)
+        self.to_v = nn.Linear(query_dim, inner, bias=True)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=True), nn.Dropout(0.0)])
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels, padding):
+        super().__init__()
+        self.channels, self.out_channels, self.padding, self.use_conv = channels, channels, padding, True
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=padding)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, channels, True
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+
+class _Block(nn.Module):
+    pass
+
+
+def _attn(cfg, channels, rescale=1.0):
+    hd = cfg['attention_head_dim']
+    heads = channels // hd if hd is not None else 1
+    dim_head = hd if hd is not None else channels
+    if heads != 1:
+        raise NotImplementedError('multi-head attention (attention_head_dim=%r) is outside the DDPM hot path' % hd)
+    return Attention(channels, heads, dim_head, cfg['norm_num_groups'], cfg['norm_eps'], rescale)
+
+
+_DEFAULTS = dict(
+    sample_size=None, in_channels=3, out_channels=3, center_input_sample=False, time_embedding_type='positional',
+    freq_shift=0, flip_sin_to_cos=True,
+    down_block_types=('DownBlock2D', 'AttnDownBlock2D', 'AttnDownBlock2D', 'AttnDownBlock2D'),
+    up_block_types=('AttnUpBlock2D', 'AttnUpBlock2D', 'AttnUpBlock2D', 'UpBlock2D'),
+    block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1, downsample_padding=1,
+    act_fn='silu', attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, resnet_time_scale_shift='default',
+    add_attention=True, class_embed_type=None, num_class_embeds=None)
+
+
+class UNet2DModel(nn.Module):
+    """Construction order follows unet_2d.py:84-217, so `state_dict()` key order matches the reference."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = dict(_DEFAULTS)
+        unknown = set(kwargs) - set(cfg)
+        if unknown:
+            raise TypeError('unexpected UNet2DModel arguments: %s' % sorted(unknown))
+        cfg.update(kwargs)
+        cfg['down_block_types'] = tuple(cfg['down_block_types'])
+        cfg['up_block_types'] = tuple(cfg['up_block_types'])
+        cfg['block_out_channels'] = tuple(cfg['block_out_channels'])
+        if cfg['time_embedding_type'] != 'positional' or cfg['act_fn'] not in ('silu', 'swish') \
+                or cfg['resnet_time_scale_shift'] != 'default' or cfg['class_embed_type'] is not None \
+                or cfg['num_class_embeds'] is not None:
+            raise NotImplementedError('only the DDPM configuration family of the hot path is implemented')
+        if len(cfg['down_block_types']) != len(cfg['up_block_types']) or \
+                len(cfg['block_out_channels']) != len(cfg['down_block_types']):
+            raise ValueError('down_block_types, up_block_types and block_out_channels must have equal lengths')
+        for bt in cfg['down_block_types']:
+            if bt not in ('DownBlock2D', 'AttnDownBlock2D'):
+                raise NotImplementedError(bt)
+        for bt in cfg['up_block_types']:
+            if bt not in ('UpBlock2D', 'AttnUpBlock2D'):
+                raise NotImplementedError(bt)
+        self.config = FrozenConfig(cfg)
+        self.sample_size = cfg['sample_size']
+        boc = cfg['block_out_channels']
+        G, eps, L = cfg['norm_num_groups'], cfg['norm_eps'], cfg['layers_per_block']
+        tdim = boc[0] * 4
+
+        self.conv_in = nn.Conv2d(cfg['in_channels'], boc[0], 3, padding=(1, 1))
+        self.time_proj = Timesteps(boc[0], cfg['flip_sin_to_cos'], cfg['freq_shift'])
+        self.time_embedding = TimestepEmbedding(boc[0], tdim)
+        self.class_embedding = None
+        self.down_blocks = nn.ModuleList([])
+        self.up_blocks = nn.ModuleList([])
+
+        out_c = boc[0]
+        for i, bt in enumerate(cfg['down_block_types']):
+            in_c, out_c = out_c, boc[i]
+            blk = _Block()
+            resnets, attns = [], []
+            for j in range(L):
+                resnets.append(ResnetBlock2D(in_c if j == 0 else out_c, out_c, tdim, G, eps))
+                if bt == 'AttnDownBlock2D':
+                    attns.append(_attn(cfg, out_c))
+            if bt == 'AttnDownBlock2D':
+                blk.attentions = nn.ModuleList(attns)
+            blk.resnets = nn.ModuleList(resnets)
+            blk.downsamplers = nn.ModuleList([Downsample2D(out_c, cfg['downsample_padding'])]) if i != len(boc) - 1 else None
+            self.down_blocks.append(blk)
+
+        msf = cfg['mid_block_scale_factor']
+        mid = _Block()
+        mid.add_attention = cfg['add_attention']
+        r0 = ResnetBlock2D(boc[-1], boc[-1], tdim, G, eps, msf)
+        att = [_attn(cfg, boc[-1], msf)] if cfg['add_attention'] else [None]
+        r1 = ResnetBlock2D(boc[-1], boc[-1], tdim, G, eps, msf)
+        mid.attentions = nn.ModuleList(att)
+        mid.resnets = nn.ModuleList([r0, r1])
+        self.mid_block = mid
+
+        rev = list(reversed(boc))
+        out_c = rev[0]
+        for i, bt in enumerate(cfg['up_block_types']):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            blk = _Block()
+            resnets, attns = [], []
+            for j in range(L + 1):
+                res_skip = in_c if j == L else out_c
+                res_in = prev if j == 0 else out_c
+                resnets.append(ResnetBlock2D(res_in + res_skip, out_c, tdim, G, eps))
+                if bt == 'AttnUpBlock2D':
+                    attns.append(_attn(cfg, out_c))
+            if bt == 'AttnUpBlock2D':
+                blk.attentions = nn.ModuleList(attns)
+            blk.resnets = nn.ModuleList(resnets)
+            blk.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if i != len(boc) - 1 else None
+            self.up_blocks.append(blk)
+
+        self.conv_norm_out = nn.GroupNorm(G, boc[0], eps=eps)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[0], cfg['out_channels'], 3, padding=1)
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**{k: v for k, v in dict(config).items() if not k.startswith('_')})
+
+    def engine(self):
+        """The HIP execution engine bound to the *current* parameter tensors (re-bound after pruning)."""
+        if self.conv_in.weight.device.type != 'cuda':
+            raise RuntimeError('UNet2DModel runs on the MI355X HIP kernels only: move the model to a cuda device '
+                               '(there is no CPU / PyTorch fallback)')
+        if self._engine is None:
+            self._engine = UNetEngine(self.config)
+        params = {n: p.detach() for n, p in self.named_parameters()}
+        self._engine.bind(params, None)
+        return self._engine
+
+    def _timesteps(self, sample, timestep):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.long, device=sample.device)
+        elif t.dim() == 0:
+            t = t[None].to(sample.device)
+        t = t.to(sample.device)
+        return t * torch.ones(sample.shape[0], dtype=t.dtype, device=sample.device)
+
+    def forward(self, sample, timestep, class_labels=None, return_dict=True):
+        if class_labels is not None:
+            raise ValueError('class conditioning is not part of this model')
+        t = self._timesteps(sample, timestep)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            names = [n for n, _ in self.named_parameters()]
+            out = _UNetFunction.apply(self, names, sample, t, *list(self.parameters()))
+        else:
+            out = self.engine().forward(sample.to(torch.float32), t, save=False)
+        if not return_dict:
+            return (out,)
+        return UNet2DOutput(sample=out)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Bridges the engine into autograd as ONE node (DDP hooks, optimizers and `loss.backward()` keep working)."""
+
+    @staticmethod
+    def forward(ctx, model, names, sample, t, *params):
+        eng = model.engine()
+        out = eng.forward(sample.detach().to(torch.float32), t, save=True)
+        ctx.model, ctx.names, ctx.saved_ctx = model, names, eng.ctx
+        eng.ctx = None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        eng = model.engine()
+        grads = {n: torch.zeros_like(p.data) for n, p in model.named_parameters()}
+        eng.bind(eng.P, grads)
+        eng.ctx = ctx.saved_ctx
+        eng.backward(dout.contiguous())
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)

@@ -137,6 +137,9 @@ int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H,
 int dp_wg_reduce(const float* w, const float* g, int R, int C, int T, int dim, int mode, float* out, int accumulate,
                  float* scratch, void* stream);
 
+/* dst[i] += src[idx[i]], i < n : adds one member's channel sums into the group score (importance.py:427-428). */
+int dp_gather_add(const float* src, const int64_t* idx, int n, float* dst, void* stream);
+
 /* Fused finetune update over flat buffers (ddpm_train.py:462-469, training_utils.py:201-216):
  *   g *= clip_coef (clip_coef read from device: min(1, max_norm/(norm+1e-6)));  Adam;  EMA with constant decay. */
 int dp_sumsq_partials(const float* x, long long n, float* partial, int nblocks, void* stream);
