@@ -1,0 +1,258 @@
+"""TEST-ONLY stand-in for `diff-pruning_amd/ops.py` built from CPU PyTorch ops.
+
+Lets the CPU suite execute the engine's hand-written backward graph, the sweep / finetune control flow and the
+multi-process (gloo) data-parallel path without a GPU.  It is never importable from the product package; the
+product has no CPU path (tests/test_cpu.py::test_no_cpu_fallback)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+_real = None
+
+
+def _spec_cls():
+    import importlib
+    return importlib.import_module('diff-pruning_amd.ops').ConvSpec
+
+
+class _Lazy:
+    def __getattr__(self, k):
+        return getattr(_spec_cls(), k)
+
+
+def ConvSpec(*a, **k):
+    return _spec_cls()(*a, **k)
+
+
+def as4d(x):
+    return x if x.dim() == 4 else x.view(x.shape[0], x.shape[1], 1, 1)
+
+
+def pack_weight(w, mode):
+    return w, mode
+
+
+def _cat(x, x2):
+    return x if x2 is None else torch.cat([x, x2], 1)
+
+
+def _prep(x, spec):
+    if spec.ups:
+        x = F.interpolate(x, scale_factor=2.0, mode='nearest')
+    if spec.stride == 2 and spec.pad == 0:
+        x = F.pad(x, (0, 1, 0, 1))
+    return x
+
+
+def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
+                 accumulate=False):
+    w = wp if wp.dim() == 4 else wp.view(wp.shape[0], wp.shape[1], 1, 1)
+    y = alpha * F.conv2d(_prep(_cat(x, x2), spec), w, None, stride=spec.stride, padding=spec.pad)
+    if bias is not None:
+        y = y + bias[None, :, None, None]
+    if tadd is not None:
+        y = y + tadd[:, :, None, None]
+    if res is not None:
+        y = y + res
+    y = y * post_scale
+    if out is not None:
+        out.copy_(out + y if accumulate else y)
+        return out
+    return y
+
+
+def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate=False):
+    w = wd if wd.dim() == 4 else wd.view(wd.shape[0], wd.shape[1], 1, 1)
+    N = dy.shape[0]
+    Hv, Wv = in_hw
+    asym = spec.stride == 2 and spec.pad == 0
+    shape = (N, Cin, Hv + (1 if asym else 0), Wv + (1 if asym else 0))
+    dx = torch.nn.grad.conv2d_input(shape, w, dy.contiguous(), stride=spec.stride, padding=spec.pad)
+    if asym:
+        dx = dx[:, :, :Hv, :Wv]
+    dx = alpha * dx
+    if out is not None:
+        out.copy_(out + dx if accumulate else dx)
+        return out
+    return dx.contiguous()
+
+
+def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=None):
+    xin = _prep(_cat(x, x2), spec)
+    k = spec.k
+    g = torch.nn.grad.conv2d_weight(xin, (dy.shape[1], xin.shape[1], k, k), dy.contiguous(), stride=spec.stride,
+                                    padding=spec.pad)
+    g = alpha * g.reshape(gw.shape)
+    gw.copy_(gw + g if accumulate else g)
+    return gw
+
+
+def bmm_tn(a, b, alpha=1.0, out=None):
+    r = alpha * torch.bmm(a.transpose(1, 2), b)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def bmm_nn(a, b, alpha=1.0, out=None):
+    return alpha * torch.bmm(a, b)
+
+
+def bmm_nt(a, b, alpha=1.0, out=None):
+    return alpha * torch.bmm(a, b.transpose(1, 2))
+
+
+def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None):
+    xc = _cat(x, x2)
+    N, C = xc.shape[:2]
+    xg = xc.reshape(N, G, -1)
+    mean = xg.mean(-1)
+    var = xg.var(-1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    y = F.group_norm(xc, G, gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    return y, torch.stack([mean, rstd], -1).reshape(N * G, 2)
+
+
+def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None):
+    xc = _cat(x, x2)
+    N, C, H, W = xc.shape
+    cpg = C // G
+    mean = stats.view(N, G, 2)[..., 0].repeat_interleave(cpg, 1)[:, :, None, None]
+    rstd = stats.view(N, G, 2)[..., 1].repeat_interleave(cpg, 1)[:, :, None, None]
+    xhat = (xc - mean) * rstd
+    ga = gamma[None, :, None, None]
+    yhat = xhat * ga + beta[None, :, None, None]
+    sg = torch.sigmoid(yhat)
+    dy = dz * (sg * (1 + yhat * (1 - sg))) if silu else dz
+    s1 = dy.sum((2, 3))
+    s2 = (dy * xhat).sum((2, 3))
+    M = cpg * H * W
+    a = (s1 * gamma[None]).view(N, G, cpg).sum(-1).repeat_interleave(cpg, 1)[:, :, None, None] / M
+    b = (s2 * gamma[None]).view(N, G, cpg).sum(-1).repeat_interleave(cpg, 1)[:, :, None, None] / M
+    dx = rstd * (ga * dy - a - xhat * b)
+    if add1 is not None:
+        dx = dx + add1
+    if add2 is not None:
+        dx = dx + add2
+    return dx.contiguous(), torch.stack([s1, s2], -1).contiguous()
+
+
+def colsum_accum(ws, N, C, wstride, woff, out, accumulate=True):
+    s = ws.reshape(N, C, wstride)[:, :, woff].sum(0)
+    out.copy_(out + s if accumulate else s)
+
+
+def rowsum_nc(x):
+    return x.sum((2, 3))
+
+
+def silu_fwd(x):
+    return F.silu(x)
+
+
+def silu_bwd(x, dy, out=None, accumulate=False):
+    s = torch.sigmoid(x)
+    v = dy * s * (1 + x * (1 - s))
+    if out is not None:
+        out.copy_(out + v if accumulate else v)
+        return out
+    return v
+
+
+def axpby(x, a, y, b):
+    y.copy_(a * x + b * y if b != 0 else a * x)
+    return y
+
+
+def copy_strided(src, dst, accumulate=False):
+    dst.copy_(dst + src if accumulate else src)
+    return dst
+
+
+def softmax_fwd(s, out=None):
+    p = s.softmax(-1)
+    if out is not None:
+        out.copy_(p)
+        return out
+    return p
+
+
+def softmax_bwd(p, dp, scale, out=None):
+    ds = scale * p * (dp - (p * dp).sum(-1, keepdim=True))
+    if out is not None:
+        out.copy_(ds)
+        return out
+    return ds
+
+
+def timestep_embedding(t, dim, flip, shift, max_period=10000.0):
+    half = dim // 2
+    e = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / (half - shift)
+    arg = t[:, None].float() * torch.exp(e)[None]
+    emb = torch.cat([torch.sin(arg), torch.cos(arg)], -1)
+    if flip:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], -1)
+    return emb
+
+
+def add_noise(x0, noise, acp, t, out=None):
+    a = acp[t]
+    return (a ** 0.5)[:, None, None, None] * x0 + ((1 - a) ** 0.5)[:, None, None, None] * noise
+
+
+def mse_fwd_bwd(out, noise, gscale, loss_scale, want_grad=True):
+    d = out - noise
+    return (loss_scale * d.square().sum()).reshape(1), (gscale * d if want_grad else None)
+
+
+def downsum2x2(dy, out=None):
+    return F.avg_pool2d(dy, 2) * 4
+
+
+def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
+    p = w * g
+    if mode == 3:
+        v = p.abs()
+    else:
+        q = p.flatten(1) if dim == 0 else p.transpose(0, 1).flatten(1)
+        v = q.abs().pow(2).sum(1) if mode == 0 else (q.abs().sum(1) if mode == 1 else q.sum(1).abs())
+    out.copy_(out + v if accumulate else v)
+    return out
+
+
+def gather_add(src, idx, dst):
+    dst.add_(src[idx])
+    return dst
+
+
+def sumsq_partials(x, nblocks=512):
+    return (x.double() ** 2).sum().float().reshape(1)
+
+
+def clip_coef(partial, max_norm):
+    n = partial.sum().sqrt()
+    return torch.stack([n, torch.clamp(max_norm / (n + 1e-6), max=1.0)])
+
+
+def adam_ema(p_, g, m, v, ema, coef, lr, b1, b2, eps, step, ema_decay):
+    gi = g * coef
+    m.mul_(b1).add_(gi, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+    denom = v.sqrt() / math.sqrt(1 - b2 ** step) + eps
+    p_.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+    if ema is not None:
+        ema.copy_((1 - ema_decay) * p_ + ema_decay * ema)
+
+
+def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None):
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    v = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+    if vnoise is not None:
+        v = v + std * vnoise
+    return v

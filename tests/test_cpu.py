@@ -251,3 +251,93 @@ def test_pruner_bookkeeping_on_cpu_model():
     assert {n: list(p.shape) for n, p in m.named_parameters()} == fx['shapes_after']
     pruning.fix_static_attributes(m)
     assert m.down_blocks[0].downsamplers[0].channels == m.down_blocks[0].downsamplers[0].conv.in_channels
+
+
+# ------------------------------------------------------------- engine graph / control flow on mocked kernels
+@pytest.fixture()
+def mocked(monkeypatch):
+    """Swap the kernel wrappers for CPU stand-ins (tests/mock_ops.py) in every product module that uses them."""
+    import mock_ops
+    for sub in ('engine', 'sweep', 'train', 'diffusion', 'pruning'):
+        monkeypatch.setattr(pkg(sub), 'ops', mock_ops)
+    unet = pkg('unet')
+    monkeypatch.setattr(unet.UNet2DModel, 'engine', _cpu_engine)
+    return mock_ops
+
+
+def _cpu_engine(self):
+    engine = pkg('engine')
+    if self._engine is None:
+        self._engine = engine.UNetEngine(self.config)
+    self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+    return self._engine
+
+
+def _cpu_model(cfg, seed):
+    m = pkg('unet').UNet2DModel(**cfg)
+    gc.det_init_(m, seed)
+    return m.eval()
+
+
+def test_engine_backward_graph_matches_oracle_autograd(mocked, monkeypatch):
+    """The engine's hand-written backward (skip-gradient routing, virtual concat, shared silu(temb), attention)
+    reproduces autograd of the oracle when its kernels are replaced by CPU stand-ins."""
+    from oracle import diffusion_ref as D
+    sweep = pkg('sweep')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = gc.TINY_CFG
+    model = _cpu_model(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=3)
+    P = oracle_params(cfg, 5)
+    losses = D.taylor_sweep(P, cfg, clean, noise, 3)
+    assert np.allclose(res['losses'], losses, rtol=1e-5)
+    for n, p in model.named_parameters():
+        if P[n].grad.abs().max() > 1e-7:
+            assert relerr(p.grad, P[n].grad) < 5e-5, n
+    # bedroom-like topology (6 levels, attention in the 5th down / 2nd up block) on tiny widths
+    cfgb = dict(gc.BEDROOM_CFG, block_out_channels=[16, 16, 32, 32, 64, 64], sample_size=32, norm_num_groups=8)
+    modelb = _cpu_model(cfgb, 3)
+    cb = torch.from_numpy(gc.det_clean((1, 3, 32, 32), 5))
+    nb = torch.from_numpy(gc.det_noise((1, 3, 32, 32), 6))
+    resb = sweep.taylor_sweep(modelb, pkg('diffusion').DDPMScheduler(), cb, nb, num_steps=2)
+    Pb = oracle_params(cfgb, 3)
+    lb = D.taylor_sweep(Pb, cfgb, cb, nb, 2)
+    assert np.allclose(resb['losses'], lb, rtol=1e-5)
+    for n, p in modelb.named_parameters():
+        if Pb[n].grad.abs().max() > 1e-7:
+            assert relerr(p.grad, Pb[n].grad) < 5e-5, n
+
+
+def _cpu_step_init(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
+    self.model, self.scheduler = model, scheduler
+    self.clean, self.noise = clean.contiguous().float(), noise.contiguous().float()
+    self.B = clean.shape[0]
+    if loss_kind == 'mse':
+        self.gscale, self.lscale = 2.0 / global_numel, 1.0 / global_numel
+    else:
+        gb = global_batch if global_batch is not None else self.B
+        self.gscale, self.lscale = 2.0 / gb, 1.0 / gb
+    self.eng = model.engine()
+    self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+    self.acp = scheduler.alphas_cumprod
+
+
+def test_prune_flow_on_mocked_kernels_matches_reference_masks(mocked, monkeypatch):
+    """sweep -> TaylorImportance -> MagnitudePruner.step(interactive) -> group.prune() end to end (host logic +
+    mocked kernels) reproduces the reference's masks for the tiny UNet."""
+    sweep = pkg('sweep')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = gc.TINY_CFG
+    fx = load_json('tiny_prune.json')
+    model = _cpu_model(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=4)
+    pr = sweep.prune_model(model, 0.3)
+    assert [r[3] for r in pr.records] == [r['pruned'] for r in fx['prune']]
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == fx['shapes_after']
+    # pruned model still runs forward + backward through the engine
+    res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1)
+    assert np.isfinite(res['losses'][0])

@@ -1,0 +1,216 @@
+"""End-to-end GPU parity: HIP engine vs the oracle and vs the reference's golden vectors.
+
+Bars: prune masks (integer channel indices) bit-exact; fp32 tensors within the tolerance written at each assert
+(fp32 kernels with a different summation order than ATen-CPU: 1e-5 relative per tensor for single passes,
+2e-5 for accumulated gradients)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_common as gc
+from helpers import load_json, load_npz, make_model, oracle_params, pkg, relerr, oracle_prune_replay
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _inputs(B, H, s1=1, s2=2):
+    return (torch.from_numpy(gc.det_clean((B, 3, H, H), s1)), torch.from_numpy(gc.det_noise((B, 3, H, H), s2)))
+
+
+def test_tiny_forward_matches_reference_and_oracle(report):
+    from oracle import diffusion_ref as D, unet_ref as U
+    cfg = gc.TINY_CFG
+    g = load_npz('tiny_unet.npz')
+    model = make_model(cfg, 5)
+    sched = pkg('diffusion').DDPMScheduler()
+    clean, noise = _inputs(2, 16)
+    t = torch.tensor([3, 500])
+    noisy = sched.add_noise(clean.to(DEV), noise.to(DEV), t.to(DEV))
+    with torch.no_grad():
+        y = model(noisy, t.to(DEV)).sample
+    e_ref = float((y.cpu() - torch.from_numpy(g['fwd_out'])).abs().max())
+    P = oracle_params(cfg, 5, requires_grad=False)
+    yo = U.unet_forward(P, cfg, D.add_noise(D.alphas_cumprod(), clean, noise, t), t)
+    e_or = float((y.cpu() - yo).abs().max())
+    report['e2e/tiny_fwd'] = dict(vs_reference_abs=e_ref, vs_oracle_abs=e_or)
+    assert e_ref < 1e-5 and e_or < 1e-5          # |y| ~ 1: 1e-5 absolute
+
+
+def _run_sweep(model, clean, noise, steps, thr=None):
+    sweep = pkg('sweep')
+    sched = pkg('diffusion').DDPMScheduler()
+    return sweep.taylor_sweep(model, sched, clean.to(DEV), noise.to(DEV), num_steps=steps, thr=thr)
+
+
+def test_tiny_sweep_gradients_match_reference(report):
+    cfg = gc.TINY_CFG
+    g = load_npz('tiny_unet.npz')
+    fx = load_json('tiny_prune.json')
+    model = make_model(cfg, 5)
+    clean, noise = _inputs(2, 16)
+    res = _run_sweep(model, clean, noise, 4)
+    assert res['steps'] == 4
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], g['losses']))
+    worst = 0.0
+    P = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith('grad::'):
+            e = relerr(P[k[6:]].grad, g[k])
+            worst = max(worst, e)
+            assert e < 2e-5, (k, e)
+    bad = []
+    for n, (s, a, q) in fx['grad_stats'].items():
+        gr = P[n].grad.double()
+        if abs(float(gr.abs().sum()) - a) > 5e-5 * a + 1e-8 * gr.numel():
+            bad.append((n, float(gr.abs().sum()), a))
+    report['e2e/tiny_sweep'] = dict(loss_rel=e_loss, grad_rel_worst=worst, n_bad_stats=len(bad))
+    assert e_loss < 1e-5 and not bad, bad[:5]
+
+
+def _compare_prune(model, fx, report, key):
+    sweep = pkg('sweep')
+    pr = sweep.prune_model(model, 0.3)
+    assert len(pr.records) == len(fx['prune'])
+    worst_score, min_margin, mism = 0.0, 1e9, []
+    from oracle import pruning_ref as R
+    for (root, chg, score, pruned), ref in zip(pr.records, fx['prune']):
+        assert root == ref['root'] and chg == ref['ch_groups']
+        rs = torch.from_numpy(gc.b64_to_f32(ref['score']))
+        worst_score = max(worst_score, relerr(score, rs))
+        min_margin = min(min_margin, R.decision_margin(rs, ref['pruned'], ref['cur'], ref['ch_groups']))
+        if pruned != ref['pruned']:
+            mism.append(root)
+    report[key] = dict(groups=len(pr.records), score_rel_worst=worst_score, min_decision_margin=min_margin,
+                       mask_mismatches=mism)
+    assert not mism, mism                                  # bit-exact integer masks, every group
+    assert worst_score < 1e-4
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == fx['shapes_after']
+    assert sum(p.numel() for p in model.parameters()) == fx['params_after']
+
+
+def test_tiny_prune_masks_bit_exact_and_post_prune_forward(report):
+    cfg = gc.TINY_CFG
+    fx = load_json('tiny_prune.json')
+    model = make_model(cfg, 5)
+    clean, noise = _inputs(2, 16)
+    _run_sweep(model, clean, noise, 4)
+    _compare_prune(model, fx, report, 'e2e/tiny_prune')
+    sched = pkg('diffusion').DDPMScheduler()
+    t = torch.tensor([3, 500], device=DEV)
+    with torch.no_grad():
+        y2 = model(sched.add_noise(clean.to(DEV), noise.to(DEV), t), t).sample
+    e = float((y2.cpu() - torch.from_numpy(gc.b64_to_f32(fx['fwd_after']))).abs().max())
+    report['e2e/tiny_prune']['fwd_after_abs'] = e
+    assert e < 1e-5
+
+
+def test_diff_pruning_early_exit_step(report):
+    cfg = gc.TINY_CFG
+    fx = load_json('tiny_prune.json')['early_exit']
+    model = make_model(cfg, 5)
+    clean, noise = _inputs(2, 16)
+    res = _run_sweep(model, clean, noise, 1000, thr=fx['thr'])
+    report['e2e/early_exit'] = dict(steps=res['steps'], ref_steps=fx['steps'])
+    assert res['steps'] == fx['steps']                     # stops at exactly the reference's timestep
+    assert np.allclose(res['losses'], fx['losses'], rtol=1e-5)
+
+
+def test_ddim_sampling_matches_reference(report):
+    g = load_npz('ddim.npz')
+    diffusion = pkg('diffusion')
+    model = make_model(gc.TINY_CFG, 5)
+    sch = diffusion.DDIMScheduler()
+    sch.set_timesteps(100)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 21)).to(DEV)
+    errs = []
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps[:5]):
+            x = sch.step(model(x, t).sample, t, x, eta=0.0).prev_sample
+            errs.append(float((x.cpu() - torch.from_numpy(g['x_steps'][i])).abs().max()))
+    # full pipeline call with a seeded CPU generator: same x_T as the reference's randn_tensor path
+    pipe = diffusion.DDIMPipeline(model, diffusion.DDIMScheduler())
+    sch2 = pipe.scheduler
+    sch2.set_timesteps(10)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 22)).to(DEV)
+    with torch.no_grad():
+        for t in sch2.timesteps:
+            x = sch2.step(model(x, t).sample, t, x).prev_sample
+    img = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu()
+    e_img = float((img - torch.from_numpy(g['chain10_image'])).abs().max())
+    report['e2e/ddim'] = dict(step_abs=errs, chain10_image_abs=e_img)
+    assert max(errs) < 5e-5 and e_img < 2e-4               # same tolerances as the oracle-vs-reference test
+    out = pipe(batch_size=2, generator=torch.Generator().manual_seed(0), num_inference_steps=4, output_type='numpy')
+    assert out.images.shape == (2, 16, 16, 3) and np.isfinite(out.images).all()
+
+
+def test_cifar_c1_masks_bit_exact(report):
+    """Config C1 of BASELINE.json: CIFAR-10 UNet, B=4, 8 timesteps, Taylor ratio 0.3 -> every pruned index list equals
+    the reference's; 35.75 M -> 19 851 157 parameters."""
+    cfg = gc.CIFAR_CFG
+    fx = load_json('cifar_c1.json')
+    model = make_model(cfg, 0)
+    clean, noise = _inputs(4, 32)
+    res = _run_sweep(model, clean, noise, 8)
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], fx['losses']))
+    P = dict(model.named_parameters())
+    bad = []
+    for n, (s, a, q) in fx['grad_stats'].items():
+        gr = P[n].grad.double()
+        if abs(float(gr.abs().sum()) - a) > 5e-5 * a + 1e-8 * gr.numel():
+            bad.append((n, float(gr.abs().sum()), a))
+    report['e2e/c1'] = dict(loss_rel=e_loss, n_bad_grad_stats=len(bad))
+    assert e_loss < 1e-5 and not bad, bad[:5]
+    _compare_prune(model, fx, report, 'e2e/c1_prune')
+    assert sum(p.numel() for p in model.parameters()) == 19851157
+
+
+def test_autograd_bridge_and_finetune_step(report):
+    """`loss.backward()` through the one-node autograd bridge equals the sweep engine; one finetune step equals the
+    oracle's clip+Adam+EMA arithmetic."""
+    from oracle import diffusion_ref as D
+    cfg = gc.TINY_CFG
+    diffusion, train = pkg('diffusion'), pkg('train')
+    model = make_model(cfg, 5)
+    model.train()
+    sched = diffusion.DDPMScheduler()
+    clean, noise = _inputs(4, 16, 3, 4)
+    t = torch.tensor([1, 250, 500, 998])
+    # autograd bridge
+    noisy = sched.add_noise(clean.to(DEV), noise.to(DEV), t.to(DEV))
+    out = model(noisy, t.to(DEV)).sample
+    loss = (noise.to(DEV) - out).square().sum(dim=(1, 2, 3)).mean(dim=0)
+    loss.backward()
+    P = oracle_params(cfg, 5)
+    lo = D.finetune_loss(P, cfg, clean, noise, t)
+    lo.backward()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if P[n].grad.abs().max() > 1e-6:
+            worst = max(worst, relerr(p.grad, P[n].grad))
+    e_l = abs(float(loss) - float(lo)) / float(lo)
+    # finetune engine, 2 steps
+    model2 = make_model(cfg, 5)
+    eng = train.FinetuneEngine(model2, sched, lr=2e-4, ema_decay=0.9999)
+    P2 = oracle_params(cfg, 5)
+    names = list(P2)
+    m = [torch.zeros_like(P2[n]) for n in names]
+    v = [torch.zeros_like(P2[n]) for n in names]
+    ema = [P2[n].detach().clone() for n in names]
+    for step in (1, 2):
+        l_gpu = eng.step(clean.to(DEV), noise.to(DEV), t.to(DEV))
+        for n in names:
+            P2[n].grad = None
+        l_cpu = D.finetune_loss(P2, cfg, clean, noise, t)
+        l_cpu.backward()
+        with torch.no_grad():
+            D.adam_ema_step([P2[n] for n in names], [P2[n].grad for n in names], m, v, ema, step)
+    pm = dict(model2.named_parameters())
+    e_p = max(relerr(pm[n], P2[n].detach()) for n in names)
+    es = eng.ema_state()
+    e_e = max(relerr(es[n], e) for n, e in zip(names, ema))
+    report['e2e/finetune'] = dict(bridge_grad_rel=worst, bridge_loss_rel=e_l, param_rel_after2=e_p, ema_rel_after2=e_e,
+                                  loss2_rel=abs(float(l_gpu) - float(l_cpu)) / float(l_cpu))
+    assert worst < 5e-5 and e_l < 1e-5
+    # Adam normalises the gradient: parameters move by ~lr per step, so 1e-5 relative on parameters of size ~0.1-1
+    assert e_p < 1e-5 and e_e < 1e-5
