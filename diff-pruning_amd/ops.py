@@ -26,6 +26,31 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# When `_prof` is a list, every contraction launch is bracketed by HIP events recorded on the launch stream and
+# logged as (kernel name, algorithmic flops, start, end): bench.py's roofline leg reads it.
+_prof = None
+_TILE_NAMES = ('128, 128', '64, 128', '64, 64')
+
+
+def _run(call, name, flops):
+    if _prof is None:
+        return call()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    r = call()
+    en.record()
+    _prof.append((name, flops, st, en))
+    return r
+
+
+def _cg_name(p):
+    return 'conv_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if p.a_kc else 'false')
+
+
+def _nt_name(p):
+    return 'nt_gemm_kernel<%s>' % _TILE_NAMES[p.tile]
+
+
 def _chk_act(x):
     assert x.dtype == _f32 and x.is_cuda and x.dim() == 4, 'activation must be a 4-D fp32 device tensor'
     N, Cc, H, W = x.shape
@@ -128,7 +153,8 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
         p.res, p.r_img_stride = _p(res), _chk_act(res)
         assert res.shape == out.shape
     p.accumulate = 1 if accumulate else 0
-    L.check(_lib().dp_conv_gemm(C.byref(p), _stream()), 'dp_conv_gemm(forward)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps),
+            'dp_conv_gemm(forward)')
     return out
 
 
@@ -153,7 +179,8 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, 1.0
     p.accumulate = 1 if accumulate else 0
-    L.check(_lib().dp_conv_gemm(C.byref(p), _stream()), 'dp_conv_gemm(dgrad)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps),
+            'dp_conv_gemm(dgrad)')
     return out
 
 
@@ -204,12 +231,12 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     p.ldo = ncols
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
-        L.check(_lib().dp_nt_gemm(C.byref(p), _stream()), 'dp_nt_gemm(wgrad)')
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.P), 'dp_nt_gemm(wgrad)')
     else:
         n = Cout * ncols
         ws = _workspace(splits * n, dy.device)
         p.out, p.o_bs, p.accumulate = _p(ws), n, 0
-        L.check(_lib().dp_nt_gemm(C.byref(p), _stream()), 'dp_nt_gemm(wgrad)')
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.P), 'dp_nt_gemm(wgrad)')
         L.check(_lib().dp_splitk_reduce(_p(ws), n, splits, _p(gw), n, 1 if accumulate else 0, _stream()),
                 'dp_splitk_reduce')
     return gw
@@ -237,7 +264,7 @@ def bmm_tn(a, b, alpha=1.0, out=None):
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
     p.alpha, p.post_scale = alpha, 1.0
-    L.check(_lib().dp_conv_gemm(C.byref(p), _stream()), 'dp_conv_gemm(bmm_tn)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * Z * M * Nn * K), 'dp_conv_gemm(bmm_tn)')
     return out
 
 
@@ -256,7 +283,7 @@ def bmm_nn(a, b, alpha=1.0, out=None):
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
     p.alpha, p.post_scale = alpha, 1.0
-    L.check(_lib().dp_conv_gemm(C.byref(p), _stream()), 'dp_conv_gemm(bmm_nn)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * Z * M * Nn * K), 'dp_conv_gemm(bmm_nn)')
     return out
 
 
@@ -276,7 +303,7 @@ def bmm_nt(a, b, alpha=1.0, out=None):
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_bs, p.ldo, p.accumulate = _p(out), M * Nn, Nn, 0
     p.alpha = alpha
-    L.check(_lib().dp_nt_gemm(C.byref(p), _stream()), 'dp_nt_gemm(bmm_nt)')
+    L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * Z * M * Nn * K), 'dp_nt_gemm(bmm_nt)')
     return out
 
 

@@ -1,0 +1,74 @@
+"""Worker for tests/test_dist_cpu.py: one rank of a world_size-2 gloo job running the PRODUCT's data-parallel sweep and
+finetune control flow (diff-pruning_amd/sweep.py, train.py) with the kernel wrappers replaced by CPU stand-ins."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE, os.path.join(HERE, 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import golden_common as gc   # noqa: E402
+import mock_ops              # noqa: E402
+
+
+def pkg(sub):
+    return importlib.import_module('diff-pruning_amd.' + sub)
+
+
+def patch():
+    for sub in ('engine', 'sweep', 'train', 'diffusion', 'pruning'):
+        pkg(sub).ops = mock_ops
+    unet, engine, sweep, train = pkg('unet'), pkg('engine'), pkg('sweep'), pkg('train')
+
+    def cpu_engine(self):
+        if self._engine is None:
+            self._engine = engine.UNetEngine(self.config)
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        return self._engine
+    unet.UNet2DModel.engine = cpu_engine
+
+    def step_init(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
+        self.model, self.scheduler = model, scheduler
+        self.clean, self.noise, self.B = clean.contiguous().float(), noise.contiguous().float(), clean.shape[0]
+        self.gscale, self.lscale = 2.0 / global_numel, 1.0 / global_numel
+        self.eng = model.engine()
+        self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+        self.acp = scheduler.alphas_cumprod
+    sweep.HipSweepStep.__init__ = step_init
+
+
+def main():
+    rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    torch.set_num_threads(2)
+    patch()
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % port, rank=rank, world_size=world)
+    cfg = gc.TINY_CFG
+    model = pkg('unet').UNet2DModel(**cfg)
+    gc.det_init_(model, 5)
+    model.eval()
+    B = 4
+    clean = torch.from_numpy(gc.det_clean((B, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((B, 3, 16, 16), 2))
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    sched = pkg('diffusion').DDPMScheduler()
+    # Diff-Pruning sweep with early exit: every rank must stop at the same step, grads summed once at the end
+    res = pkg('sweep').taylor_sweep(model, sched, clean[sl], noise[sl], num_steps=50, thr=0.995)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    pr = pkg('sweep').prune_model(model, 0.3)
+    masks = [r[3] for r in pr.records]
+    torch.save(dict(losses=res['losses'], steps=res['steps'], grads=grads, masks=masks,
+                    global_batch=res['global_batch']), os.path.join(outdir, 'r%d_w%d.pt' % (rank, world)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

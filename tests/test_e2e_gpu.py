@@ -188,7 +188,7 @@ def test_autograd_bridge_and_finetune_step(report):
     for n, p in model.named_parameters():
         if P[n].grad.abs().max() > 1e-6:
             worst = max(worst, relerr(p.grad, P[n].grad))
-    e_l = abs(float(loss) - float(lo)) / float(lo)
+    e_l = abs(float(loss.detach()) - float(lo.detach())) / float(lo.detach())
     # finetune engine, 2 steps
     model2 = make_model(cfg, 5)
     eng = train.FinetuneEngine(model2, sched, lr=2e-4, ema_decay=0.9999)
@@ -206,7 +206,12 @@ def test_autograd_bridge_and_finetune_step(report):
         with torch.no_grad():
             D.adam_ema_step([P2[n] for n in names], [P2[n].grad for n in names], m, v, ema, step)
     pm = dict(model2.named_parameters())
-    e_p = max(relerr(pm[n], P2[n].detach()) for n in names)
+    # to_k.bias has an identically-zero gradient in exact arithmetic (softmax shift invariance); Adam normalises the
+    # fp32 rounding noise it receives to +-lr per step, so those parameters are only bounded by n_steps * lr.
+    noisy_names = [n for n in names if n.endswith('to_k.bias')]
+    for n in noisy_names:
+        assert float((pm[n].cpu() - P2[n].detach()).abs().max()) <= 2 * 2e-4 * 2 + 1e-7
+    e_p = max(relerr(pm[n], P2[n].detach()) for n in names if n not in noisy_names)
     es = eng.ema_state()
     e_e = max(relerr(es[n], e) for n, e in zip(names, ema))
     report['e2e/finetune'] = dict(bridge_grad_rel=worst, bridge_loss_rel=e_l, param_rel_after2=e_p, ema_rel_after2=e_e,
