@@ -22,6 +22,7 @@ class ConvGeom(C.Structure):
 class ConvGemmParams(C.Structure):
     _fields_ = [('A', C.c_void_p), ('a_bs', LL), ('lda', C.c_int), ('a_kc', C.c_int),
                 ('X1', C.c_void_p), ('X2', C.c_void_p), ('x_bs', LL),
+                ('a_bytes', C.c_uint), ('x1_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('_pad0', C.c_uint),
                 ('g', ConvGeom),
                 ('M', C.c_int), ('C', C.c_int), ('NPIX', C.c_int), ('ntaps', C.c_int), ('batches', C.c_int),
                 ('tile', C.c_int),
@@ -35,6 +36,7 @@ class ConvGemmParams(C.Structure):
 class NtGemmParams(C.Structure):
     _fields_ = [('A', C.c_void_p), ('a_bs', LL), ('a_img_stride', LL),
                 ('X1', C.c_void_p), ('X2', C.c_void_p), ('x_bs', LL),
+                ('a_bytes', C.c_uint), ('x1_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('_pad0', C.c_uint),
                 ('g', ConvGeom),
                 ('M', C.c_int), ('C', C.c_int), ('NCOLS', C.c_int), ('ntaps', C.c_int), ('P', C.c_int),
                 ('batches', C.c_int), ('splits', C.c_int), ('p_per_split', C.c_int), ('tile', C.c_int),

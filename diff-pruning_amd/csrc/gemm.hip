@@ -11,6 +11,35 @@
 // for k-contiguous ones).
 #include "dp_common.h"
 
+// Raw buffer loads: the hardware range check (offset >= num_records -> 0.0f) replaces every bounds / padding /
+// tail select, so the loaders are straight-line code and hipcc is free to hoist all global loads of tile i+1 above the
+// MFMAs of tile i.  Invalid elements set bit 31 of the byte offset (all real offsets are < 2 GiB, enforced by ops.py).
+#define DP_RSRC_FLAGS 0x00020000
+#define DP_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dp_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DP_RSRC_FLAGS);
+}
+// Descriptor for a base that is wave-uniform by construction but not provably so to the compiler: pinning the words
+// with readfirstlane keeps hipcc from wrapping every load in a waterfall loop (cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dp_rsrc_uniform(const float* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const float* b = (const float*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)__builtin_amdgcn_readfirstlane(bytes), DP_RSRC_FLAGS);
+}
+// The empty asm makes the (selected) offset opaque: without it hipcc turns load(select(valid, off, OOB)) back into
+// two predicated loads behind exec branches with a full vmcnt(0) wait after each.
+__device__ __forceinline__ float dp_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));   // b32 = raw bits
+}
+__device__ __forceinline__ float4 dp_bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA core: acc[TM][TN] += A_tile * B_tile for one LDS-resident K-tile.
 // A_KC: As[m*(BK+1) + k]  else As[k*BM + m];   B_KC: Bs[n*(BK+1) + k]  else Bs[k*BN + n].
@@ -21,32 +50,38 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
                                           int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
     const int li = lane & 31;
     const int lk = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
+    // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+    float a[2][TM], b[2][TN];
+    auto frag = [&](int ks, float (&fa)[TM], float (&fb)[TN]) {
         const int kk = ks * 2 + lk;
-        float a[TM], b[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int m = wm0 + tm * 32 + li;
-            a[tm] = A_KC ? As[m * (BK + 1) + kk] : As[kk * BM + m];
+            fa[tm] = A_KC ? As[m * (BK + 1) + kk] : As[kk * BM + m];
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = wn0 + tn * 32 + li;
-            b[tn] = B_KC ? Bs[n * (BK + 1) + kk] : Bs[kk * BN + n];
+            fb[tn] = B_KC ? Bs[n * (BK + 1) + kk] : Bs[kk * BN + n];
         }
+    };
+    frag(0, a[0], b[0]);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < BK / 2) frag(ks + 1, a[cur ^ 1], b[cur ^ 1]);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // conv_gemm
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC>
+template <int BM, int BN, bool A_KC, bool STRADDLE>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_params p) {
     constexpr int BK = 16;
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -102,7 +137,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_param
     float ras[NAS];
     float rb[NB];
 
-    auto load_tile = [&](int it) {
+    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(Ab, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t r1 = dp_rsrc(X1, p.x1_bytes);
+    const float* __restrict__ X2s = X2 ? X2 : X1;
+    const unsigned x2b = X2 ? p.x2_bytes : p.x1_bytes;
+    const __amdgpu_buffer_rsrc_t r2 = dp_rsrc(X2s, x2b);
+    const unsigned pb1 = (unsigned)b_img1 * 4u;        // byte offset of this thread's image in X1 / X2
+    const unsigned pb2 = (unsigned)b_img2 * 4u;
+    const int csplit = g.c_split;
+
+    auto load_tile = [&](int it, bool live) {
         const int tap = it / nch;
         const int c0 = (it - tap * nch) * BK;
         // A
@@ -112,34 +156,46 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_param
                 const int e = tid + 256 * j;
                 const int k = e / (BM / 4);
                 const int m = m0 + 4 * (e % (BM / 4));
-                const bool v = (c0 + k < C) && (m < p.lda);
-                ra4[j] = v ? *reinterpret_cast<const float4*>(Ab + (long long)(tap * C + c0 + k) * p.lda + m)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool v = live && (c0 + k < C) && (m < p.lda);
+                const unsigned o = (unsigned)(((tap * C + c0 + k) * p.lda + m) * 4);
+                ra4[j] = dp_bload4(rA, v ? o : DP_OOB);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NAS; ++j) {
                 const int k = tid & (BK - 1);
                 const int m = m0 + (tid / BK) + (256 / BK) * j;
-                const bool v = (m < p.M) && (c0 + k < C);
-                ras[j] = v ? Ab[(long long)m * p.lda + c0 + k] : 0.f;
+                const bool v = live && (m < p.M) && (c0 + k < C);
+                const unsigned o = (unsigned)((m * p.lda + c0 + k) * 4);
+                ras[j] = dp_bload(rA, v ? o : DP_OOB);
             }
         }
         // B
         const int ky = tap / g.kw;
         const int kx = tap - ky * g.kw;
         int off;
-        const bool tv = dp_gather(g, b_ho, b_wo, ky, kx, off) && bpv;
+        const bool tv = dp_gather(g, b_ho, b_wo, ky, kx, off) && bpv && live;
+        const int cb = c0 + bk0;
+        if constexpr (!STRADDLE) {                          // every K-chunk lives in one source (host-checked)
+            const bool first = c0 < csplit;                  // chunk start decides (c_split % 16 == 0 or single source)
+            const __amdgpu_buffer_rsrc_t rs = dp_rsrc_uniform(first ? X1 : X2s, first ? p.x1_bytes : x2b);
+            const unsigned o0 = (first ? pb1 : pb2) + (unsigned)(((first ? cb : cb - csplit) * HsWs + off) * 4);
+            const unsigned step = (unsigned)(BROWS * HsWs * 4);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int c = c0 + bk0 + BROWS * j;
-            const bool v = tv && (c < C);
-            float val = 0.f;
-            if (v) {
-                if (c < g.c_split) val = X1[b_img1 + (long long)c * HsWs + off];
-                else               val = X2[b_img2 + (long long)(c - g.c_split) * HsWs + off];
+            for (int j = 0; j < NB; ++j) {
+                const bool v = tv && (cb + BROWS * j < C);
+                rb[j] = dp_bload(rs, v ? (o0 + j * step) : DP_OOB);
             }
-            rb[j] = val;
+        } else {                                            // chunk straddles the concat boundary (pruned widths)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int c = cb + BROWS * j;
+                const bool v = tv && (c < C);
+                const bool f1 = c < csplit;
+                const unsigned o1 = pb1 + (unsigned)((c * HsWs + off) * 4);
+                const unsigned o2 = pb2 + (unsigned)(((c - csplit) * HsWs + off) * 4);
+                rb[j] = dp_bload(r1, (v && f1) ? o1 : DP_OOB) + dp_bload(r2, (v && !f1) ? o2 : DP_OOB);
+            }
         }
     };
 
@@ -174,15 +230,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_param
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    load_tile(0);
+    // The prefetch of tile it+1 is unconditional: past the last tile every offset is out of range (the buffer
+    // unit returns zeros without touching memory), so there is no branch and no register merge that would force
+    // hipcc to drain the loads before the MFMA block.
+    load_tile(0, true);
     store_tile(0);
     __syncthreads();
     for (int it = 0; it < nIter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nIter) load_tile(it + 1);
+        load_tile(it + 1, it + 1 < nIter);
         const float* As = smem + buf * STAGE;
         mfma_tile<BM, BN, BK, TM, TN, A_KC, false>(As, As + A_SZ, wm0, wn0, lane, acc);
-        if (it + 1 < nIter) store_tile(buf ^ 1);
+        store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -219,8 +278,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_param
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.batches > 0 ? p.batches : 1);
-    if (p.a_kc) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, p);
-    else        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, p);
+    // a K-chunk of 16 channels can straddle the concat boundary only when c_split is not a multiple of 16
+    const bool straddle = p.X2 != nullptr && (p.g.c_split % 16) != 0;
+    if (p.a_kc) {
+        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, p);
+        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, p);
+        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, p);
+    }
     return DP_LAUNCH_CHECK();
 }
 
@@ -239,9 +305,12 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// nt_gemm
+// nt_gemm: D[m][c] (per tap) = alpha * sum_pix A[m][pix] * X(pix, c, tap)
+//   blockIdx.z = batch (batched mode) or split*ntaps + tap: one kernel tap per workgroup, so the gather geometry is
+//   wave-uniform and the per-element address is one add (same loader cost as conv_gemm).
+//   Output element (m, c, tap) at out[zo*o_bs + m*ldo + c*ntaps + tap]  (torch [Cout][Cin][kh][kw] layout).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, bool STRADDLE>
 __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p) {
     constexpr int BK = 32;
     constexpr int LD = BK + 1;
@@ -265,61 +334,73 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
     const int HoWo = g.Ho * g.Wo;
     const int HsWs = g.Hs * g.Ws;
     const int batch = p.batched ? z : 0;
-    const int p_begin = p.batched ? 0 : z * p.p_per_split;
+    const int split = p.batched ? 0 : z / p.ntaps;
+    const int tap = p.batched ? 0 : z - split * p.ntaps;
+    const int ky = tap / g.kw;
+    const int kx = tap - ky * g.kw;
+    const int p_begin = split * p.p_per_split;
     int p_end = p.batched ? p.P : (p_begin + p.p_per_split);
     if (p_end > p.P) p_end = p.P;
     const int nIter = (p_end > p_begin) ? (p_end - p_begin + BK - 1) / BK : 0;
 
     const float* __restrict__ Ab = p.A + (long long)batch * p.a_bs;
     const float* __restrict__ X1 = p.X1 + (long long)batch * p.x_bs;
-    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)batch * p.x_bs : nullptr;
+    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)batch * p.x_bs : X1;
+    const int csplit = g.c_split;
 
     constexpr int NA = BM / 8;
     constexpr int NB = BN / 8;
-    const int lk = tid & 31;       // this thread's k (pixel) within the K-tile
+    const int lk = tid & 31;       // this thread's pixel within the K-tile
     const int r0 = tid >> 5;       // first row; rows r0 + 8*j
     float ra[NA], rb[NB];
+    // the N-tile [n0, n0+BN) is either entirely inside one source or straddles the concat boundary (block-uniform)
+    const bool first_src = n0 < csplit;               // tile start decides in the non-straddling variant
 
-    // column decode (fixed per thread): n -> (c, ky, kx), packed as c*16 + ky*4 + kx (-1 = out of range)
-    int bcode[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int col = n0 + r0 + 8 * j;
-        const int c = col / p.ntaps;
-        const int tap = col - c * p.ntaps;
-        const int ky = tap / g.kw;
-        const int kx = tap - ky * g.kw;
-        bcode[j] = (col < p.NCOLS) ? (c * 16 + ky * 4 + kx) : -1;
-    }
+    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(Ab, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t r1 = dp_rsrc(X1, p.x1_bytes);
+    const __amdgpu_buffer_rsrc_t r2 = dp_rsrc(X2, p.X2 ? p.x2_bytes : p.x1_bytes);
+    const __amdgpu_buffer_rsrc_t rs_one = dp_rsrc_uniform(first_src ? X1 : X2, (first_src || !p.X2) ? p.x1_bytes : p.x2_bytes);
 
-    auto load_tile = [&](int it) {
+    auto load_tile = [&](int it, bool live) {
         const int pp = p_begin + it * BK + lk;
-        const bool pv = pp < p_end;
-        const int pq = pv ? pp : 0;
+        const bool pv = live && (pp < p_end);
+        const int pq = pv ? pp : p_begin;
         const int img = pq / HoWo;
         const int r = pq - img * HoWo;
         const int ho = r / g.Wo;
         const int wo = r - ho * g.Wo;
-        const long long abase = (long long)img * p.a_img_stride + r;
-        const long long i1 = (long long)img * g.x1_img_stride;
-        const long long i2 = (long long)img * g.x2_img_stride;
+        const unsigned ab = (unsigned)(((long long)img * p.a_img_stride + r) * 4);
+        const unsigned astep = (unsigned)(HoWo * 4);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int m = m0 + r0 + 8 * j;
-            ra[j] = (pv && m < p.M) ? Ab[abase + (long long)m * HoWo] : 0.f;
+            const bool v = pv && (m < p.M);
+            ra[j] = dp_bload(rA, v ? (ab + (unsigned)m * astep) : DP_OOB);
         }
+        int off;
+        const bool tv = dp_gather(g, ho, wo, ky, kx, off) && pv;
+        const unsigned pb1 = (unsigned)((long long)img * g.x1_img_stride * 4);
+        const unsigned pb2 = (unsigned)((long long)img * g.x2_img_stride * 4);
+        const int cb = n0 + r0;
+        if constexpr (!STRADDLE) {
+            const __amdgpu_buffer_rsrc_t rs = rs_one;
+            const unsigned o0 = (first_src ? pb1 : pb2) + (unsigned)(((first_src ? cb : cb - csplit) * HsWs + off) * 4);
+            const unsigned step = (unsigned)(8 * HsWs * 4);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int off;
-            const int code = bcode[j];
-            const bool v = pv && (code >= 0) && dp_gather(g, ho, wo, (code >> 2) & 3, code & 3, off);
-            float val = 0.f;
-            if (v) {
-                const int c = code >> 4;
-                if (c < g.c_split) val = X1[i1 + (long long)c * HsWs + off];
-                else               val = X2[i2 + (long long)(c - g.c_split) * HsWs + off];
+            for (int j = 0; j < NB; ++j) {
+                const bool v = tv && (cb + 8 * j < p.NCOLS);
+                rb[j] = dp_bload(rs, v ? (o0 + j * step) : DP_OOB);
             }
-            rb[j] = val;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int c = cb + 8 * j;
+                const bool v = tv && (c < p.NCOLS);
+                const bool f1 = c < csplit;
+                const unsigned o1 = pb1 + (unsigned)((c * HsWs + off) * 4);
+                const unsigned o2 = pb2 + (unsigned)(((c - csplit) * HsWs + off) * 4);
+                rb[j] = dp_bload(r1, (v && f1) ? o1 : DP_OOB) + dp_bload(r2, (v && !f1) ? o2 : DP_OOB);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -339,21 +420,20 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    if (nIter > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
+    load_tile(0, nIter > 0);
+    store_tile(0);
     __syncthreads();
     for (int it = 0; it < nIter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nIter) load_tile(it + 1);
+        load_tile(it + 1, it + 1 < nIter);
         const float* As = smem + buf * STAGE;
         mfma_tile<BM, BN, BK, TM, TN, true, true>(As, As + A_SZ, wm0, wn0, lane, acc);
-        if (it + 1 < nIter) store_tile(buf ^ 1);
+        store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    float* __restrict__ outb = p.out + (long long)z * p.o_bs;
+    const int zo = p.batched ? z : split;
+    float* __restrict__ outb = p.out + (long long)zo * p.o_bs + tap;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn0 + tn * 32 + (lane & 31);
@@ -364,7 +444,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
-                float* o = outb + (long long)m * p.ldo + col;
+                float* o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
                 float v = p.alpha * acc[tm][tn][r];
                 if (p.accumulate) v += *o;
                 *o = v;
@@ -375,9 +455,11 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
 
 template <int BM, int BN>
 static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
-    const int gz = p.batched ? p.batches : p.splits;
+    const int gz = p.batched ? p.batches : p.splits * p.ntaps;
     dim3 grid((p.NCOLS + BN - 1) / BN, (p.M + BM - 1) / BM, gz > 0 ? gz : 1);
-    hipLaunchKernelGGL((nt_gemm_kernel<BM, BN>), grid, dim3(256), 0, st, p);
+    const bool straddle = p.X2 != nullptr && (p.g.c_split % BN) != 0;     // an N-tile may span both concat sources
+    if (straddle) hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, p);
+    else          hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, p);
     return DP_LAUNCH_CHECK();
 }
 

@@ -199,20 +199,30 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     return DP_LAUNCH_CHECK();
 }
 
-// out[c*1] (+)= sum_n ws[(n*C + c)*wstride + woff]
+// out[c] (+)= sum_n ws[(n*C + c)*wstride + woff].  64 channels per workgroup (coalesced across lanes), the rows are
+// split over the 4 wavefronts and combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, int N, int C, int wstride, int woff,
                                                      float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += ws[((long long)n * C + c) * wstride + woff];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C) {
+        for (int n = wave; n < N; n += 4) s += ws[((long long)n * C + c) * wstride + woff];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 extern "C" int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate,
                                void* stream) {
     if (C <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, N, C, wstride, woff, out,
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, N, C, wstride, woff, out,
                        accumulate);
     return DP_LAUNCH_CHECK();
 }

@@ -44,11 +44,15 @@ def _run(call, name, flops):
 
 
 def _cg_name(p):
-    return 'conv_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if p.a_kc else 'false')
+    straddle = bool(p.X2) and (p.g.c_split % 16) != 0
+    return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[p.tile], 'true' if p.a_kc else 'false',
+                                             'true' if straddle else 'false')
 
 
 def _nt_name(p):
-    return 'nt_gemm_kernel<%s>' % _TILE_NAMES[p.tile]
+    bn = _TILES[p.tile][1]
+    straddle = bool(p.X2) and (p.g.c_split % bn) != 0
+    return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if straddle else 'false')
 
 
 def _chk_act(x):
@@ -57,6 +61,22 @@ def _chk_act(x):
     assert x.stride(3) == 1 or W == 1
     assert (x.stride(2) == W or H == 1) and (x.stride(1) == H * W or Cc == 1), 'inner strides must be contiguous'
     return x.stride(0) if N > 1 else Cc * H * W
+
+
+_MAX_BYTES = 1 << 31
+
+
+def _extent_bytes(x):
+    """Readable extent (bytes) of a 4-D activation view starting at its data_ptr; must stay below 2 GiB because the
+    kernels address it through a raw buffer descriptor with 32-bit offsets (bit 31 marks out-of-range elements)."""
+    if x is None:
+        return 0
+    N, Cc, H, W = x.shape
+    s0 = x.stride(0) if N > 1 else 0
+    n = ((N - 1) * s0 + Cc * H * W) * 4
+    if n >= _MAX_BYTES:
+        raise ValueError('tensor extent %d bytes >= 2 GiB: split the batch (32-bit buffer addressing)' % n)
+    return n
 
 
 def as4d(x):
@@ -141,6 +161,7 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(wp), 0, ld, 0
     p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = wp.numel() * 4, _extent_bytes(x), _extent_bytes(x2)
     p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
                 C1 if x2 is not None else Cin, s1, s2)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = Cout, Cin, N * Ho * Wo, spec.k * spec.k, 1
@@ -171,6 +192,7 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(wd), 0, ldd, 0
     p.X1, p.X2, p.x_bs = _p(dy), None, 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = wd.numel() * 4, _extent_bytes(dy), 0
     # dX[h] = sum_ky' dY[(h + ky' - (k-1-pad)) / stride] Wflip[ky']
     padp = spec.k - 1 - spec.pad
     p.g = _geom(Hv, Wv, Ho, Wo, Ho, Wo, spec.k, 1, spec.stride, padp, padp, 0, Cout, sd, 0)
@@ -211,10 +233,12 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     assert gw.is_contiguous() and gw.numel() == Cout * Cin * taps
     ncols = Cin * taps
     P = N * Ho * Wo
-    tile = pick_tile(Cout, ncols)
+    # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension
+    # (N*Ho*Wo, up to 262144) supplies the parallelism; partial sums are reduced in a fixed order (deterministic).
+    tile = 0 if Cout > 64 else 1
     bm, bn, _ = _TILES[tile]
-    tiles = -(-Cout // bm) * -(-ncols // bn)
-    splits = max(1, min(-(-768 // tiles), P // 512 if P >= 1024 else 1))
+    tiles = -(-Cout // bm) * -(-Cin // bn) * taps
+    splits = max(1, min(-(-768 // tiles), P // 1024 if P >= 2048 else 1))
     if max_splits is not None:
         splits = max(1, min(splits, max_splits))
     pps = -(-P // splits)
@@ -223,20 +247,21 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     p = L.NtGemmParams()
     p.A, p.a_bs, p.a_img_stride = _p(dy), 0, sd
     p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(dy), _extent_bytes(x), _extent_bytes(x2)
     p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
                 C1 if x2 is not None else Cin, s1, s2)
-    p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, ncols, taps, P
+    p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, taps, P
     p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, pps, tile, 0
     p.alpha = alpha
     p.ldo = ncols
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
-        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.P), 'dp_nt_gemm(wgrad)')
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.ntaps * p.P), 'dp_nt_gemm(wgrad)')
     else:
         n = Cout * ncols
         ws = _workspace(splits * n, dy.device)
         p.out, p.o_bs, p.accumulate = _p(ws), n, 0
-        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.P), 'dp_nt_gemm(wgrad)')
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * p.M * p.NCOLS * p.ntaps * p.P), 'dp_nt_gemm(wgrad)')
         L.check(_lib().dp_splitk_reduce(_p(ws), n, splits, _p(gw), n, 1 if accumulate else 0, _stream()),
                 'dp_splitk_reduce')
     return gw
@@ -259,6 +284,7 @@ def bmm_tn(a, b, alpha=1.0, out=None):
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(a), K * M, M, 0
     p.X1, p.X2, p.x_bs = _p(b), None, K * Nn
+    p.a_bytes, p.x1_bytes, p.x2_bytes = K * M * 4, K * Nn * 4, 0
     p.g = _bgeom(Nn, K)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
@@ -278,6 +304,7 @@ def bmm_nn(a, b, alpha=1.0, out=None):
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(a), M * K, K, 1
     p.X1, p.X2, p.x_bs = _p(b), None, K * Nn
+    p.a_bytes, p.x1_bytes, p.x2_bytes = M * K * 4, K * Nn * 4, 0
     p.g = _bgeom(Nn, K)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
@@ -297,6 +324,7 @@ def bmm_nt(a, b, alpha=1.0, out=None):
     p = L.NtGemmParams()
     p.A, p.a_bs, p.a_img_stride = _p(a), M * K, 0
     p.X1, p.X2, p.x_bs = _p(b), None, Nn * K
+    p.a_bytes, p.x1_bytes, p.x2_bytes = M * K * 4, Nn * K * 4, 0
     p.g = _bgeom(K, Nn)
     p.M, p.C, p.NCOLS, p.ntaps, p.P = M, Nn, Nn, 1, K
     p.batches, p.splits, p.p_per_split, p.batched = Z, 1, 0, 1

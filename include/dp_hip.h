@@ -37,6 +37,7 @@ typedef struct dp_conv_geom {
 typedef struct dp_conv_gemm_params {
     const float* A; long long a_bs; int lda; int a_kc;
     const float* X1; const float* X2; long long x_bs;
+    unsigned a_bytes, x1_bytes, x2_bytes, _pad0;   /* readable extent of A / X1 / X2 (per batch), each < 2 GiB */
     dp_conv_geom g;
     int M, C, NPIX, ntaps, batches, tile;      /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
     float* out; long long o_img_stride; long long o_bs;
@@ -47,17 +48,18 @@ typedef struct dp_conv_gemm_params {
 } dp_conv_gemm_params;
 int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
 
-/* D[m][n] = alpha * sum_pix A[m][pix] * X(pix, n=(c,tap))  -- weight gradients (split over pixels) and the
- * k-contiguous batched products of attention (P.V, dQ).  Replaces the weight-gradient half of
+/* D[m][c][tap] = alpha * sum_pix A[m][pix] * X(pix, c, tap)  -- weight gradients (split over pixels, one kernel tap
+ * per workgroup) and the k-contiguous batched products of attention (P.V, dQ).  Replaces the weight-gradient half of
  * ConvolutionBackward / AddmmBackward reached from loss.backward() (ddpm_prune.py:102) and torch.bmm
  * (attention_processor.py:446).
- * A element (m, pix=(img,r)) at A + z*a_bs + img*a_img_stride + m*HoWo + r.
- * batched = 1: blockIdx.z = batch, output out[z*o_bs + m*ldo + n];
- * batched = 0: blockIdx.z = split over pixels, partial sums to out[split*o_bs + m*ldo + n]
+ * A element (m, pix=(img,r)) at A + z*a_bs + img*a_img_stride + m*HoWo + r;  NCOLS = number of channels c.
+ * batched = 1: blockIdx.z = batch, output out[z*o_bs + m*ldo + c]  (ntaps must be 1);
+ * batched = 0: blockIdx.z = split*ntaps + tap, partial sums to out[split*o_bs + m*ldo + c*ntaps + tap]
  *              (reduce with dp_splitk_reduce), or direct (+accumulate) when splits == 1. */
 typedef struct dp_nt_gemm_params {
     const float* A; long long a_bs; long long a_img_stride;
     const float* X1; const float* X2; long long x_bs;
+    unsigned a_bytes, x1_bytes, x2_bytes, _pad0;   /* readable extent of A / X1 / X2 (per batch), each < 2 GiB */
     dp_conv_geom g;
     int M, C, NCOLS, ntaps, P, batches, splits, p_per_split, tile, batched;   /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
     float* out; long long o_bs; int ldo; int accumulate;

@@ -197,23 +197,27 @@ def test_autograd_bridge_and_finetune_step(report):
     m = [torch.zeros_like(P2[n]) for n in names]
     v = [torch.zeros_like(P2[n]) for n in names]
     ema = [P2[n].detach().clone() for n in names]
+    worst_g = 0.0
     for step in (1, 2):
         l_gpu = eng.step(clean.to(DEV), noise.to(DEV), t.to(DEV))
         for n in names:
             P2[n].grad = None
         l_cpu = D.finetune_loss(P2, cfg, clean, noise, t)
         l_cpu.backward()
+        gpu_g = {n: p.grad.detach().cpu().clone() for n, p in model2.named_parameters()}   # raw (un-clipped) grads
+        for n in names:
+            if float(P2[n].grad.abs().max()) > 1e-6:
+                worst_g = max(worst_g, relerr(gpu_g[n], P2[n].grad))
+        # The optimizer arithmetic is checked on IDENTICAL gradients (Adam's g/(sqrt(v)+eps) turns the fp32 rounding
+        # noise of near-zero gradient elements into +-lr steps, so parameters are not comparable across two
+        # independently rounded backward passes; gradients are -- see worst_g).
         with torch.no_grad():
-            D.adam_ema_step([P2[n] for n in names], [P2[n].grad for n in names], m, v, ema, step)
+            D.adam_ema_step([P2[n] for n in names], [gpu_g[n] for n in names], m, v, ema, step)
     pm = dict(model2.named_parameters())
-    # to_k.bias has an identically-zero gradient in exact arithmetic (softmax shift invariance); Adam normalises the
-    # fp32 rounding noise it receives to +-lr per step, so those parameters are only bounded by n_steps * lr.
-    noisy_names = [n for n in names if n.endswith('to_k.bias')]
-    for n in noisy_names:
-        assert float((pm[n].cpu() - P2[n].detach()).abs().max()) <= 2 * 2e-4 * 2 + 1e-7
-    e_p = max(relerr(pm[n], P2[n].detach()) for n in names if n not in noisy_names)
+    e_p = max(relerr(pm[n], P2[n].detach()) for n in names)
     es = eng.ema_state()
     e_e = max(relerr(es[n], e) for n, e in zip(names, ema))
+    assert worst_g < 5e-5, worst_g
     report['e2e/finetune'] = dict(bridge_grad_rel=worst, bridge_loss_rel=e_l, param_rel_after2=e_p, ema_rel_after2=e_e,
                                   loss2_rel=abs(float(l_gpu) - float(l_cpu)) / float(l_cpu))
     assert worst < 5e-5 and e_l < 1e-5
