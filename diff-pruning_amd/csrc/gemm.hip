@@ -82,7 +82,7 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 // conv_gemm
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool A_KC, bool STRADDLE>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_params p) {
+__global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_params p) {
     constexpr int BK = 16;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -146,9 +146,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dp_conv_gemm_param
     const unsigned pb2 = (unsigned)b_img2 * 4u;
     const int csplit = g.c_split;
 
+    // K order: channel chunk outer, kernel tap inner -- the 16-channel input slab (tile + halo, ~10 KB) is re-read by
+    // the 9 taps back-to-back and stays in L1/L2 instead of being evicted between taps.
     auto load_tile = [&](int it, bool live) {
-        const int tap = it / nch;
-        const int c0 = (it - tap * nch) * BK;
+        const int ch = it / p.ntaps;
+        const int tap = it - ch * p.ntaps;
+        const int c0 = ch * BK;
         // A
         if constexpr (!A_KC) {
 #pragma unroll
@@ -310,10 +313,14 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
 //   wave-uniform and the per-element address is one add (same loader cost as conv_gemm).
 //   Output element (m, c, tap) at out[zo*o_bs + m*ldo + c*ntaps + tap]  (torch [Cout][Cin][kh][kw] layout).
 // ------------------------------------------------------------------------------------------------
+#ifndef NT_BK
+#define NT_BK 16
+#endif
 template <int BM, int BN, bool STRADDLE>
-__global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p) {
-    constexpr int BK = 32;
+__global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params p) {
+    constexpr int BK = NT_BK;
     constexpr int LD = BK + 1;
+    constexpr int RSTEP = 256 / BK;      // rows covered per pass of the 256 threads
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_SZ = BM * LD;
@@ -348,10 +355,10 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
     const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)batch * p.x_bs : X1;
     const int csplit = g.c_split;
 
-    constexpr int NA = BM / 8;
-    constexpr int NB = BN / 8;
-    const int lk = tid & 31;       // this thread's pixel within the K-tile
-    const int r0 = tid >> 5;       // first row; rows r0 + 8*j
+    constexpr int NA = BM / RSTEP;
+    constexpr int NB = BN / RSTEP;
+    const int lk = tid & (BK - 1);  // this thread's pixel within the K-tile
+    const int r0 = tid / BK;        // first row; rows r0 + RSTEP*j
     float ra[NA], rb[NB];
     // the N-tile [n0, n0+BN) is either entirely inside one source or straddles the concat boundary (block-uniform)
     const bool first_src = n0 < csplit;               // tile start decides in the non-straddling variant
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
         const unsigned astep = (unsigned)(HoWo * 4);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int m = m0 + r0 + 8 * j;
+            const int m = m0 + r0 + RSTEP * j;
             const bool v = pv && (m < p.M);
             ra[j] = dp_bload(rA, v ? (ab + (unsigned)m * astep) : DP_OOB);
         }
@@ -385,16 +392,16 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
         if constexpr (!STRADDLE) {
             const __amdgpu_buffer_rsrc_t rs = rs_one;
             const unsigned o0 = (first_src ? pb1 : pb2) + (unsigned)(((first_src ? cb : cb - csplit) * HsWs + off) * 4);
-            const unsigned step = (unsigned)(8 * HsWs * 4);
+            const unsigned step = (unsigned)(RSTEP * HsWs * 4);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const bool v = tv && (cb + 8 * j < p.NCOLS);
+                const bool v = tv && (cb + RSTEP * j < p.NCOLS);
                 rb[j] = dp_bload(rs, v ? (o0 + j * step) : DP_OOB);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int c = cb + 8 * j;
+                const int c = cb + RSTEP * j;
                 const bool v = tv && (c < p.NCOLS);
                 const bool f1 = c < csplit;
                 const unsigned o1 = pb1 + (unsigned)((c * HsWs + off) * 4);
@@ -407,9 +414,9 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const dp_nt_gemm_params p)
         float* As = smem + buf * STAGE;
         float* Bs = As + A_SZ;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) As[(r0 + 8 * j) * LD + lk] = ra[j];
+        for (int j = 0; j < NA; ++j) As[(r0 + RSTEP * j) * LD + lk] = ra[j];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Bs[(r0 + 8 * j) * LD + lk] = rb[j];
+        for (int j = 0; j < NB; ++j) Bs[(r0 + RSTEP * j) * LD + lk] = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -467,7 +474,7 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
     const dp_nt_gemm_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     if (p.M <= 0 || p.NCOLS <= 0) return 0;
-    if (!p.batched && (p.p_per_split <= 0 || (p.p_per_split & 31))) return (int)hipErrorInvalidValue;
+    if (!p.batched && (p.p_per_split <= 0 || (p.p_per_split & (NT_BK - 1)))) return (int)hipErrorInvalidValue;
     switch (p.tile) {
         case 0: return launch_nt_gemm<128, 128>(p, st);
         case 1: return launch_nt_gemm<64, 128>(p, st);

@@ -209,7 +209,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < C) {
-        for (int n = wave; n < N; n += 4) s += ws[((long long)n * C + c) * wstride + woff];
+        // 4 independent partial sums keep 4 loads in flight per lane (the loop is latency-, not bandwidth-bound)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int n = wave;
+        for (; n + 12 < N; n += 16) {
+            s0 += ws[((long long)n * C + c) * wstride + woff];
+            s1 += ws[((long long)(n + 4) * C + c) * wstride + woff];
+            s2 += ws[((long long)(n + 8) * C + c) * wstride + woff];
+            s3 += ws[((long long)(n + 12) * C + c) * wstride + woff];
+        }
+        for (; n < N; n += 4) s0 += ws[((long long)n * C + c) * wstride + woff];
+        s = (s0 + s1) + (s2 + s3);
     }
     part[wave][lane] = s;
     __syncthreads();
