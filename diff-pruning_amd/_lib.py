@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdp_hip.so')
+LIB_PATH = os.environ.get('DP_HIP_LIB') or os.path.join(_HERE, 'libdp_hip.so')   # DP_HIP_LIB: kernel A/B experiments
 
 c_float_p = C.c_void_p
 LL = C.c_longlong

@@ -66,6 +66,9 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
         }
     };
     frag(0, a[0], b[0]);
+#ifdef DP_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
         const int cur = ks & 1;
@@ -76,6 +79,9 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
     }
+#ifdef DP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -97,7 +103,18 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     const int wm0 = (wave >> 1) * WM;
     const int wn0 = (wave & 1) * WN;
     const int m0 = blockIdx.y * BM;
+#ifdef DP_XCD
+    // workgroup b is dispatched to XCD b % 8: remap so that each XCD owns a contiguous run of pixel tiles (neighbouring
+    // tiles share input halo rows and all tiles share the weights -> private-L2 reuse).  Bijective for any grid size.
+    int bx = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bx & 7, k = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n0 = bx * BN;
+#else
     const int n0 = blockIdx.x * BN;
+#endif
     const int z = blockIdx.z;
 
     const ConvGeom& g = p.g;

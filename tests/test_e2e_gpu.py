@@ -223,3 +223,41 @@ def test_autograd_bridge_and_finetune_step(report):
     assert worst < 5e-5 and e_l < 1e-5
     # Adam normalises the gradient: parameters move by ~lr per step, so 1e-5 relative on parameters of size ~0.1-1
     assert e_p < 1e-5 and e_e < 1e-5
+
+
+def test_pruned_model_sweep_matches_oracle(report):
+    """After pruning, channel counts are no longer multiples of 16 and the concat boundaries fall inside K-chunks /
+    N-tiles: the straddling variants of the contraction kernels are exercised in forward, dgrad and wgrad."""
+    from oracle import diffusion_ref as D
+    cfg = gc.TINY_CFG
+    model = make_model(cfg, 5)
+    clean, noise = _inputs(2, 16)
+    _run_sweep(model, clean, noise, 4)
+    pkg('sweep').prune_model(model, 0.3)
+    P = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    res = _run_sweep(model, clean, noise, 2)
+    ref = D.taylor_sweep(P, cfg, clean, noise, 2)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-7:
+            worst = max(worst, relerr(p.grad, P[n].grad))
+    report['e2e/pruned_sweep'] = dict(loss_rel=max(abs(a - b) / b for a, b in zip(res['losses'], ref)), grad_rel_worst=worst,
+                                      widths=sorted({int(p.shape[0]) for p in model.parameters()}))
+    assert report['e2e/pruned_sweep']['loss_rel'] < 1e-5 and worst < 2e-5
+
+
+def test_bedroom_topology_sweep_matches_oracle(report):
+    """6-level bedroom/church topology (attention in the 5th down / 2nd up block, 18 skips) at reduced width, 64x64."""
+    from oracle import diffusion_ref as D
+    cfg = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
+    model = make_model(cfg, 7)
+    clean, noise = _inputs(2, 64, 11, 12)
+    res = _run_sweep(model, clean, noise, 2)
+    P = oracle_params(cfg, 7)
+    ref = D.taylor_sweep(P, cfg, clean, noise, 2)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-7:
+            worst = max(worst, relerr(p.grad, P[n].grad))
+    report['e2e/bedroom_topology'] = dict(loss_rel=max(abs(a - b) / b for a, b in zip(res['losses'], ref)), grad_rel_worst=worst)
+    assert report['e2e/bedroom_topology']['loss_rel'] < 1e-5 and worst < 2e-5
