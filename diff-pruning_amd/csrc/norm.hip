@@ -95,6 +95,93 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __r
     }
 }
 
+// float4 variant (HW % 4 == 0, 16-byte aligned planes): a float4 never straddles a channel.
+__global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int C, int HW, int G, float eps,
+                                                          int silu, float* __restrict__ y, long long y_img_stride,
+                                                          float* __restrict__ stats) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / G;
+    const int g = blockIdx.x - n * G;
+    const int cpg = C / G;
+    const int cnt4 = cpg * HW / 4;
+    const int HW4 = HW / 4;
+    const int tid = threadIdx.x;
+    const bool cached = cnt4 <= 256 * (GN_CACHE / 4);
+    const int c_base = g * cpg;
+    float4 xr[GN_CACHE / 4];
+    float s = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE / 4; ++i) {
+            const int e = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < cnt4) {
+                const int cl = e / HW4;
+                v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
+            }
+            xr[i] = v;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int e = tid; e < cnt4; e += 256) {
+            const int cl = e / HW4;
+            const float4 v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    }
+    const float mean = dp_block_sum_256(s, red) / (float)(cnt4 * 4);
+    float q = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE / 4; ++i) {
+            const int e = tid + 256 * i;
+            if (e < cnt4) {
+                const float4 v = xr[i];
+                const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+    } else {
+        for (int e = tid; e < cnt4; e += 256) {
+            const int cl = e / HW4;
+            const float4 v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = dp_block_sum_256(q, red) / (float)(cnt4 * 4);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (tid == 0) {
+        stats[(long long)blockIdx.x * 2 + 0] = mean;
+        stats[(long long)blockIdx.x * 2 + 1] = rstd;
+    }
+    float4* yb = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c_base * HW);
+    auto apply = [&](float4 v, int c) {
+        const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
+        float4 o;
+        o.x = (v.x - mean) * rstd * gamma[c] + beta[c];
+        o.y = (v.y - mean) * rstd * gamma[c] + beta[c];
+        o.z = (v.z - mean) * rstd * gamma[c] + beta[c];
+        o.w = (v.w - mean) * rstd * gamma[c] + beta[c];
+        (void)ga; (void)be;
+        if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+        return o;
+    };
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < GN_CACHE / 4; ++i) {
+            const int e = tid + 256 * i;
+            if (e < cnt4) yb[e] = apply(xr[i], c_base + e / HW4);
+        }
+    } else {
+        for (int e = tid; e < cnt4; e += 256) {
+            const int cl = e / HW4;
+            yb[e] = apply(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4], c_base + cl);
+        }
+    }
+}
+
 extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                      long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
                                      int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
@@ -102,8 +189,14 @@ extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_spl
     if (N <= 0 || C <= 0) return 0;
     if (C % G) return (int)hipErrorInvalidValue;
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
-    hipLaunchKernelGGL(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu, y,
-                       y_img_stride, stats);
+    const bool vec4 = (HW % 4 == 0) && (x1_img_stride % 4 == 0) && (x2_img_stride % 4 == 0) && (y_img_stride % 4 == 0) &&
+                      (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0);
+    if (vec4)
+        hipLaunchKernelGGL(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
+                           silu, y, y_img_stride, stats);
+    else
+        hipLaunchKernelGGL(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu,
+                           y, y_img_stride, stats);
     return DP_LAUNCH_CHECK();
 }
 
@@ -186,6 +279,86 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
     }
 }
 
+__global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const float* __restrict__ dz, long long dz_img_stride, int C,
+                                                          int HW, int G, int silu, float* __restrict__ dx,
+                                                          long long dx_img_stride, const float* __restrict__ add1,
+                                                          long long add1_s, const float* __restrict__ add2, long long add2_s,
+                                                          float* __restrict__ pws) {
+    __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
+    const int n = blockIdx.x / G;
+    const int g = blockIdx.x - n * G;
+    const int cpg = C / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c_base = g * cpg;
+    const int HW4 = HW / 4;
+    const float mean = stats[(long long)blockIdx.x * 2 + 0];
+    const float rstd = stats[(long long)blockIdx.x * 2 + 1];
+    const float* dzb = dz + (long long)n * dz_img_stride;
+    auto dyv = [&](float4 xv, float4 dv, float ga, float be, float4& xh) {
+        xh.x = (xv.x - mean) * rstd; xh.y = (xv.y - mean) * rstd; xh.z = (xv.z - mean) * rstd; xh.w = (xv.w - mean) * rstd;
+        if (silu) {
+            dv.x *= dp_silu_grad(xh.x * ga + be); dv.y *= dp_silu_grad(xh.y * ga + be);
+            dv.z *= dp_silu_grad(xh.z * ga + be); dv.w *= dp_silu_grad(xh.w * ga + be);
+        }
+        return dv;
+    };
+    for (int cl = wave; cl < cpg; cl += 4) {
+        const int c = c_base + cl;
+        const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
+        const float4* dp = reinterpret_cast<const float4*>(dzb + (long long)c * HW);
+        const float ga = gamma[c], be = beta[c];
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = lane; i < HW4; i += 64) {
+            float4 xh;
+            const float4 d = dyv(xp[i], dp[i], ga, be, xh);
+            a1 += (d.x + d.y) + (d.z + d.w);
+            a2 += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+        }
+        a1 = dp_wave_sum(a1);
+        a2 = dp_wave_sum(a2);
+        if (lane == 0) {
+            s1[cl] = a1;
+            s2[cl] = a2;
+            pws[((long long)n * C + c) * 2 + 0] = a1;
+            pws[((long long)n * C + c) * 2 + 1] = a2;
+        }
+    }
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga = gamma[c_base + cl];
+        a += ga * s1[cl];
+        b += ga * s2[cl];
+    }
+    const float invM = 1.0f / (float)(cpg * HW);
+    a *= invM;
+    b *= invM;
+    const int cnt4 = cpg * HW4;
+    float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
+    const float4* dzc = reinterpret_cast<const float4*>(dzb + (long long)c_base * HW);
+    const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
+    const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
+    for (int e = tid; e < cnt4; e += 256) {
+        const int cl = e / HW4;
+        const int c = c_base + cl;
+        const float ga = gamma[c];
+        float4 xh;
+        const float4 d = dyv(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4], dzc[e], ga, beta[c], xh);
+        float4 v;
+        v.x = rstd * (ga * d.x - a - xh.x * b);
+        v.y = rstd * (ga * d.y - a - xh.y * b);
+        v.z = rstd * (ga * d.z - a - xh.z * b);
+        v.w = rstd * (ga * d.w - a - xh.w * b);
+        if (a1b) { const float4 t = a1b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (a2b) { const float4 t = a2b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        dxb[e] = v;
+    }
+}
+
 extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                      long long x2_img_stride, const float* gamma, const float* beta, const float* stats,
                                      const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
@@ -194,8 +367,17 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     if (N <= 0 || C <= 0) return 0;
     if (C % G || C / G > GN_MAXCPG) return (int)hipErrorInvalidValue;
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
-                       dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, pws);
+    const bool vec4 = (HW % 4 == 0) && ((x1_img_stride | x2_img_stride | dz_img_stride | dx_img_stride | add1_img_stride |
+                                         add2_img_stride) % 4 == 0) &&
+                      (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)add1 | (uintptr_t)add2) % 16 == 0);
+    if (vec4)
+        hipLaunchKernelGGL(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                           dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
+                           pws);
+    else
+        hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                           dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
+                           pws);
     return DP_LAUNCH_CHECK();
 }
 

@@ -150,14 +150,21 @@ class UNetGraph:
 
 # ---------------------------------------------------------------------------------------------------
 class ChannelView:
-    """Current channel counts, read off the live parameter shapes ({name: shape})."""
+    """Current channel counts: either a {param name: shape} dict or a callable layer name -> out channels
+    (read lazily off the live modules, so nothing is rebuilt while the caller prunes between groups)."""
 
     def __init__(self, shapes):
-        self.shapes = shapes
+        if callable(shapes):
+            self._out = shapes
+        else:
+            self._out = lambda name: shapes[name + '.weight'][0]
+
+    def layer_out(self, name):
+        return self._out(name)
 
     def out_channels(self, node):
         if node.kind in ('conv', 'linear', 'gn'):
-            return self.shapes[node.name + '.weight'][0]
+            return self._out(node.name)
         if node.kind == 'cat':
             return sum(self.out_channels(i) for i in node.inputs)
         for i in node.inputs:           # element-wise: same as (any) input
@@ -253,7 +260,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
         if node.name in ignored or node.name in visited:
             continue
         chan = chan_fn()
-        n_out = chan.shapes[node.name + '.weight'][0]
+        n_out = chan.layer_out(node.name)
         members = coupled_members(graph, chan, node.name, list(range(n_out)))
         prunable = True
         for m in members:

@@ -307,7 +307,8 @@ class DependencyGraph:
         self.module2name = {m: n for n, m in self.name2module.items()}
 
     def _chan(self):
-        return ChannelView({n: tuple(p.shape) for n, p in self.model.named_parameters()})
+        n2m = self.name2module
+        return ChannelView(lambda name: n2m[name].weight.shape[0])
 
     def _group(self, members):
         return Group([(Dependency(self.name2module[m.name], m.name, m.kind), list(m.idxs)) for m in members])
