@@ -76,6 +76,11 @@ SIGNATURES = {
     'dp_clip_coef': [_vp, _i, _f, _vp, _vp, _vp],
     'dp_adam_ema': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
     'dp_ddim_step': [_vp, _vp, _vp, _f, _f, _f, _i, _vp, _ll, _vp],
+    'dp_layernorm_fwd': [_vp, _ll, _vp, _vp, _i, _i, _i, _f, _vp, _ll, _vp, _vp],
+    'dp_layernorm_bwd': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _vp],
+    'dp_geglu_fwd': [_vp, _i, _ll, _vp, _vp],
+    'dp_geglu_bwd': [_vp, _vp, _i, _ll, _vp, _vp],
+    'dp_add_rowvec': [_vp, _ll, _vp, _i, _i, _i, _vp, _ll, _vp],
     'dp_version': [],
 }
 

@@ -19,6 +19,12 @@ _SPEC3 = ops.ConvSpec(3, 1, 1, 0)
 _SPEC1 = ops.ConvSpec(1, 1, 0, 0)
 _SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
 
+# parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
+RES_DIFFUSERS = dict(norm1='.norm1', conv1='.conv1', temb='.time_emb_proj', norm2='.norm2', conv2='.conv2',
+                     shortcut='.conv_shortcut')
+RES_LDM = dict(norm1='.in_layers.0', conv1='.in_layers.2', temb='.emb_layers.1', norm2='.out_layers.0',
+               conv2='.out_layers.3', shortcut='.skip_connection')
+
 
 class _Packs:
     """Cache of packed (m-contiguous) weight operands, keyed by the identity + version of the source tensor."""
@@ -89,53 +95,54 @@ class UNetEngine:
         ops.colsum_accum(pws, N, C, 2, 0, self.G[name + '.bias'], True)
 
     # ---- ResnetBlock2D (resnet.py:589-639) -----------------------------------------------------
-    def resnet_fwd(self, pre, xa, xb, semb, out_scale, save):
+    def resnet_fwd(self, pre, xa, xb, semb, out_scale, save, names=RES_DIFFUSERS, G=None, eps=None):
         P, cfg = self.P, self.cfg
-        G, eps = cfg['norm_num_groups'], cfg['norm_eps']
-        n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + '.norm1.weight'], P[pre + '.norm1.bias'], G, eps, True)
-        tproj = self._linear(pre + '.time_emb_proj', semb)
-        h = self._conv(pre + '.conv1', n1, None, _SPEC3, tadd=tproj)
-        n2, st2 = ops.groupnorm_fwd(h, None, P[pre + '.norm2.weight'], P[pre + '.norm2.bias'], G, eps, True)
-        has_sc = (pre + '.conv_shortcut.weight') in P
+        G = cfg['norm_num_groups'] if G is None else G
+        eps = cfg['norm_eps'] if eps is None else eps
+        nm = names
+        n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], G, eps, True)
+        tproj = self._linear(pre + nm['temb'], semb)
+        h = self._conv(pre + nm['conv1'], n1, None, _SPEC3, tadd=tproj)
+        n2, st2 = ops.groupnorm_fwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], G, eps, True)
+        has_sc = (pre + nm['shortcut'] + '.weight') in P
         if has_sc:
-            res = self._conv(pre + '.conv_shortcut', xa, xb, _SPEC1)
+            res = self._conv(pre + nm['shortcut'], xa, xb, _SPEC1)
         else:
             if xb is not None:       # identity shortcut over a concat: materialise it (not reached by UNet2DModel configs)
                 res = torch.cat([xa, xb], 1)
             else:
                 res = xa
-        out = self._conv(pre + '.conv2', n2, None, _SPEC3, res=res, post_scale=1.0 / out_scale)
+        out = self._conv(pre + nm['conv2'], n2, None, _SPEC3, res=res, post_scale=1.0 / out_scale)
         if save is not None:
-            save[pre] = (xa, xb, st1, n1, h, st2, n2, has_sc, out_scale)
+            save[pre] = (xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G)
         return out
 
     def resnet_bwd(self, pre, dout, semb, d_semb, extra=None):
         """Returns d(input) over the (virtually concatenated) input channels."""
-        xa, xb, st1, n1, h, st2, n2, has_sc, out_scale = self.ctx.pop(pre)
-        P, cfg = self.P, self.cfg
-        G = cfg['norm_num_groups']
+        xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G = self.ctx.pop(pre)
+        P = self.P
         hw = tuple(h.shape[2:])
         d = dout
         if out_scale != 1.0:
             d = ops.axpby(dout.contiguous(), 1.0 / out_scale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
         rows_d = ops.rowsum_nc(d)
-        dn2 = self._conv_bwd(pre + '.conv2', d, n2, None, _SPEC3, hw, rows=rows_d)
-        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + '.norm2.weight'], P[pre + '.norm2.bias'], st2, dn2, G, True)
-        self._gn_param_grads(pre + '.norm2', pws2)
+        dn2 = self._conv_bwd(pre + nm['conv2'], d, n2, None, _SPEC3, hw, rows=rows_d)
+        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], st2, dn2, G, True)
+        self._gn_param_grads(pre + nm['norm2'], pws2)
         del dn2
         # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
         rows_h = ops.rowsum_nc(dh)
-        self._conv_bwd(pre + '.time_emb_proj', ops.as4d(rows_h), ops.as4d(semb), None, _SPEC1, (1, 1), rows=rows_h,
+        self._conv_bwd(pre + nm['temb'], ops.as4d(rows_h), ops.as4d(semb), None, _SPEC1, (1, 1), rows=rows_h,
                        dx_out=ops.as4d(d_semb), dx_accumulate=True)
-        dn1 = self._conv_bwd(pre + '.conv1', dh, n1, None, _SPEC3, hw, rows=rows_h)
+        dn1 = self._conv_bwd(pre + nm['conv1'], dh, n1, None, _SPEC3, hw, rows=rows_h)
         del dh
         if has_sc:
-            add1 = self._conv_bwd(pre + '.conv_shortcut', d, xa, xb, _SPEC1, hw, rows=rows_d)
+            add1 = self._conv_bwd(pre + nm['shortcut'], d, xa, xb, _SPEC1, hw, rows=rows_d)
         else:
             add1 = d
-        dx, pws1 = ops.groupnorm_bwd(xa, xb, P[pre + '.norm1.weight'], P[pre + '.norm1.bias'], st1, dn1, G, True,
-                                     add1=add1, add2=extra)
-        self._gn_param_grads(pre + '.norm1', pws1)
+        dx, pws1 = ops.groupnorm_bwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], st1, dn1, G,
+                                     True, add1=add1, add2=extra)
+        self._gn_param_grads(pre + nm['norm1'], pws1)
         return dx
 
     # ---- Attention (attention_processor.py:415-470, heads == 1) ---------------------------------

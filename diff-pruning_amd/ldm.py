@@ -1,0 +1,372 @@
+"""LDM (CompVis latent-diffusion) UNet on the HIP engine: the model of the reference's LDM importance pass
+(ldm_exp/prune_ldm.py:86-132, config ldm_exp/configs/latent-diffusion/cin256-v2.yaml).
+
+`UNetModel` mirrors ldm_exp/ldm/modules/diffusionmodules/openaimodel.py:413-742 for the configuration family the
+reference prunes (use_spatial_transformer=True, num_heads=1, transformer_depth=1, no class labels): same constructor
+arguments, same `forward(x, timesteps, context)` and the same state-dict keys, with every weight held by a real
+nn.Conv2d / nn.Linear / nn.GroupNorm / nn.LayerNorm (parameter holders; all arithmetic is in the HIP kernels).
+
+Engine notes.  Tokens stay channel-major ([N][C][T]), so proj_in / q,k,v / FF projections are the same implicit-GEMM
+kernel as the 1x1 convolutions and LayerNorm reduces over the strided channel axis with one thread per token.
+Cross-attention (`attn2`) over the ONE class-embedding token (attention.py:168-193 with context [B,1,512]): the softmax
+over a single key is identically 1, so its output is to_out(to_v(context)) broadcast over the tokens; norm2, to_q and
+to_k receive exactly-zero gradients (as under autograd in the reference) and are not evaluated.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import UNetEngine, RES_LDM, _SPEC1, _SPEC3, _SPEC_UP
+
+_SPEC_DOWN = ops.ConvSpec(3, 2, 1, 0)
+
+
+def ldm_blocks(cfg):
+    """Block structure of UNetModel(**cfg) (openaimodel.py:517-692)."""
+    mc, mult, nres = cfg['model_channels'], list(cfg['channel_mult']), cfg['num_res_blocks']
+    att = set(cfg['attention_resolutions'])
+    inp = [[('conv_in', cfg['in_channels'], mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            items = [('res', ch, m * mc)]
+            ch = m * mc
+            if ds in att:
+                items.append(('st', ch))
+            inp.append(items)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inp.append([('down', ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = ch
+    out = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            ich = chans.pop()
+            items = [('res', ch + ich, mc * m)]
+            ch = mc * m
+            if ds in att:
+                items.append(('st', ch))
+            if level and i == nres:
+                items.append(('up', ch))
+                ds //= 2
+            out.append(items)
+    return inp, out, mid
+
+
+# ---- parameter-holder modules (names as in the CompVis code base) -----------------------------------------------
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim))
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim, heads, dim_head):
+        super().__init__()
+        inner = heads * dim_head
+        self.scale, self.heads = dim_head ** -0.5, heads
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, context_dim):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, dim, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, context_dim):
+        super().__init__()
+        inner = n_heads * d_head
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, channels, emb_channels, out_channels):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, out_channels))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, out_channels), nn.SiLU(), nn.Dropout(0.0),
+                                        nn.Conv2d(out_channels, out_channels, 3, padding=1))
+        self.skip_connection = nn.Identity() if channels == out_channels else nn.Conv2d(channels, out_channels, 1)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = self.out_channels = channels
+        self.op = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = self.out_channels = channels
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), num_heads=1, use_spatial_transformer=True, transformer_depth=1,
+                 context_dim=None):
+        super().__init__()
+        if not use_spatial_transformer or num_heads != 1 or transformer_depth != 1 or context_dim is None or dropout:
+            raise NotImplementedError('only the cin256-v2 configuration family of the LDM importance pass is implemented')
+        self.config = dict(image_size=image_size, in_channels=in_channels, model_channels=model_channels,
+                           out_channels=out_channels, num_res_blocks=num_res_blocks,
+                           attention_resolutions=list(attention_resolutions), channel_mult=list(channel_mult),
+                           num_heads=num_heads, use_spatial_transformer=True, transformer_depth=1, context_dim=context_dim)
+        tdim = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, tdim), nn.SiLU(), nn.Linear(tdim, tdim))
+        inp, out, mid = ldm_blocks(self.config)
+
+        def make(it):
+            if it[0] == 'conv_in':
+                return nn.Conv2d(it[1], it[2], 3, padding=1)
+            if it[0] == 'res':
+                return ResBlock(it[1], tdim, it[2])
+            if it[0] == 'st':
+                return SpatialTransformer(it[1], 1, it[1], context_dim)
+            if it[0] == 'down':
+                return Downsample(it[1])
+            return Upsample(it[1])
+
+        self.input_blocks = nn.ModuleList([nn.Sequential(*[make(it) for it in items]) for items in inp])
+        self.middle_block = nn.Sequential(ResBlock(mid, tdim, mid), SpatialTransformer(mid, 1, mid, context_dim),
+                                          ResBlock(mid, tdim, mid))
+        self.output_blocks = nn.ModuleList([nn.Sequential(*[make(it) for it in items]) for items in out])
+        self.out = nn.Sequential(nn.GroupNorm(32, model_channels), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self._engine = None
+
+    @property
+    def device(self):
+        return self.out[2].weight.device
+
+    def engine(self):
+        if self.device.type != 'cuda':
+            raise RuntimeError('UNetModel runs on the MI355X HIP kernels only (no CPU / PyTorch fallback)')
+        if self._engine is None:
+            self._engine = LdmEngine(self.config)
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        return self._engine
+
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        if y is not None:
+            raise ValueError('class-label conditioning (num_classes) is not part of this configuration')
+        return self.engine().forward(x.to(torch.float32), timesteps, context, save=False)
+
+
+class LdmEngine(UNetEngine):
+    """Forward + hand-written backward of the LDM UNet (openaimodel.py:710-742) on the HIP kernels."""
+
+    def res_fwd(self, pre, xa, xb, semb, save):
+        return self.resnet_fwd(pre, xa, xb, semb, 1.0, save, names=RES_LDM, G=32, eps=1e-5)
+
+    # ---- SpatialTransformer (attention.py:215-258) ------------------------------------------------------------
+    def st_fwd(self, pre, x, ctx2d, dim_head, save):
+        P = self.P
+        N, C, H, W = x.shape
+        T = H * W
+        tb = pre + '.transformer_blocks.0'
+        scale = float(dim_head) ** -0.5
+        n0, st0 = ops.groupnorm_fwd(x, None, P[pre + '.norm.weight'], P[pre + '.norm.bias'], 32, 1e-6, False)
+        h = self._conv(pre + '.proj_in', n0, None, _SPEC1)
+        inner = h.shape[1]
+        # attn1: self-attention
+        l1, ls1 = ops.layernorm_fwd(h, P[tb + '.norm1.weight'], P[tb + '.norm1.bias'])
+        q = self._conv(tb + '.attn1.to_q', l1, None, _SPEC1)
+        k = self._conv(tb + '.attn1.to_k', l1, None, _SPEC1)
+        v = self._conv(tb + '.attn1.to_v', l1, None, _SPEC1)
+        ai = q.shape[1]
+        s = ops.bmm_tn(q.view(N, ai, T), k.view(N, ai, T), alpha=scale)
+        p = ops.softmax_fwd(s, out=s)
+        o = ops.bmm_nt(v.view(N, ai, T), p)
+        h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, ai, H, W), None, _SPEC1, res=h)
+        # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
+        v2 = self._linear(tb + '.attn2.to_v', ctx2d)
+        o2 = self._linear(tb + '.attn2.to_out.0', v2)
+        h2 = ops.add_rowvec(h1, o2.contiguous())
+        # feed-forward (GEGLU)
+        l3, ls3 = ops.layernorm_fwd(h2, P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
+        pr = self._conv(tb + '.ff.net.0.proj', l3, None, _SPEC1)
+        gg = ops.geglu_fwd(pr)
+        h3 = self._conv(tb + '.ff.net.2', gg, None, _SPEC1, res=h2)
+        out = self._conv(pre + '.proj_out', h3, None, _SPEC1, res=x)
+        if save is not None:
+            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale)
+        return out
+
+    def _ln_param_grads(self, name, pws):
+        N, C = pws.shape[0], pws.shape[1]
+        ops.colsum_accum(pws, N, C, 2, 1, self.G[name + '.weight'], True)
+        ops.colsum_accum(pws, N, C, 2, 0, self.G[name + '.bias'], True)
+
+    def st_bwd(self, pre, dout, extra=None):
+        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale) = self.ctx.pop(pre)
+        P = self.P
+        N, C, H, W = x.shape
+        T = H * W
+        hw = (H, W)
+        tb = pre + '.transformer_blocks.0'
+        inner, ai = h.shape[1], q.shape[1]
+        dh3 = self._conv_bwd(pre + '.proj_out', dout, h3, None, _SPEC1, hw)
+        # feed-forward
+        dgg = self._conv_bwd(tb + '.ff.net.2', dh3, gg, None, _SPEC1, hw)
+        dpr = ops.geglu_bwd(pr, dgg)
+        dl3 = self._conv_bwd(tb + '.ff.net.0.proj', dpr, l3, None, _SPEC1, hw)
+        dh2, pws = ops.layernorm_bwd(h2, P[tb + '.norm3.weight'], ls3, dl3, add=dh3)
+        self._ln_param_grads(tb + '.norm3', pws)
+        # attn2 (context token): d o2[n, c] = sum_t dh2
+        rows = ops.rowsum_nc(dh2)
+        dv2 = self._conv_bwd(tb + '.attn2.to_out.0', ops.as4d(rows), ops.as4d(v2), None, _SPEC1, (1, 1), rows=rows)
+        self._conv_bwd(tb + '.attn2.to_v', dv2, ops.as4d(ctx2d), None, _SPEC1, None, need_dx=False)
+        # attn1
+        do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, ai, H, W), None, _SPEC1, hw)
+        do3 = do.view(N, ai, T)
+        dv = ops.bmm_nn(do3, p)
+        dp = ops.bmm_tn(do3, v.view(N, ai, T))
+        ds = ops.softmax_bwd(p, dp, scale, out=dp)
+        dq = ops.bmm_nt(k.view(N, ai, T), ds)
+        dk = ops.bmm_nn(q.view(N, ai, T), ds)
+        dl1 = torch.empty_like(l1)
+        first = True
+        for dproj, name in ((dq, '.attn1.to_q'), (dk, '.attn1.to_k'), (dv, '.attn1.to_v')):
+            self._conv_bwd(tb + name, dproj.view(N, ai, H, W), l1, None, _SPEC1, hw, dx_out=dl1, dx_accumulate=not first)
+            first = False
+        dh, pws = ops.layernorm_bwd(h, P[tb + '.norm1.weight'], ls1, dl1, add=dh2)
+        self._ln_param_grads(tb + '.norm1', pws)
+        dn0 = self._conv_bwd(pre + '.proj_in', dh, n0, None, _SPEC1, hw)
+        dx, pws = ops.groupnorm_bwd(x, None, P[pre + '.norm.weight'], P[pre + '.norm.bias'], st0, dn0, 32, False,
+                                    add1=dout, add2=extra)
+        self._gn_param_grads(pre + '.norm', pws)
+        return dx
+
+    # ---- whole network ----------------------------------------------------------------------------------------
+    def forward(self, x, timesteps, context, save=False):
+        P, cfg = self.P, self.cfg
+        if context is None or context.dim() != 3 or context.shape[1] != 1:
+            raise NotImplementedError('context must be [B, 1, context_dim] (the class-embedding token of cin256-v2)')
+        ctx2d = context.reshape(context.shape[0], context.shape[2]).contiguous().float()
+        inp, out, mid = ldm_blocks(cfg)
+        ctx = {} if save else None
+        x = x.contiguous()
+        t_emb = ops.timestep_embedding(timesteps.to(torch.float32), cfg['model_channels'], True, 0.0)
+        h1 = self._linear('time_embed.0', t_emb)
+        a1 = ops.silu_fwd(h1)
+        emb = self._linear('time_embed.2', a1)
+        semb = ops.silu_fwd(emb)
+        hs = []
+        h = x
+        for bi, items in enumerate(inp):
+            for li, it in enumerate(items):
+                pre = 'input_blocks.%d.%d' % (bi, li)
+                if it[0] == 'conv_in':
+                    h = self._conv(pre, h, None, _SPEC3)
+                elif it[0] == 'res':
+                    h = self.res_fwd(pre, h, None, semb, ctx)
+                elif it[0] == 'st':
+                    h = self.st_fwd(pre, h, ctx2d, it[1], ctx)
+                else:
+                    hin = h
+                    h = self._conv(pre + '.op', hin, None, _SPEC_DOWN)
+                    if ctx is not None:
+                        ctx[pre] = hin
+            hs.append(h)
+        h = self.res_fwd('middle_block.0', h, None, semb, ctx)
+        h = self.st_fwd('middle_block.1', h, ctx2d, mid, ctx)
+        h = self.res_fwd('middle_block.2', h, None, semb, ctx)
+        for bi, items in enumerate(out):
+            skip = hs.pop()
+            for li, it in enumerate(items):
+                pre = 'output_blocks.%d.%d' % (bi, li)
+                if it[0] == 'res':
+                    h = self.res_fwd(pre, h, skip, semb, ctx)
+                elif it[0] == 'st':
+                    h = self.st_fwd(pre, h, ctx2d, it[1], ctx)
+                else:
+                    hin = h
+                    h = self._conv(pre + '.conv', hin, None, _SPEC_UP)
+                    if ctx is not None:
+                        ctx[pre] = hin
+        ho = h
+        no, sto = ops.groupnorm_fwd(ho, None, P['out.0.weight'], P['out.0.bias'], 32, 1e-5, True)
+        y = self._conv('out.2', no, None, _SPEC3)
+        if ctx is not None:
+            ctx['_head'] = (x, t_emb, h1, a1, emb, semb, ho, no, sto)
+            self.ctx = ctx
+        return y
+
+    def backward(self, dout):
+        P, cfg, ctx = self.P, self.cfg, self.ctx
+        assert ctx is not None
+        inp, out, mid = ldm_blocks(cfg)
+        x, t_emb, h1, a1, emb, semb, ho, no, sto = ctx.pop('_head')
+        d_semb = torch.zeros_like(semb)
+        dno = self._conv_bwd('out.2', dout, no, None, _SPEC3, tuple(ho.shape[2:]))
+        dx, pws = ops.groupnorm_bwd(ho, None, P['out.0.weight'], P['out.0.bias'], sto, dno, 32, True)
+        self._gn_param_grads('out.0', pws)
+        n_in = len(inp)
+        sg = {}                                   # index into hs -> gradient view from the output path
+        for bi in reversed(range(len(out))):
+            items = out[bi]
+            for li in reversed(range(len(items))):
+                it = items[li]
+                pre = 'output_blocks.%d.%d' % (bi, li)
+                if it[0] == 'up':
+                    hin = ctx.pop(pre)
+                    dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC_UP, (2 * hin.shape[2], 2 * hin.shape[3]))
+                    dx = ops.downsum2x2(dxv)
+                elif it[0] == 'st':
+                    dx = self.st_bwd(pre, dx)
+                else:
+                    c1 = self.ctx[pre][0].shape[1]
+                    dcat = self.resnet_bwd(pre, dx, semb, d_semb)
+                    dx = dcat[:, :c1]
+                    sg[n_in - 1 - bi] = dcat[:, c1:]          # output block bi popped hs[n_in-1-bi]
+        dx = self.resnet_bwd('middle_block.2', dx, semb, d_semb)
+        dx = self.st_bwd('middle_block.1', dx)
+        dx = self.resnet_bwd('middle_block.0', dx, semb, d_semb, extra=sg.pop(n_in - 1))
+        for bi in reversed(range(n_in)):
+            items = inp[bi]
+            for li in reversed(range(len(items))):
+                it = items[li]
+                pre = 'input_blocks.%d.%d' % (bi, li)
+                extra = sg.pop(bi - 1) if (li == 0 and bi > 0) else None      # this item consumed hs[bi-1]
+                if it[0] == 'st':
+                    dx = self.st_bwd(pre, dx, extra=extra)
+                elif it[0] == 'res':
+                    dx = self.resnet_bwd(pre, dx, semb, d_semb, extra=extra)
+                elif it[0] == 'down':
+                    hin = ctx.pop(pre)
+                    dxd = self._conv_bwd(pre + '.op', dx, hin, None, _SPEC_DOWN, tuple(hin.shape[2:]))
+                    ops.copy_strided(extra, dxd, accumulate=True)
+                    dx = dxd
+                else:
+                    self._conv_bwd(pre, dx, x, None, _SPEC3, None, need_dx=False)
+        assert not sg
+        d_emb = ops.silu_bwd(emb, d_semb)
+        d_a1 = self._conv_bwd('time_embed.2', ops.as4d(d_emb), ops.as4d(a1), None, _SPEC1, (1, 1), rows=d_emb)
+        d_h1 = ops.silu_bwd(h1, d_a1.view(d_a1.shape[0], d_a1.shape[1]))
+        self._conv_bwd('time_embed.0', ops.as4d(d_h1), ops.as4d(t_emb), None, _SPEC1, None, need_dx=False, rows=d_h1)
+        assert not ctx, 'unconsumed context: %s' % list(ctx)
+        self.ctx = None

@@ -527,3 +527,57 @@ def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None):
     L.check(_lib().dp_ddim_step(_p(x), _p(eps), _p(vnoise), float(a_t), float(a_prev), float(std), 1 if clip else 0,
                                 _p(out), x.numel(), _stream()), 'dp_ddim_step')
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# LDM transformer-block glue (channel-major tokens [N, C, H, W] == [N][C][T])
+# --------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
+    s = _chk_act(x)
+    N, Cc, H, W = x.shape
+    T = H * W
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
+    stats = torch.empty((N, T, 2), dtype=_f32, device=x.device)
+    L.check(_lib().dp_layernorm_fwd(_p(x), s, _p(gamma), _p(beta), N, Cc, T, eps, _p(out), _chk_act(out), _p(stats),
+                                    _stream()), 'dp_layernorm_fwd')
+    return out, stats
+
+
+def layernorm_bwd(x, gamma, stats, dy, add=None, out=None):
+    """Returns (dx, pws [N, C, 2]); dgamma = sum_n pws[..., 1], dbeta = sum_n pws[..., 0]."""
+    s = _chk_act(x)
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
+    pws = torch.empty((N, Cc, 2), dtype=_f32, device=x.device)
+    L.check(_lib().dp_layernorm_bwd(_p(x), s, _p(gamma), _p(stats), _p(dy), _chk_act(dy), N, Cc, H * W, _p(out),
+                                    _chk_act(out), _p(add), (_chk_act(add) if add is not None else 0), _p(pws), _stream()),
+            'dp_layernorm_bwd')
+    return out, pws
+
+
+def geglu_fwd(x):
+    assert x.is_contiguous()
+    N, C2, H, W = x.shape
+    out = torch.empty((N, C2 // 2, H, W), dtype=_f32, device=x.device)
+    L.check(_lib().dp_geglu_fwd(_p(x), N, (C2 // 2) * H * W, _p(out), _stream()), 'dp_geglu_fwd')
+    return out
+
+
+def geglu_bwd(x, dout):
+    assert x.is_contiguous() and dout.is_contiguous()
+    N, C2, H, W = x.shape
+    din = torch.empty_like(x)
+    L.check(_lib().dp_geglu_bwd(_p(x), _p(dout), N, (C2 // 2) * H * W, _p(din), _stream()), 'dp_geglu_bwd')
+    return din
+
+
+def add_rowvec(x, v, out=None):
+    s = _chk_act(x)
+    N, Cc, H, W = x.shape
+    assert v.shape == (N, Cc) and v.is_contiguous()
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
+    L.check(_lib().dp_add_rowvec(_p(x), s, _p(v), N, Cc, H * W, _p(out), _chk_act(out), _stream()), 'dp_add_rowvec')
+    return out

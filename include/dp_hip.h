@@ -154,6 +154,21 @@ int dp_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long l
 int dp_ddim_step(const float* x, const float* eps, const float* vnoise, float a_t, float a_prev, float std, int clip,
                  float* out, long long n, void* stream);
 
+/* ---- LDM (CompVis) transformer-block glue on channel-major tokens x[n][c][t]  (ldm_exp/ldm/modules/attention.py) ---- */
+/* LayerNorm over the C channels of every token (attention.py:200-212 norm1/2/3); stats[(n*T+t)*2+{0,1}] = {mean, rstd}. */
+int dp_layernorm_fwd(const float* x, long long x_img_stride, const float* gamma, const float* beta, int N, int C, int T,
+                     float eps, float* y, long long y_img_stride, float* stats, void* stream);
+/* dx = layernorm_backward(dy) (+ add);  pws[(n*C+c)*2+{0,1}] = {sum_t dy, sum_t dy*xhat} (reduce over n: dp_colsum_accum). */
+int dp_layernorm_bwd(const float* x, long long x_img_stride, const float* gamma, const float* stats, const float* dy,
+                     long long dy_img_stride, int N, int C, int T, float* dx, long long dx_img_stride, const float* add,
+                     long long add_img_stride, float* pws, void* stream);
+/* GEGLU (attention.py:37-46): in [N][2D][T] -> out [N][D][T] = in[:, :D] * gelu(in[:, D:]); half_plane = D*T. */
+int dp_geglu_fwd(const float* in, int N, long long half_plane, float* out, void* stream);
+int dp_geglu_bwd(const float* in, const float* dout, int N, long long half_plane, float* din, void* stream);
+/* out[n][c][t] = x[n][c][t] + v[n*C + c]  (cross-attention over a single context token, attention.py:168-193) */
+int dp_add_rowvec(const float* x, long long x_img_stride, const float* v, int N, int C, int T, float* out,
+                  long long o_img_stride, void* stream);
+
 /* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
 int dp_version(void);
 

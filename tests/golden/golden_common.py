@@ -29,6 +29,14 @@ BEDROOM_CFG = dict(
     block_out_channels=[128, 128, 256, 256, 512, 512])
 
 
+# ldm_exp/configs/latent-diffusion/cin256-v2.yaml unet_config: 400.9 M parameters
+LDM_CIN256_CFG = dict(image_size=64, in_channels=3, out_channels=3, model_channels=192, attention_resolutions=[8, 4, 2],
+                      num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_heads=1, use_spatial_transformer=True,
+                      transformer_depth=1, context_dim=512)
+# same topology at reduced width / resolution for full-tensor fixtures
+LDM_TINY_CFG = dict(LDM_CIN256_CFG, image_size=16, model_channels=32, context_dim=16)
+
+
 def _rng(name, seed):
     return np.random.default_rng([zlib.crc32(name.encode()), seed])
 

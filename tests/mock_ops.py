@@ -256,3 +256,43 @@ def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None):
     if vnoise is not None:
         v = v + std * vnoise
     return v
+
+
+# ---- LDM transformer glue ------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None):
+    N, C, H, W = x.shape
+    xt = x.reshape(N, C, H * W)
+    mean = xt.mean(1)
+    rstd = 1.0 / torch.sqrt(xt.var(1, unbiased=False) + eps)
+    y = ((xt - mean[:, None]) * rstd[:, None]) * gamma[None, :, None] + beta[None, :, None]
+    return y.reshape(N, C, H, W).contiguous(), torch.stack([mean, rstd], -1).contiguous()
+
+
+def layernorm_bwd(x, gamma, stats, dy, add=None, out=None):
+    N, C, H, W = x.shape
+    xt, dt = x.reshape(N, C, H * W), dy.reshape(N, C, H * W)
+    mean, rstd = stats[..., 0][:, None], stats[..., 1][:, None]
+    xh = (xt - mean) * rstd
+    gd = gamma[None, :, None] * dt
+    a = gd.mean(1, keepdim=True)
+    b = (gd * xh).mean(1, keepdim=True)
+    dx = (rstd * (gd - a - xh * b)).reshape(N, C, H, W)
+    if add is not None:
+        dx = dx + add
+    pws = torch.stack([dt.sum(2), (dt * xh).sum(2)], -1)
+    return dx.contiguous(), pws.contiguous()
+
+
+def geglu_fwd(x):
+    a, g = x.chunk(2, dim=1)
+    return (a * F.gelu(g)).contiguous()
+
+
+def geglu_bwd(x, dout):
+    a, g = x.chunk(2, dim=1)
+    gg = 0.5 * (1 + torch.erf(g / math.sqrt(2))) + g * torch.exp(-0.5 * g * g) / math.sqrt(2 * math.pi)
+    return torch.cat([dout * F.gelu(g), dout * a * gg], 1).contiguous()
+
+
+def add_rowvec(x, v, out=None):
+    return x + v[:, :, None, None]

@@ -341,3 +341,70 @@ def test_prune_flow_on_mocked_kernels_matches_reference_masks(mocked, monkeypatc
     # pruned model still runs forward + backward through the engine
     res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1)
     assert np.isfinite(res['losses'][0])
+
+
+# ------------------------------------------------------------------------------------------------ LDM (row a17)
+def test_ldm_oracle_matches_reference_unet():
+    """oracle/ldm_ref.py vs the reference's own UNetModel (fixtures from make_golden_ldm.py): bit-exact forward, loss and
+    gradients on the reduced-width config; full cin256-v2 parameter table (400 920 579 parameters)."""
+    from oracle import ldm_ref as L
+    cfg = gc.LDM_TINY_CFG
+    fx = load_json('ldm_unet_stats.json')
+    S = L.ldm_param_shapes(cfg)
+    assert {n: list(s) for n, s in S.items()} == fx['shapes']
+    SF = L.ldm_param_shapes(gc.LDM_CIN256_CFG)
+    assert {n: list(s) for n, s in SF.items()} == fx['cin256_shapes']
+    assert sum(int(np.prod(s)) for s in SF.values()) == fx['cin256_params'] == 400920579
+    P = {n: torch.from_numpy(gc.det_param(n, s, 9)).requires_grad_(True) for n, s in S.items()}
+    g = load_npz('ldm_unet.npz')
+    x, ctx, noise, t = _ldm_inputs()
+    y = L.ldm_unet_forward(P, cfg, x, t, ctx)
+    assert float((y.detach() - torch.from_numpy(g['fwd_out'])).abs().max()) < 1e-6
+    loss = (y - noise).square().mean(dim=(1, 2, 3)).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-6
+    for k in g.files:
+        if k.startswith('grad::'):
+            assert relerr(P[k[6:]].grad, g[k]) < 1e-5 or float(np.abs(g[k]).max()) == 0.0, k
+    for n, (s, a) in fx['grad_stats'].items():
+        assert abs(float(P[n].grad.double().abs().sum()) - a) <= 2e-5 * a + 1e-8 * P[n].numel(), n
+
+
+def _ldm_inputs():
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 31))
+    ctx = torch.from_numpy(gc.det_noise((2, 1, 16), 32))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 33))
+    return x, ctx, noise, torch.tensor([7, 640])
+
+
+def test_ldm_engine_backward_graph_matches_oracle(mocked, monkeypatch):
+    """LdmEngine's hand-written backward (SpatialTransformer incl. the single-token cross-attention shortcut, GEGLU,
+    LayerNorm, skip routing) vs autograd of the oracle, kernels replaced by CPU stand-ins."""
+    from oracle import ldm_ref as L
+    ldm = pkg('ldm')
+    monkeypatch.setattr(ldm, 'ops', mocked)
+    cfg = gc.LDM_TINY_CFG
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    state_names = [n for n, _ in model.named_parameters()]
+    assert set(state_names) == set(L.ldm_param_shapes(cfg))
+    eng = ldm.LdmEngine(model.config)
+    grads = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    eng.bind({n: p.detach() for n, p in model.named_parameters()}, grads)
+    x, ctx, noise, t = _ldm_inputs()
+    y = eng.forward(x, t, ctx, save=True)
+    n = y.numel()
+    loss, dout = mocked.mse_fwd_bwd(y, noise, 2.0 / n, 1.0 / n)
+    eng.backward(dout)
+    P = {k: torch.from_numpy(gc.det_param(k, s, 9)).requires_grad_(True) for k, s in L.ldm_param_shapes(cfg).items()}
+    yo = L.ldm_unet_forward(P, cfg, x, t, ctx)
+    lo = (yo - noise).square().mean(dim=(1, 2, 3)).mean()
+    lo.backward()
+    assert float((y - yo.detach()).abs().max()) < 1e-5
+    assert abs(float(loss) - float(lo.detach())) < 1e-6
+    for k in P:
+        ref = P[k].grad
+        if float(ref.abs().max()) > 1e-7:
+            assert relerr(grads[k], ref) < 5e-5, k
+        else:
+            assert float(grads[k].abs().max()) < 1e-6, k        # norm2 / attn2.to_q / attn2.to_k: exactly zero

@@ -316,3 +316,40 @@ def test_mse_wg_adam_ddim(ops, report):
     res['mse_grad'] = e2
     report['scalar_kernels'] = res
     assert max(res.values()) < 1e-5, res
+
+
+@pytest.mark.parametrize('N,C,H', [(2, 96, 8), (3, 384, 16), (2, 50, 3)])
+def test_layernorm_geglu_rowvec(ops, report, N, C, H):
+    x = rnd(N, C, H, H, seed=1) + 0.2
+    gamma = 1 + 0.2 * rnd(C, seed=2)
+    beta = 0.1 * rnd(C, seed=3)
+    y, st = ops.layernorm_fwd(x, gamma, beta)
+    xr = x.double().cpu().requires_grad_(True)
+    gr = gamma.double().cpu().requires_grad_(True)
+    br = beta.double().cpu().requires_grad_(True)
+    yr = F.layer_norm(xr.permute(0, 2, 3, 1), (C,), gr, br, 1e-5).permute(0, 3, 1, 2)
+    e_f = relerr(y, yr.detach())
+    dy = rnd(N, C, H, H, seed=4)
+    add = rnd(N, C, H, H, seed=5)
+    yr.backward(dy.double().cpu())
+    dx, pws = ops.layernorm_bwd(x, gamma, st, dy, add=add)
+    e_dx = relerr(dx, xr.grad + add.double().cpu())
+    dg = torch.zeros(C, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    ops.colsum_accum(pws, N, C, 2, 1, dg, accumulate=False)
+    ops.colsum_accum(pws, N, C, 2, 0, db, accumulate=False)
+    e_g, e_b = relerr(dg, gr.grad), relerr(db, br.grad)
+    # GEGLU
+    z = rnd(N, 2 * C, H, H, seed=6)
+    zr = z.double().cpu().requires_grad_(True)
+    a, g = zr.chunk(2, dim=1)
+    o_ref = a * F.gelu(g)
+    o = ops.geglu_fwd(z)
+    e_gf = relerr(o, o_ref.detach())
+    do = rnd(N, C, H, H, seed=7)
+    o_ref.backward(do.double().cpu())
+    e_gb = relerr(ops.geglu_bwd(z, do), zr.grad)
+    v = rnd(N, C, seed=8)
+    e_rv = relerr(ops.add_rowvec(x, v), x.double().cpu() + v.double().cpu()[:, :, None, None])
+    report['ln/%d_%d_%d' % (N, C, H)] = dict(fwd=e_f, dx=e_dx, dgamma=e_g, dbeta=e_b, geglu=e_gf, geglu_bwd=e_gb, rowvec=e_rv)
+    assert max(e_f, e_dx, e_g, e_b, e_gf, e_gb, e_rv) < 1e-5
