@@ -81,6 +81,8 @@ SIGNATURES = {
     'dp_geglu_fwd': [_vp, _i, _ll, _vp, _vp],
     'dp_geglu_bwd': [_vp, _vp, _i, _ll, _vp, _vp],
     'dp_add_rowvec': [_vp, _ll, _vp, _i, _i, _i, _vp, _ll, _vp],
+    'dp_q_sample': [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
+    'dp_cfg_combine': [_vp, _vp, _f, _vp, _ll, _vp],
     'dp_version': [],
 }
 

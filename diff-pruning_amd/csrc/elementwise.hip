@@ -282,3 +282,37 @@ extern "C" int dp_ddim_step(const float* x, const float* eps, const float* vnois
                        sqrt_b_t, sqrt_a_prev, dir_coef, stdv, clip, out, n);
     return DP_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------
+// LDM glue: q_sample with precomputed sqrt tables (ldm/models/diffusion/ddpm.py q_sample) and the classifier-free
+// guidance combination e = e_u + s (e_c - e_u) (ldm/models/diffusion/ddim.py:178-183)
+// ---------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ sa,
+                                const float* __restrict__ sb, const int64_t* __restrict__ t, int B, long long per_img,
+                                float* __restrict__ out) {
+    const long long total = (long long)B * per_img;
+    GS_LOOP(i, total) {
+        const int b = (int)(i / per_img);
+        out[i] = sa[t[b]] * x0[i] + sb[t[b]] * noise[i];
+    }
+}
+extern "C" int dp_q_sample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1m_acp,
+                           const int64_t* t, int B, long long per_img, float* out, void* stream) {
+    if ((long long)B * per_img <= 0) return 0;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
+                       sqrt_acp, sqrt_1m_acp, t, B, per_img, out);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __restrict__ ec, float s, float* __restrict__ out,
+                                   long long n) {
+    GS_LOOP(i, n) {
+        const float u = eu[i];
+        out[i] = u + s * (ec[i] - u);
+    }
+}
+extern "C" int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, e_uncond, e_cond, scale, out, n);
+    return DP_LAUNCH_CHECK();
+}

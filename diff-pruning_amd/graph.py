@@ -18,7 +18,7 @@ recorded from the reference (tests/golden/groups.json, tiny_prune.json, cifar_c1
 
 
 class GNode:
-    __slots__ = ('kind', 'name', 'inputs', 'outputs', 'uid')
+    __slots__ = ('kind', 'name', 'inputs', 'outputs', 'uid', 'part')
 
     def __init__(self, kind, name, inputs, uid):
         self.kind, self.name, self.uid = kind, name, uid
@@ -32,9 +32,7 @@ class GNode:
         return '%s(%s)' % (self.kind, self.name or self.uid)
 
 
-class UNetGraph:
-    """Symbolic op graph of UNet2DModel.forward for a given config."""
-
+class _GraphBase:
     def __init__(self, cfg):
         self.cfg = cfg
         self._n = 0
@@ -62,6 +60,41 @@ class UNetGraph:
     def linear(self, name, x):
         # AddmmBackward0.next_functions = (bias [AccumulateGrad, skipped], input, TBackward0(weight))
         return self._node('linear', name, [x, self.ew()])
+
+    def ln(self, name, x):
+        return self._node('ln', name, [x])
+
+    def slice(self, x, part, nparts):
+        """One output of torch.chunk / split along channels (SplitBackward0): channels [part*D, (part+1)*D) of x."""
+        n = self._node('slice', None, [x])
+        n.part = (part, nparts)
+        return n
+
+    # ---- dependency.py:761-806 -------------------------------------------------------------------
+    @staticmethod
+    def _trace_order(root):
+        order, seen_nodes = [], set()
+
+        def create(n):
+            if n.uid not in seen_nodes:
+                seen_nodes.add(n.uid)
+                order.append(n)
+
+        stack, visited = [root], set()
+        while stack:
+            f = stack.pop()
+            if f.uid in visited:
+                continue
+            create(f)
+            for inp in f.inputs:
+                create(inp)
+                stack.append(inp)
+            visited.add(f.uid)
+        return order
+
+
+class UNetGraph(_GraphBase):
+    """Symbolic op graph of UNet2DModel.forward for a given config."""
 
     def resnet(self, pre, x, emb, has_shortcut):
         h = self.ew(self.gn(pre + '.norm1', x))                 # silu(norm1(x))
@@ -125,27 +158,76 @@ class UNetGraph:
         x = self.ew(self.gn('conv_norm_out', x))
         return self.conv('conv_out', x)
 
-    # ---- dependency.py:761-806 -------------------------------------------------------------------
-    @staticmethod
-    def _trace_order(root):
-        order, seen_nodes = [], set()
 
-        def create(n):
-            if n.uid not in seen_nodes:
-                seen_nodes.add(n.uid)
-                order.append(n)
+class LdmGraph(_GraphBase):
+    """Symbolic op graph of the CompVis UNetModel.forward (ldm_exp/ldm/modules/diffusionmodules/openaimodel.py:710-742,
+    ResBlock._forward :236-275, attention.py:37-46,168-212,246-258) with autograd's next_functions input order."""
 
-        stack, visited = [root], set()
-        while stack:
-            f = stack.pop()
-            if f.uid in visited:
-                continue
-            create(f)
-            for inp in f.inputs:
-                create(inp)
-                stack.append(inp)
-            visited.add(f.uid)
-        return order
+    def res(self, pre, x, emb, has_skip):
+        h = self.conv(pre + '.in_layers.2', self.ew(self.gn(pre + '.in_layers.0', x)))
+        e = self.linear(pre + '.emb_layers.1', self.ew(emb))
+        e = self.ew(self.ew(e))                                   # emb_out[..., None] twice
+        h = self.ew(h, e)                                         # h + emb_out
+        h = self.conv(pre + '.out_layers.3', self.ew(self.gn(pre + '.out_layers.0', h)))
+        if has_skip:
+            x = self.conv(pre + '.skip_connection', x)
+        return self.ew(x, h)                                      # skip_connection(x) + h
+
+    def cross_attn(self, pre, x, ctx_is_x):
+        q = self.ew(self.ew(self.linear(pre + '.to_q', x)))       # rearrange 'b n (h d) -> (b h) n d'
+        k = self.ew(self.ew(self.linear(pre + '.to_k', x if ctx_is_x else None)))
+        v = self.ew(self.ew(self.linear(pre + '.to_v', x if ctx_is_x else None)))
+        sim = self.ew(self.ew(q, k))                              # einsum (bmm) then * scale
+        attn = self.ew(sim)                                       # softmax
+        out = self.ew(self.ew(self.ew(attn, v)))                  # einsum (bmm), rearrange back
+        return self.linear(pre + '.to_out.0', out)                # Dropout is the identity
+
+    def transformer(self, pre, x):
+        tb = pre + '.transformer_blocks.0'
+        h = self.gn(pre + '.norm', x)
+        h = self.conv(pre + '.proj_in', h)
+        h = self.ew(self.ew(h))                                   # rearrange 'b c h w -> b (h w) c'
+        h = self.ew(self.cross_attn(tb + '.attn1', self.ln(tb + '.norm1', h), True), h)
+        h = self.ew(self.cross_attn(tb + '.attn2', self.ln(tb + '.norm2', h), False), h)
+        p = self.linear(tb + '.ff.net.0.proj', self.ln(tb + '.norm3', h))
+        gl = self.ew(self.slice(p, 0, 2), self.ew(self.slice(p, 1, 2)))      # x * gelu(gate)
+        h = self.ew(self.linear(tb + '.ff.net.2', gl), h)
+        h = self.ew(self.ew(h))                                   # rearrange back
+        return self.ew(self.conv(pre + '.proj_out', h), x)        # x + x_in
+
+    def _build(self):
+        from .ldm import ldm_blocks
+        cfg = self.cfg
+        inp, out, mid = ldm_blocks(cfg)
+        emb = self.linear('time_embed.2', self.ew(self.linear('time_embed.0', None)))
+        hs = []
+        h = None
+        for bi, items in enumerate(inp):
+            for li, it in enumerate(items):
+                pre = 'input_blocks.%d.%d' % (bi, li)
+                if it[0] == 'conv_in':
+                    h = self.conv(pre, None)
+                elif it[0] == 'res':
+                    h = self.res(pre, h, emb, it[1] != it[2])
+                elif it[0] == 'st':
+                    h = self.transformer(pre, h)
+                else:
+                    h = self.conv(pre + '.op', h)
+            hs.append(h)
+        h = self.res('middle_block.0', h, emb, False)
+        h = self.transformer('middle_block.1', h)
+        h = self.res('middle_block.2', h, emb, False)
+        for bi, items in enumerate(out):
+            h = self._node('cat', None, [h, hs.pop()])
+            for li, it in enumerate(items):
+                pre = 'output_blocks.%d.%d' % (bi, li)
+                if it[0] == 'res':
+                    h = self.res(pre, h, emb, True)
+                elif it[0] == 'st':
+                    h = self.transformer(pre, h)
+                else:
+                    h = self.conv(pre + '.conv', self.ew(h))      # F.interpolate
+        return self.conv('out.2', self.ew(self.gn('out.0', h)))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -163,10 +245,12 @@ class ChannelView:
         return self._out(name)
 
     def out_channels(self, node):
-        if node.kind in ('conv', 'linear', 'gn'):
+        if node.kind in ('conv', 'linear', 'gn', 'ln'):
             return self._out(node.name)
         if node.kind == 'cat':
             return sum(self.out_channels(i) for i in node.inputs)
+        if node.kind == 'slice':
+            return self.out_channels(node.inputs[0]) // node.part[1]
         for i in node.inputs:           # element-wise: same as (any) input
             c = self.out_channels(i)
             if c is not None:
@@ -193,7 +277,7 @@ def coupled_members(graph, chan, root_name, idxs):
     (Group.add_and_merge, dependency.py:492-494).
 
     A channel set S living on the output tensor of node n implies
-      producer side: conv/linear -> member (n, 'out', S), stop;  GroupNorm -> member (n, 'gn', S) and S on its input;
+      producer side: conv/linear -> member (n, 'out', S), stop;  Group/LayerNorm -> member (n, 'gn'|'ln', S) and S on its input;
                      element-wise -> S on every input;  cat -> S split over the inputs by their channel offsets;
       consumer side: conv/linear -> member (c, 'in', S), stop;  GroupNorm / element-wise -> S on c's output;
                      cat -> S shifted by the input's offset on c's output."""
@@ -219,10 +303,13 @@ def coupled_members(graph, chan, root_name, idxs):
         # ---- producer side
         if node.kind in ('conv', 'linear'):
             add(node.name, 'out', ii)
-        elif node.kind == 'gn':
-            add(node.name, 'gn', ii)
+        elif node.kind in ('gn', 'ln'):
+            add(node.name, node.kind, ii)
             for inp in node.inputs:
                 stack.append((inp, ii))
+        elif node.kind == 'slice':
+            d = chan.out_channels(node)
+            stack.append((node.inputs[0], [i + node.part[0] * d for i in ii]))
         elif node.kind == 'cat':
             off = 0
             for inp in node.inputs:
@@ -245,6 +332,11 @@ def coupled_members(graph, chan, root_name, idxs):
                         break
                     off += chan.out_channels(inp)
                 stack.append((c, [i + off for i in ii]))
+            elif c.kind == 'slice':
+                d = chan.out_channels(c)
+                sub = [i - c.part[0] * d for i in ii if c.part[0] * d <= i < (c.part[0] + 1) * d]
+                if sub:
+                    stack.append((c, sub))
             else:
                 stack.append((c, ii))
     return [Member(n, k, sorted(members[(n, k)])) for (n, k) in order]
@@ -264,7 +356,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
         members = coupled_members(graph, chan, node.name, list(range(n_out)))
         prunable = True
         for m in members:
-            if m.kind == 'out':
+            if m.kind in ('out', 'gn', 'ln'):        # members pruned through an out-channel pruning function
                 visited.add(m.name)
                 if m.name in ignored:
                     prunable = False

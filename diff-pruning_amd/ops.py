@@ -581,3 +581,22 @@ def add_rowvec(x, v, out=None):
         out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
     L.check(_lib().dp_add_rowvec(_p(x), s, _p(v), N, Cc, H * W, _p(out), _chk_act(out), _stream()), 'dp_add_rowvec')
     return out
+
+
+def q_sample(x0, noise, sqrt_acp, sqrt_1m_acp, t_long, out=None):
+    B = x0.shape[0]
+    if out is None:
+        out = torch.empty_like(x0)
+    assert t_long.dtype == torch.int64 and x0.is_contiguous() and noise.is_contiguous()
+    L.check(_lib().dp_q_sample(_p(x0), _p(noise), _p(sqrt_acp), _p(sqrt_1m_acp), _p(t_long), B, x0.numel() // B, _p(out),
+                               _stream()), 'dp_q_sample')
+    return out
+
+
+def cfg_combine(e_uncond, e_cond, scale, out=None):
+    assert e_uncond.is_contiguous() and e_cond.is_contiguous()
+    if out is None:
+        out = torch.empty_like(e_cond)
+    L.check(_lib().dp_cfg_combine(_p(e_uncond), _p(e_cond), float(scale), _p(out), e_cond.numel(), _stream()),
+            'dp_cfg_combine')
+    return out

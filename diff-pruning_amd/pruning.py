@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .graph import UNetGraph, ChannelView, coupled_members, all_groups
+from .graph import UNetGraph, LdmGraph, ChannelView, coupled_members, all_groups
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -81,13 +81,27 @@ def prune_groupnorm_out_channels(layer, idxs):
 
 prune_groupnorm_in_channels = prune_groupnorm_out_channels
 
+
+def prune_layernorm_out_channels(layer, idxs):
+    """function.py LayerNormPruner: slice the normalised (last) dimension of weight / bias."""
+    n = layer.normalized_shape[-1]
+    keep = _keep(n, idxs, layer.weight.device)
+    layer.normalized_shape = tuple(layer.normalized_shape[:-1]) + (n - len(set(idxs)),)
+    if layer.elementwise_affine:
+        _slice_param(layer, 'weight', 0, keep)
+        _slice_param(layer, 'bias', 0, keep)
+    return layer
+
 function = SimpleNamespace(
     prune_conv_out_channels=prune_conv_out_channels, prune_conv_in_channels=prune_conv_in_channels,
     prune_linear_out_channels=prune_linear_out_channels, prune_linear_in_channels=prune_linear_in_channels,
-    prune_groupnorm_out_channels=prune_groupnorm_out_channels, prune_groupnorm_in_channels=prune_groupnorm_in_channels)
+    prune_groupnorm_out_channels=prune_groupnorm_out_channels, prune_groupnorm_in_channels=prune_groupnorm_in_channels,
+    prune_layernorm_out_channels=prune_layernorm_out_channels)
 
 
 def _handler_for(layer, kind):
+    if kind == 'ln':
+        return prune_layernorm_out_channels
     if kind == 'gn':
         return prune_groupnorm_out_channels
     if isinstance(layer, nn.Linear):
@@ -100,6 +114,8 @@ def _out_channels(layer):
         return layer.out_features
     if isinstance(layer, nn.GroupNorm):
         return layer.num_channels
+    if isinstance(layer, nn.LayerNorm):
+        return layer.normalized_shape[-1]
     return layer.out_channels
 
 
@@ -108,6 +124,8 @@ def _in_channels(layer):
         return layer.in_features
     if isinstance(layer, nn.GroupNorm):
         return layer.num_channels
+    if isinstance(layer, nn.LayerNorm):
+        return layer.normalized_shape[-1]
     return layer.in_channels
 
 
@@ -158,6 +176,8 @@ def _member_kind(dep):
     fn = dep.handler
     owner = type(getattr(fn, '__self__', None)).__name__
     name = getattr(fn, '__name__', '')
+    if 'LayerNorm' in owner or 'layernorm' in name:
+        return 'ln'
     if 'GroupNorm' in owner or 'groupnorm' in name:
         return 'gn'
     if owner in ('ConvPruner', 'LinearPruner') or 'conv' in name or 'linear' in name:
@@ -223,7 +243,7 @@ class TaylorImportance(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
-            if kind is None:
+            if kind is None or kind == 'ln':          # LayerNorm members carry no term (importance.py:383-418)
                 continue
             layer = dep.target.module
             if kind == 'gn' and not layer.affine:
@@ -302,7 +322,8 @@ class DependencyGraph:
 
     def __init__(self, model):
         self.model = model
-        self.graph = UNetGraph(dict(model.config))
+        cfg = dict(model.config)
+        self.graph = LdmGraph(cfg) if 'model_channels' in cfg else UNetGraph(cfg)
         self.name2module = dict(model.named_modules())
         self.module2name = {m: n for n, m in self.name2module.items()}
 
@@ -324,7 +345,7 @@ class DependencyGraph:
 
     def check_pruning_group(self, group):
         for dep, idxs in group:
-            n = _out_channels(dep.target.module) if dep.kind in ('out', 'gn') else _in_channels(dep.target.module)
+            n = _out_channels(dep.target.module) if dep.kind in ('out', 'gn', 'ln') else _in_channels(dep.target.module)
             if n <= len(idxs):
                 return False
         return True
@@ -353,7 +374,7 @@ class MetaPruner:
         self.iterative_steps, self.current_step = iterative_steps, 0
         self.layer_init_out_ch, self.layer_init_in_ch = {}, {}
         for m in model.modules():
-            if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
+            if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
                 self.layer_init_out_ch[m] = _out_channels(m)
                 self.layer_init_in_ch[m] = _in_channels(m)
         self.per_step_ch_sparsity = iterative_sparsity_scheduler(ch_sparsity, iterative_steps)
@@ -386,7 +407,7 @@ class MetaPruner:
     def _check_sparsity(self, group):
         for dep, _ in group:
             m = dep.target.module
-            if dep.kind in ('out', 'gn'):
+            if dep.kind in ('out', 'gn', 'ln'):
                 n = _out_channels(m)
                 if n < self.layer_init_out_ch[m] * (1 - self.max_ch_sparsity) or n == 1:
                     return False

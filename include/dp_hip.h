@@ -169,6 +169,12 @@ int dp_geglu_bwd(const float* in, const float* dout, int N, long long half_plane
 int dp_add_rowvec(const float* x, long long x_img_stride, const float* v, int N, int C, int T, float* out,
                   long long o_img_stride, void* stream);
 
+/* q_sample with precomputed fp32 sqrt tables (ldm_exp/ldm/models/diffusion/ddpm.py q_sample / extract_into_tensor) */
+int dp_q_sample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1m_acp, const int64_t* t,
+                int B, long long per_img, float* out, void* stream);
+/* classifier-free guidance: out = e_uncond + scale * (e_cond - e_uncond)  (ldm_exp/ldm/models/diffusion/ddim.py:178-183) */
+int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, long long n, void* stream);
+
 /* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
 int dp_version(void);
 

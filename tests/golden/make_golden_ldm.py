@@ -47,10 +47,124 @@ def run(cfg, seed, B, tag):
     return stats, {n: list(p.shape) for n, p in P.items()}
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     stats, shapes = run(gc.LDM_TINY_CFG, 9, 2, '')
     full = UNetModel(**gc.LDM_CIN256_CFG)
     json.dump(dict(grad_stats=stats, shapes=shapes, cin256_params=sum(p.numel() for p in full.parameters()),
                    cin256_shapes={n: list(p.shape) for n, p in full.named_parameters()}),
               open(os.path.join(HERE, 'ldm_unet_stats.json'), 'w'))
     print('ok', len(stats))
+
+
+def ldm_groups():
+    """Group table of the LDM UNet under the reference's vendored torch_pruning (prune_ldm.py:70-100 setup)."""
+    sys.path.insert(0, '/root/reference/ddpm_exp')
+    os.makedirs('/tmp/golden_scratch', exist_ok=True)
+    os.chdir('/tmp/golden_scratch')
+    import torch_pruning as tp
+    out = {}
+    for tag, cfg in (('tiny', gc.LDM_TINY_CFG),):
+        m = UNetModel(**cfg).eval()
+        gc.det_init_(m, 9)
+        H = cfg['image_size']
+        ex = {'x': torch.randn(2, 3, H, H), 'timesteps': torch.full((2,), 1, dtype=torch.long),
+              'context': torch.randn(2, 1, cfg['context_dim'])}
+        pr = tp.pruner.MagnitudePruner(m, ex, importance=tp.importance.TaylorImportance(), iterative_steps=1,
+                                       channel_groups={}, ch_sparsity=0.3, ignored_layers=[m.out], round_to=2)
+        names = {mod: n for n, mod in m.named_modules()}
+        f = tp.function
+        table = []
+        for g in pr.DG.get_all_groups(ignored_layers=pr.ignored_layers, root_module_types=pr.root_module_types):
+            mem = []
+            for dep, idxs in g:
+                mod = dep.target.module
+                if mod not in names:
+                    continue
+                h = dep.handler
+                kind = ('out' if h in (f.prune_conv_out_channels, f.prune_linear_out_channels) else
+                        'in' if h in (f.prune_conv_in_channels, f.prune_linear_in_channels) else
+                        'gn' if h == f.prune_groupnorm_out_channels else
+                        'ln' if h == f.prune_layernorm_out_channels else 'other')
+                rng = []
+                for i in sorted(idxs):
+                    if rng and rng[-1][1] == i:
+                        rng[-1][1] = i + 1
+                    else:
+                        rng.append([i, i + 1])
+                mem.append([names[mod], kind, rng])
+            table.append(dict(ch_groups=int(pr.get_channel_groups(g)), members=mem))
+        out[tag] = table
+        print(tag, 'groups', len(table))
+    json.dump(out, open(os.path.join(HERE, 'ldm_groups.json'), 'w'))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'groups':
+    ldm_groups()
+
+
+def ldm_prune():
+    """One backward of the golden loss, then the reference's interactive prune (vendored TaylorImportance, ratio 0.3,
+    round_to=2, head groups for to_q/k/v as in prune_ldm.py:75-81) recording every group's scores and mask."""
+    sys.path.insert(0, '/root/reference/ddpm_exp')
+    os.makedirs('/tmp/golden_scratch', exist_ok=True)
+    os.chdir('/tmp/golden_scratch')
+    import torch_pruning as tp
+    from ldm.modules.attention import CrossAttention
+    cfg = gc.LDM_TINY_CFG
+    m = UNetModel(**cfg).eval()
+    gc.det_init_(m, 9)
+    H = cfg['image_size']
+    x = torch.from_numpy(gc.det_noise((2, 3, H, H), 31))
+    ctx = torch.from_numpy(gc.det_noise((2, 1, cfg['context_dim']), 32))
+    noise = torch.from_numpy(gc.det_noise((2, 3, H, H), 33))
+    t = torch.tensor([7, 640])
+    ex = {'x': torch.randn(2, 3, H, H), 'timesteps': torch.full((2,), 1, dtype=torch.long), 'context': torch.randn(2, 1, cfg['context_dim'])}
+    channel_groups = {}
+    for mod in m.modules():
+        if isinstance(mod, CrossAttention):
+            channel_groups[mod.to_q] = mod.heads
+            channel_groups[mod.to_k] = mod.heads
+            channel_groups[mod.to_v] = mod.heads
+    pr = tp.pruner.MagnitudePruner(m, ex, importance=tp.importance.TaylorImportance(), iterative_steps=1,
+                                   channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[m.out], round_to=2)
+    m.zero_grad()
+    loss = (m(x, t, context=ctx) - noise).square().mean(dim=(1, 2, 3)).mean()
+    loss.backward()
+    pr.current_step += 1
+    names = {mod: n for n, mod in m.named_modules()}
+    rec = []
+    for group in pr.DG.get_all_groups(ignored_layers=pr.ignored_layers, root_module_types=pr.root_module_types):
+        if not pr._check_sparsity(group):
+            continue
+        module, fn = group[0][0].target.module, group[0][0].handler
+        ch_groups = pr.get_channel_groups(group)
+        imp = pr.estimate_importance(group, ch_groups=ch_groups)
+        if imp is None:
+            continue
+        cur = pr.DG.get_out_channels(module)
+        n_pruned = cur - int(pr.layer_init_out_ch[module] * (1 - pr.get_target_sparsity(module)))
+        if pr.round_to:
+            n_pruned = n_pruned - (n_pruned % pr.round_to)
+        if n_pruned <= 0:
+            continue
+        if ch_groups > 1:
+            gs, per = cur // ch_groups, n_pruned // ch_groups
+            idxs = torch.cat([torch.argsort(imp[c * gs:(c + 1) * gs])[:per] + c * gs for c in range(ch_groups)], 0)
+        else:
+            idxs = torch.argsort(imp)[:(n_pruned // ch_groups)]
+        g2 = pr.DG.get_pruning_group(module, fn, idxs.tolist())
+        ok = pr.DG.check_pruning_group(g2)
+        rec.append(dict(root=names[module], ch_groups=int(ch_groups), cur=int(cur), n_pruned=int(n_pruned),
+                        pruned=sorted(int(i) for i in idxs.tolist()), score=gc.f32_to_b64(imp.detach().float().numpy()), ok=bool(ok)))
+        if ok:
+            g2.prune()
+    with torch.no_grad():
+        y2 = m(x, t, context=ctx)
+    json.dump(dict(prune=rec, shapes_after={n: list(p.shape) for n, p in m.named_parameters()},
+                   params_after=sum(p.numel() for p in m.parameters()), fwd_after=gc.f32_to_b64(y2.numpy())),
+              open(os.path.join(HERE, 'ldm_prune.json'), 'w'))
+    print('ldm prune groups', len(rec), 'params after', sum(p.numel() for p in m.parameters()))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'prune':
+    ldm_prune()

@@ -48,30 +48,31 @@ def relerr(a, ref):
     return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None):
+def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ignored=('conv_out',), gn_groups=None,
+                        round_to=None):
     """Run the oracle's score / select / slice arithmetic over the PRODUCT's group enumeration (host logic that is
     itself pinned against the reference's group tables).  P/G: {name: tensor} dicts, modified in place.
     Returns a list of dict(root, ch_groups, score, pruned, margin)."""
     from oracle import pruning_ref as R
-    graph = graph_mod.UNetGraph(cfg)
+    graph = graph if graph is not None else graph_mod.UNetGraph(cfg)
     init_out = {n[:-7]: P[n].shape[0] for n in P if n.endswith('.weight')}
     out = []
 
     def chan():
         return graph_mod.ChannelView({n: tuple(t.shape) for n, t in P.items()})
 
-    for root, members in graph_mod.all_groups(graph, chan, ('conv_out',)):
+    for root, members in graph_mod.all_groups(graph, chan, ignored):
         mem = [(m.name, m.kind, list(m.idxs)) for m in members]
-        score = R.taylor_score(P, G, mem)
+        score = R.taylor_score(P, G, [m for m in mem if m[1] != 'ln'])
         if score is None:
             continue
-        ch_groups = cfg['norm_num_groups'] if any(k == 'gn' for _, k, _ in mem) else 1
+        ch_groups = (gn_groups or cfg['norm_num_groups']) if any(k == 'gn' for _, k, _ in mem) else 1
         cur = P[root + '.weight'].shape[0]
-        pruned = R.select_pruned(score, cur, init_out[root], ratio, ch_groups)
+        pruned = R.select_pruned(score, cur, init_out[root], ratio, ch_groups, round_to)
         if not pruned:
             continue
         margin = R.decision_margin(score, pruned, cur, ch_groups)
         out.append(dict(root=root, ch_groups=ch_groups, score=score.clone(), pruned=pruned, margin=margin, cur=cur))
         for m in graph_mod.coupled_members(graph, chan(), root, pruned):
-            R.slice_member(P, G, m.name, m.kind, m.idxs)
+            R.slice_member(P, G, m.name, 'gn' if m.kind == 'ln' else m.kind, m.idxs)
     return out

@@ -296,3 +296,11 @@ def geglu_bwd(x, dout):
 
 def add_rowvec(x, v, out=None):
     return x + v[:, :, None, None]
+
+
+def q_sample(x0, noise, sa, sb, t, out=None):
+    return sa[t][:, None, None, None] * x0 + sb[t][:, None, None, None] * noise
+
+
+def cfg_combine(eu, ec, scale, out=None):
+    return eu + scale * (ec - eu)

@@ -408,3 +408,138 @@ def test_ldm_engine_backward_graph_matches_oracle(mocked, monkeypatch):
             assert relerr(grads[k], ref) < 5e-5, k
         else:
             assert float(grads[k].abs().max()) < 1e-6, k        # norm2 / attn2.to_q / attn2.to_k: exactly zero
+
+
+def _ldm_sweep_fixture(steps=3, n=2):
+    emb_w = torch.from_numpy(gc.det_noise((1001, 16), 77))
+    rng = np.random.default_rng(5)
+    draws = []
+    for t in range(steps):
+        xc = torch.tensor(rng.choice(1000, size=n, replace=False))
+        draws.append((xc, torch.from_numpy(gc.det_noise((n, 3, 16, 16), 300 + t)),
+                      torch.from_numpy(gc.det_noise((n, 3, 16, 16), 400 + t))))
+    return emb_w, draws
+
+
+def _ldm_oracle_sweep(cfg, emb_w, draws, S, thr):
+    from oracle import ldm_ref as L
+    P = {k: torch.from_numpy(gc.det_param(k, s, 9)).requires_grad_(True) for k, s in L.ldm_param_shapes(cfg).items()}
+    acp = L.ldm_alphas_cumprod()
+    n = draws[0][0].shape[0]
+    uc = emb_w[torch.tensor(n * [1000])][:, None, :]
+    losses, max_loss = [], -1.0
+    for t, (xc, x_T, noise) in enumerate(draws):
+        c = emb_w[xc][:, None, :]
+        Pd = {k: v.detach() for k, v in P.items()}
+        x0 = L.ddim_sample_cfg(Pd, cfg, acp, x_T, c, uc, S=S, scale=3.0)
+        loss = L.ldm_loss_at_t(P, cfg, acp, x0, torch.full((n,), t, dtype=torch.long), c, noise)
+        lv = float(loss.detach())
+        losses.append(lv)
+        max_loss = max(max_loss, lv)
+        if thr is not None and lv / max_loss < thr:
+            break
+        loss.backward()
+    return P, losses
+
+
+def test_ldm_importance_sweep_control_flow_matches_oracle(mocked, monkeypatch):
+    """prune_ldm.py:101-131 driver (CFG DDIM sampling -> loss at t -> break-before-backward) on mocked kernels."""
+    ldm, ldm_sweep, sweep = pkg('ldm'), pkg('ldm_sweep'), pkg('sweep')
+    for m in (ldm, ldm_sweep):
+        monkeypatch.setattr(m, 'ops', mocked)
+
+    def cpu_engine(self):
+        if self._engine is None:
+            self._engine = ldm.LdmEngine(self.config)
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        return self._engine
+    monkeypatch.setattr(ldm.UNetModel, 'engine', cpu_engine)
+    cfg = gc.LDM_TINY_CFG
+    emb_w, draws = _ldm_sweep_fixture()
+    for thr, expect_steps in ((None, 3), (1.5, 1)):        # thr 1.5: loss/max_loss = 1 < 1.5 at t = 0 -> break, nothing accumulated
+        model = ldm.UNetModel(**cfg)
+        gc.det_init_(model, 9)
+        embedder = ldm_sweep.ClassEmbedder(16, 1001)
+        with torch.no_grad():
+            embedder.embedding.weight.copy_(emb_w)
+        res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=3, thr=thr, n_samples=2, ddim_steps=4,
+                                             latent_shape=(3, 16, 16), draws=lambda t: draws[t])
+        P, losses = _ldm_oracle_sweep(cfg, emb_w, draws, 4, thr)
+        assert res['steps'] == len(losses) == expect_steps
+        assert np.allclose(res['losses'], losses, rtol=2e-5)
+        if thr is None:
+            for k, p in model.named_parameters():
+                ref = P[k].grad
+                if float(ref.abs().max()) > 1e-7:
+                    assert relerr(p.grad, ref) < 1e-4, k
+        else:
+            assert res['accumulated'] == 0 and float(res['flat_grads'].abs().max()) == 0.0
+
+
+def test_ldm_group_enumeration_matches_reference():
+    from oracle import ldm_ref as L
+    G = pkg('graph')
+    cfg = gc.LDM_TINY_CFG
+    table = load_json('ldm_groups.json')['tiny']
+    shapes = L.ldm_param_shapes(cfg)
+    groups = list(G.all_groups(G.LdmGraph(cfg), lambda: G.ChannelView(shapes), ('out', 'out.0', 'out.1', 'out.2')))
+    assert len(groups) == len(table) == 109
+    for ref, (root, mem) in zip(table, groups):
+        assert ref['members'][0][0] == root
+        assert {(m[0], m[1]): gc.expand(m[2]) for m in ref['members']} == {(m.name, m.kind): m.idxs for m in mem}, root
+
+
+def _ldm_grads_oracle():
+    from oracle import ldm_ref as L
+    cfg = gc.LDM_TINY_CFG
+    P = {k: torch.from_numpy(gc.det_param(k, s, 9)).requires_grad_(True) for k, s in L.ldm_param_shapes(cfg).items()}
+    x, ctx, noise, t = _ldm_inputs()
+    loss = (L.ldm_unet_forward(P, cfg, x, t, ctx) - noise).square().mean(dim=(1, 2, 3)).mean()
+    loss.backward()
+    return cfg, P
+
+
+def test_ldm_oracle_prune_masks_match_reference():
+    """Vendored Taylor scores + masks (ratio 0.3, round_to 2, GEGLU split coupling, LayerNorm members) for the LDM UNet."""
+    from oracle import ldm_ref as L
+    G = pkg('graph')
+    cfg, P = _ldm_grads_oracle()
+    fx = load_json('ldm_prune.json')
+    Pd = {n: p.detach().clone() for n, p in P.items()}
+    Gd = {n: p.grad.clone() for n, p in P.items()}
+    rec = oracle_prune_replay(Pd, Gd, cfg, 0.3, G, graph=G.LdmGraph(cfg), ignored=('out', 'out.0', 'out.1', 'out.2'),
+                              gn_groups=32, round_to=2)
+    ref_nonempty = [r for r in fx['prune'] if r['pruned']]      # GN groups of 32 channels prune 10 // 32 = 0 per sub-group
+    assert len(rec) == len(ref_nonempty)
+    for mine, ref in zip(rec, ref_nonempty):
+        assert mine['root'] == ref['root'] and mine['ch_groups'] == ref['ch_groups'], (mine['root'], ref['root'])
+        assert relerr(mine['score'], gc.b64_to_f32(ref['score'])) < 1e-5, ref['root']
+        assert mine['pruned'] == ref['pruned'], (ref['root'], mine['margin'])
+    assert {n: list(t.shape) for n, t in Pd.items()} == fx['shapes_after']
+    x, ctx, noise, t = _ldm_inputs()
+    with torch.no_grad():
+        y2 = L.ldm_unet_forward(Pd, cfg, x, t, ctx)
+    assert float((y2 - torch.from_numpy(gc.b64_to_f32(fx['fwd_after']))).abs().max()) < 1e-5
+
+
+def test_ldm_prune_flow_on_mocked_kernels(mocked, monkeypatch):
+    """MagnitudePruner(round_to=2, head channel_groups) on the product's LDM UNetModel reproduces the reference masks."""
+    ldm, pruning = pkg('ldm'), pkg('pruning')
+    cfg, P = _ldm_grads_oracle()
+    fx = load_json('ldm_prune.json')
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    for n, p in model.named_parameters():
+        p.grad = P[n].grad.clone()
+    channel_groups = {}
+    for m in model.modules():
+        if isinstance(m, ldm.CrossAttention):
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    pr = pruning.MagnitudePruner(model, None, importance=pruning.TaylorImportance(), iterative_steps=1,
+                                 channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.out], round_to=2)
+    for g in pr.step(interactive=True):
+        g.prune()
+    assert [r[0] for r in pr.records] == [r['root'] for r in fx['prune']]
+    assert [r[3] for r in pr.records] == [r['pruned'] for r in fx['prune']]
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == fx['shapes_after']
+    assert sum(p.numel() for p in model.parameters()) == fx['params_after']
