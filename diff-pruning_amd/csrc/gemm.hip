@@ -11,6 +11,12 @@
 // for k-contiguous ones).
 #include "dp_common.h"
 
+// Global -> LDS DMA for the lane-linear tiles of conv_gemm (A/B: same speed on the large shapes, +4..8 % on the 8x8 / 4x4
+// resolution layers, 16 fewer VGPRs -> 5 wavefronts/SIMD); compile with -UDP_LDSDMA ... to get the register-staged path.
+#ifndef DP_NO_LDSDMA
+#define DP_LDSDMA 1
+#endif
+
 // Raw buffer loads: the hardware range check (offset >= num_records -> 0.0f) replaces every bounds / padding /
 // tail select, so the loaders are straight-line code and hipcc is free to hoist all global loads of tile i+1 above the
 // MFMAs of tile i.  Invalid elements set bit 31 of the byte offset (all real offsets are < 2 GiB, enforced by ops.py).
@@ -33,6 +39,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dp_rsrc_uniform(const float* b
 __device__ __forceinline__ float dp_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     asm volatile("" : "+v"(byte_off));
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));   // b32 = raw bits
+}
+// LDS-DMA forms (buffer_load_dword[x4] ... lds): the wavefront writes base + lane*size directly into LDS, no VGPR
+// staging and no ds_write; out-of-range lanes write 0 (probed on gfx950: tools/probe/lds_probe.hip).
+typedef __attribute__((address_space(3))) void dp_lds_void;
+__device__ __forceinline__ void dp_bload_lds(__amdgpu_buffer_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dp_lds_void*)lds_wave_base, 4, (int)byte_off, 0, 0, 0);
+}
+__device__ __forceinline__ void dp_bload4_lds(__amdgpu_buffer_rsrc_t r, float* lds_wave_base, unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dp_lds_void*)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
 }
 __device__ __forceinline__ float4 dp_bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     asm volatile("" : "+v"(byte_off));
@@ -219,6 +236,40 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
         }
     };
 
+#ifdef DP_LDSDMA
+    // global -> LDS directly (only for the m-contiguous, non-straddling variant: its LDS images are lane-linear)
+    auto dma_tile = [&](int it, bool live, int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_SZ;
+        const int ch = it / p.ntaps;
+        const int tap = it - ch * p.ntaps;
+        const int c0 = ch * BK;
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            const int e = tid + 256 * j;
+            const int k = e / (BM / 4);
+            const int m = m0 + 4 * (e % (BM / 4));
+            const bool v = live && (c0 + k < C) && (m < p.lda);
+            const unsigned o = (unsigned)(((tap * C + c0 + k) * p.lda + m) * 4);
+            dp_bload4_lds(rA, As + 4 * (e - lane), v ? o : DP_OOB);
+        }
+        const int ky = tap / g.kw;
+        const int kx = tap - ky * g.kw;
+        int off;
+        const bool tv = dp_gather(g, b_ho, b_wo, ky, kx, off) && bpv && live;
+        const int cb = c0 + bk0;
+        const bool first = c0 < csplit;
+        const __amdgpu_buffer_rsrc_t rs = dp_rsrc_uniform(first ? X1 : X2s, first ? p.x1_bytes : x2b);
+        const unsigned o0 = (first ? pb1 : pb2) + (unsigned)(((first ? cb : cb - csplit) * HsWs + off) * 4);
+        const unsigned step = (unsigned)(BROWS * HsWs * 4);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool v = tv && (cb + BROWS * j < C);
+            dp_bload_lds(rs, Bs + (bk0 + BROWS * j) * BN + (bn - lane), v ? (o0 + j * step) : DP_OOB);
+        }
+    };
+#endif
+
     auto store_tile = [&](int buf) {
         float* As = smem + buf * STAGE;
         float* Bs = As + A_SZ;
@@ -253,16 +304,33 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     // The prefetch of tile it+1 is unconditional: past the last tile every offset is out of range (the buffer
     // unit returns zeros without touching memory), so there is no branch and no register merge that would force
     // hipcc to drain the loads before the MFMA block.
-    load_tile(0, true);
-    store_tile(0);
-    __syncthreads();
-    for (int it = 0; it < nIter; ++it) {
-        const int buf = it & 1;
-        load_tile(it + 1, it + 1 < nIter);
-        const float* As = smem + buf * STAGE;
-        mfma_tile<BM, BN, BK, TM, TN, A_KC, false>(As, As + A_SZ, wm0, wn0, lane, acc);
-        store_tile(buf ^ 1);
+#ifdef DP_LDSDMA
+    if constexpr (!A_KC && !STRADDLE) {
+        dma_tile(0, true, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int it = 0; it < nIter; ++it) {
+            const int buf = it & 1;
+            dma_tile(it + 1, it + 1 < nIter, buf ^ 1);       // lands in the other buffer while this one is consumed
+            const float* As = smem + buf * STAGE;
+            mfma_tile<BM, BN, BK, TM, TN, A_KC, false>(As, As + A_SZ, wm0, wn0, lane, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA complete before anyone reads buf^1
+            __syncthreads();
+        }
+    } else
+#endif
+    {
+        load_tile(0, true);
+        store_tile(0);
+        __syncthreads();
+        for (int it = 0; it < nIter; ++it) {
+            const int buf = it & 1;
+            load_tile(it + 1, it + 1 < nIter);
+            const float* As = smem + buf * STAGE;
+            mfma_tile<BM, BN, BK, TM, TN, A_KC, false>(As, As + A_SZ, wm0, wn0, lane, acc);
+            store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
