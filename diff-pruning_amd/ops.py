@@ -207,6 +207,7 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
 
 
 _ws_cache = {}
+WGRAD_BLOCKS = 1024          # target workgroups per wgrad launch (256 CUs x 4 resident workgroups)
 
 
 def _workspace(n, device):
@@ -238,7 +239,7 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     tile = 0 if Cout > 64 else 1
     bm, bn, _ = _TILES[tile]
     tiles = -(-Cout // bm) * -(-Cin // bn) * taps
-    splits = max(1, min(-(-768 // tiles), P // 1024 if P >= 2048 else 1))
+    splits = max(1, min(WGRAD_BLOCKS // tiles, P // 512 if P >= 1024 else 1))     # floor: never spill into a 2nd round
     if max_splits is not None:
         splits = max(1, min(splits, max_splits))
     pps = -(-P // splits)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Config C3 shape check + timing: bedroom/church-256 UNet (113.7 M params), batch 4 per GPU, sweep timesteps."""
+import importlib, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
+import golden_common as gc
+unet = importlib.import_module('diff-pruning_amd.unet'); sweep = importlib.import_module('diff-pruning_amd.sweep')
+diffusion = importlib.import_module('diff-pruning_amd.diffusion')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+m = unet.UNet2DModel(**gc.BEDROOM_CFG); gc.det_init_(m, 0); m = m.cuda().eval()
+print('params', sum(p.numel() for p in m.parameters()))
+clean = torch.from_numpy(gc.det_clean((B, 3, 256, 256), 1)).cuda(); noise = torch.from_numpy(gc.det_noise((B, 3, 256, 256), 2)).cuda()
+flat = sweep.flatten_grads(m)
+step = sweep.HipSweepStep(m, diffusion.DDPMScheduler(), clean, noise, B * clean[0].numel(), 'mse', B)
+for k in range(2): l = step(k)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for k in range(2, 6): l = step(k)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+print('bedroom-256 B=%d: %.1f ms/step, %.2f image-steps/s, %.1f TFLOP/s (1.491 TFLOP/img-step), loss %.5f, grad finite %s, peak mem %.1f GB'
+      % (B, dt * 1e3, B / dt, 1.491e12 * B / dt / 1e12, float(l), bool(torch.isfinite(flat).all()), torch.cuda.max_memory_allocated() / 2**30))
+t0 = time.perf_counter(); pr = sweep.prune_model(m, 0.3); torch.cuda.synchronize()
+print('prune: %d groups, %.0f ms, params after %d' % (len(pr.records), (time.perf_counter() - t0) * 1e3, sum(p.numel() for p in m.parameters())))

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""wgrad split-K target sweep."""
+import importlib, math, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ops = importlib.import_module('diff-pruning_amd.ops')
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / iters * 1e-3
+B = 256
+shapes = [(128, 128, 32, 3), (256, 256, 16, 3), (512, 256, 16, 3), (384, 128, 32, 3), (256, 256, 8, 3), (256, 256, 4, 3), (512, 256, 16, 1), (128, 3, 32, 3)]
+for blocks in (768, 1024, 2048):
+    ops.WGRAD_BLOCKS = blocks
+    out = []
+    for (ci, co, h, k) in shapes:
+        x = torch.randn(B, ci, h, h, device='cuda'); dy = torch.randn(B, co, h, h, device='cuda'); gw = torch.zeros(co, ci, k, k, device='cuda')
+        spec = ops.ConvSpec(k, 1, k // 2, 0)
+        t = timeit(lambda: ops.conv_wgrad(dy, x, None, gw, spec, accumulate=True))
+        out.append('%.0f' % (2.0 * B * h * h * ci * co * k * k / t / 1e12))
+    print(blocks, ' '.join(out), flush=True)
