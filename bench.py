@@ -132,15 +132,28 @@ def main():
         torch.cuda.synchronize()
         log, ops._prof = ops._prof, None
         agg = {}
-        for name, fl, st, en in log:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, fl, st, en, ab in log:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += fl
             a[2] += st.elapsed_time(en) * 1e-3
+            a[3] += ab
         dom = max(agg, key=lambda n: agg[n][2])
-        cnt, fl, sec = agg[dom]
+        cnt, fl, sec, ab = agg[dom]
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same command, profiles/round1_pmc_bench_traffic.json); KB -> bytes.
+        # FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on gfx950 (MI355X_MICROARCH.md, HBM section).
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'round1_pmc_bench_traffic.json')))
+            k = pm.get(dom)
+            if k:
+                traffic = (k['FETCH_SIZE']['avg_kb'] + k['WRITE_SIZE']['avg_kb']) * 1024.0
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roof = dict(bound='mfma', kernel=dom, achieved=fl / sec / 1e12, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
-                    frac=fl / sec / 1e12 / PEAK_F32_TFLOPS, traffic=None, launches_per_step=cnt,
+                    frac=fl / sec / 1e12 / PEAK_F32_TFLOPS, traffic=traffic, algorithmic_bytes_per_launch=ab / cnt,
+                    launches_per_step=cnt,
                     avg_launch_ms=sec / cnt * 1e3, flop_per_launch=fl / cnt,
                     step_share=sec / (t_sweep / args.steps),
                     kernels={n: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, ms=v[2] * 1e3) for n, v in agg.items()},

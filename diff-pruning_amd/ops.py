@@ -32,14 +32,14 @@ _prof = None
 _TILE_NAMES = ('128, 128', '64, 128', '64, 64')
 
 
-def _run(call, name, flops):
+def _run(call, name, flops, abytes=0.0):
     if _prof is None:
         return call()
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st.record()
     r = call()
     en.record()
-    _prof.append((name, flops, st, en))
+    _prof.append((name, flops, st, en, abytes))
     return r
 
 
@@ -174,8 +174,8 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
         p.res, p.r_img_stride = _p(res), _chk_act(res)
         assert res.shape == out.shape
     p.accumulate = 1 if accumulate else 0
-    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps),
-            'dp_conv_gemm(forward)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
+                 4.0 * (N * Cin * Hs * Ws + wp.numel() + out.numel())), 'dp_conv_gemm(forward)')
     return out
 
 
@@ -201,8 +201,8 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, 1.0
     p.accumulate = 1 if accumulate else 0
-    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps),
-            'dp_conv_gemm(dgrad)')
+    L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
+                 4.0 * (dy.numel() + wd.numel() + out.numel())), 'dp_conv_gemm(dgrad)')
     return out
 
 
