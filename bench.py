@@ -103,6 +103,7 @@ def main():
     losses = []
     for k in range(args.steps):
         losses.append(step(k))
+    t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (GPU runs asynchronously)
     torch.cuda.synchronize()
     t_sweep = time.perf_counter() - t0
     if world > 1:
@@ -176,6 +177,7 @@ def main():
                                    % (B, args.steps - 1),
                        'global_batch': world * B, 'image': '3x32x32', 'parallelism': 'dp%d (batch shards)' % world,
                        'sweep_only_images_per_s': imgs / t_sweep, 'tail_ms': (t_total - t_sweep) * 1e3,
+                       'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
                        'pruned_groups': len(pr.records), 'params_after': n_params_after,
                        'loss_first_last': [loss_vals[0], loss_vals[-1]]},
             'roofline': roof, 'cpu_baseline': cpu,

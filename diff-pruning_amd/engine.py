@@ -59,6 +59,14 @@ class UNetEngine:
         self.P = params
         self.G = grads
 
+    def prepare_packs(self):
+        """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
+        must not be recorded into the replayed graph)."""
+        for name, w in self.P.items():
+            if name.endswith('.weight') and w.dim() >= 2:
+                self.packs.get(name[:-7], w, 0)
+                self.packs.get(name[:-7], w, 1)
+
     def attn_scale(self, channels):
         hd = self.cfg.get('attention_head_dim')
         return float(hd if hd is not None else channels) ** -0.5

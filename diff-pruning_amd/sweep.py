@@ -46,18 +46,39 @@ class HipSweepStep:
         self.eng = model.engine()
         self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
         self.acp = scheduler._acp_on(clean.device)
+        self._graph = None
 
-    def __call__(self, k):
-        t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+    def _step(self, t):
         noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
         loss, dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
         self.eng.backward(dout)
-        return loss          # [1] device tensor: this rank's share of L_t
+        return loss
+
+    def capture(self):
+        """Record one timestep (~900 kernel launches) into a hipGraph; afterwards every step is: write t, replay.
+        Removes the ~60 ms of Python/ctypes launch overhead per step -- the launch-bound regime at small batch."""
+        self.eng.prepare_packs()
+        ops._workspace(1 << 25, self.clean.device)          # split-K workspace must exist before capture
+        self._t = torch.zeros(self.B, dtype=torch.long, device=self.clean.device)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._loss = self._step(self._t)
+        self._graph = g
+        return self
+
+    def __call__(self, k):
+        if self._graph is not None:
+            self._t.fill_(int(k))
+            self._graph.replay()
+            return self._loss.clone()
+        t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+        return self._step(t)          # [1] device tensor: this rank's share of L_t
 
 
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
-                 step_fn=None, flat_grads=None, reduce_grads=True):
+                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
 
     clean_images / noise: this rank's shard.  `group`: torch.distributed process group (None = default group if
@@ -77,6 +98,8 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         flat_grads = flatten_grads(model)
     if step_fn is None:
         step_fn = HipSweepStep(model, scheduler, clean_images, noise, B_global * per_img, loss_kind, B_global)
+        if use_graph:
+            step_fn.capture()
     losses = []
     pending = []
     loss_max = 0.0

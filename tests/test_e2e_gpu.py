@@ -397,3 +397,25 @@ def test_ldm_importance_sweep_matches_oracle(report):
     report['e2e/ldm_sweep'] = dict(loss_rel=e_l, grad_rel_worst=worst, steps=res['steps'])
     # 4 CFG-DDIM steps (guidance scale 3 amplifies rounding) feed the loss: 1e-4 on losses / gradients
     assert res['steps'] == 3 and e_l < 1e-4 and worst < 2e-4
+
+
+def test_hipgraph_sweep_matches_eager(report):
+    """One captured timestep replayed per t gives bit-identical losses and gradients to the eager launch sequence."""
+    import time
+    cfg = gc.CIFAR_CFG
+    clean, noise = _inputs(4, 32)
+    sweep = pkg('sweep')
+    sched = pkg('diffusion').DDPMScheduler()
+    out = {}
+    for mode in (False, True):
+        model = make_model(cfg, 0)
+        sweep.taylor_sweep(model, sched, clean.to(DEV), noise.to(DEV), num_steps=1, use_graph=mode)     # warm
+        model = make_model(cfg, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sweep.taylor_sweep(model, sched, clean.to(DEV), noise.to(DEV), num_steps=8, use_graph=mode)
+        torch.cuda.synchronize()
+        out[mode] = (res['losses'], torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone(), time.perf_counter() - t0)
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+    report['e2e/hipgraph'] = dict(eager_s=out[False][2], graph_s=out[True][2], config='C1: CIFAR UNet B=4, 8 timesteps (incl. capture)')
