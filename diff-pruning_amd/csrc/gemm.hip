@@ -139,11 +139,18 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     const int HsWs = g.Hs * g.Ws;
     const int C = p.C;
     const int nch = (C + BK - 1) / BK;
-    const int nIter = p.ntaps * nch;
+    const int nIterAll = p.ntaps * nch;
+    // split-K (ksplit > 1, non-batched): workgroup z reduces K-tiles [it0, it0 + nIter) and stores its raw partial
+    // tile to ws[z][m][pix]; dp_conv_splitk_epilogue sums the partials in ascending z and applies the epilogue.
+    const bool ksplit = p.ksplit > 1;
+    const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
+    const int it0 = ksplit ? z * per : 0;
+    const int nIter = ksplit ? max(0, min(per, nIterAll - it0)) : nIterAll;
+    const int zb = ksplit ? 0 : z;            // batch index (0 in split-K mode)
 
-    const float* __restrict__ Ab = p.A + (long long)z * p.a_bs;
-    const float* __restrict__ X1 = p.X1 + (long long)z * p.x_bs;
-    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)z * p.x_bs : nullptr;
+    const float* __restrict__ Ab = p.A + (long long)zb * p.a_bs;
+    const float* __restrict__ X1 = p.X1 + (long long)zb * p.x_bs;
+    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)zb * p.x_bs : nullptr;
 
     // ---- B loader: this thread owns pixel column bn of the tile for the whole K loop
     constexpr int NB = BK * BN / 256;
@@ -182,7 +189,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 
     // K order: channel chunk outer, kernel tap inner -- the 16-channel input slab (tile + halo, ~10 KB) is re-read by
     // the 9 taps back-to-back and stays in L1/L2 instead of being evicted between taps.
-    auto load_tile = [&](int it, bool live) {
+    auto load_tile = [&](int itr, bool live) {
+        const int it = it0 + itr;
         const int ch = it / p.ntaps;
         const int tap = it - ch * p.ntaps;
         const int c0 = ch * BK;
@@ -238,9 +246,10 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 
 #ifdef DP_LDSDMA
     // global -> LDS directly (only for the m-contiguous, non-straddling variant: its LDS images are lane-linear)
-    auto dma_tile = [&](int it, bool live, int buf) {
+    auto dma_tile = [&](int itr, bool live, int buf) {
         float* As = smem + buf * STAGE;
         float* Bs = As + A_SZ;
+        const int it = it0 + itr;
         const int ch = it / p.ntaps;
         const int tap = it - ch * p.ntaps;
         const int c0 = ch * BK;
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     // hipcc to drain the loads before the MFMA block.
 #ifdef DP_LDSDMA
     if constexpr (!A_KC && !STRADDLE) {
-        dma_tile(0, true, 0);
+        dma_tile(0, nIter > 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int it = 0; it < nIter; ++it) {
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     } else
 #endif
     {
-        load_tile(0, true);
+        load_tile(0, nIter > 0);
         store_tile(0);
         __syncthreads();
         for (int it = 0; it < nIter; ++it) {
@@ -334,6 +343,22 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if (ksplit) {
+        float* __restrict__ wsb = p.ws + (long long)z * p.M * p.NPIX;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int pix = n0 + wn0 + tn * 32 + (lane & 31);
+            if (pix >= p.NPIX) continue;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) wsb[(long long)m * p.NPIX + pix] = acc[tm][tn][r];
+                }
+        }
+        return;
+    }
     float* __restrict__ outb = p.out + (long long)z * p.o_bs;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
-    dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.batches > 0 ? p.batches : 1);
+    dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
     // a K-chunk of 16 channels can straddle the concat boundary only when c_split is not a multiple of 16
     const bool straddle = p.X2 != nullptr && (p.g.c_split % 16) != 0;
     if (p.a_kc) {
@@ -378,18 +403,47 @@ static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     return DP_LAUNCH_CHECK();
 }
 
+// out = epilogue(sum_z ws[z][m][pix])  -- fixed summation order; same epilogue arithmetic as the fused path
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const dp_conv_gemm_params p) {
+    const long long total = (long long)p.M * p.NPIX;
+    const int HoWo = p.g.Ho * p.g.Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.NPIX);
+        const int pix = (int)(i - (long long)m * p.NPIX);
+        float a = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) a += p.ws[(long long)z * total + i];
+        const int img = pix / HoWo;
+        const int r_in = pix - img * HoWo;
+        float v = p.alpha * a;
+        if (p.bias) v += p.bias[m];
+        if (p.tadd) v += p.tadd[(long long)img * p.tadd_stride + m];
+        if (p.res) v += p.res[(long long)img * p.r_img_stride + (long long)m * HoWo + r_in];
+        v *= p.post_scale;
+        float* o = p.out + (long long)img * p.o_img_stride + (long long)m * HoWo + r_in;
+        if (p.accumulate) v += *o;
+        *o = v;
+    }
+}
+
 extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
     const dp_conv_gemm_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
     if (p.M <= 0 || p.NPIX <= 0) return 0;
+    if (p.ksplit > 1 && (p.batches > 1 || !p.ws)) return (int)hipErrorInvalidValue;
     if (!p.a_kc && (p.lda & 3)) return (int)hipErrorInvalidValue;
     if (p.a_kc && p.ntaps != 1) return (int)hipErrorInvalidValue;
+    int e;
     switch (p.tile) {
-        case 0: return launch_conv_gemm<128, 128>(p, st);
-        case 1: return launch_conv_gemm<64, 128>(p, st);
-        case 2: return launch_conv_gemm<64, 64>(p, st);
+        case 0: e = launch_conv_gemm<128, 128>(p, st); break;
+        case 1: e = launch_conv_gemm<64, 128>(p, st); break;
+        case 2: e = launch_conv_gemm<64, 64>(p, st); break;
         default: return (int)hipErrorInvalidValue;
     }
+    if (e || p.ksplit <= 1) return e;
+    long long nb = ((long long)p.M * p.NPIX + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+    return DP_LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -99,6 +99,24 @@ def pick_tile(M, N, z=1):
     return best
 
 
+CONV_SPLITK_BLOCKS = 1024      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
+
+
+def _conv_ksplit(p, device):
+    """Choose split-K for a non-batched conv_gemm whose tile grid would leave most CUs idle (8x8 / 4x4 resolution
+    layers, small batches): big tiles keep the MFMA efficiency, the K loop supplies the parallelism."""
+    p.ksplit, p.ws = 1, None
+    if CONV_SPLITK_BLOCKS <= 0:
+        return
+    tiles = -(-p.M // 128) * -(-p.NPIX // 128)
+    n_iter = p.ntaps * -(-p.C // 16)
+    s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // 8)
+    if s >= 2 and p.M >= 64:
+        p.tile = 0 if p.M > 64 else 1
+        p.ksplit = s
+        p.ws = _p(_workspace(s * p.M * p.NPIX, device))
+
+
 def roundup4(n):
     return (n + 3) & ~3
 
@@ -174,6 +192,7 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
         p.res, p.r_img_stride = _p(res), _chk_act(res)
         assert res.shape == out.shape
     p.accumulate = 1 if accumulate else 0
+    _conv_ksplit(p, x.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
                  4.0 * (N * Cin * Hs * Ws + wp.numel() + out.numel())), 'dp_conv_gemm(forward)')
     return out
@@ -201,6 +220,7 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, 1.0
     p.accumulate = 1 if accumulate else 0
+    _conv_ksplit(p, dy.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
                  4.0 * (dy.numel() + wd.numel() + out.numel())), 'dp_conv_gemm(dgrad)')
     return out

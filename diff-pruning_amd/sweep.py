@@ -31,6 +31,7 @@ def flatten_grads(model):
 
 class HipSweepStep:
     """One timestep of the sweep on the local image shard (forward + loss + backward on the HIP kernels)."""
+    _graph = None
 
     def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
         if clean.device.type != 'cuda':
@@ -46,7 +47,6 @@ class HipSweepStep:
         self.eng = model.engine()
         self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
         self.acp = scheduler._acp_on(clean.device)
-        self._graph = None
 
     def _step(self, t):
         noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
@@ -59,7 +59,7 @@ class HipSweepStep:
         """Record one timestep (~900 kernel launches) into a hipGraph; afterwards every step is: write t, replay.
         Removes the ~60 ms of Python/ctypes launch overhead per step -- the launch-bound regime at small batch."""
         self.eng.prepare_packs()
-        ops._workspace(1 << 25, self.clean.device)          # split-K workspace must exist before capture
+        ops._workspace(1 << 26, self.clean.device)          # split-K workspace must exist before capture
         self._t = torch.zeros(self.B, dtype=torch.long, device=self.clean.device)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -33,7 +33,9 @@ typedef struct dp_conv_geom {
  * a_kc = 0: A is a packed weight  A[(tap*C + c)*lda + m]  (m contiguous, lda % 4 == 0, zero padded)
  * a_kc = 1: A[m*lda + c]  (c contiguous; taps must be 1)
  * Epilogue: v = alpha*acc (+bias[m]) (+tadd[img*tadd_stride + m]) (+res[img*r_img_stride + m*HoWo + r]);
- *           v *= post_scale; out = accumulate ? out + v : v. */
+ *           v *= post_scale; out = accumulate ? out + v : v.
+ * ksplit > 1 (small pixel counts): the K loop is split over workgroups, raw partial tiles go to ws and a second
+ * kernel sums them in a fixed order and applies the same epilogue (deterministic). */
 typedef struct dp_conv_gemm_params {
     const float* A; long long a_bs; int lda; int a_kc;
     const float* X1; const float* X2; long long x_bs;
@@ -44,7 +46,8 @@ typedef struct dp_conv_gemm_params {
     float alpha; float post_scale;
     const float* bias; const float* tadd; long long tadd_stride;
     const float* res; long long r_img_stride;
-    int accumulate; int _pad;
+    int accumulate; int ksplit;            /* ksplit > 1: split the K loop over blockIdx.z, partials in ws (non-batched only) */
+    float* ws;                             /* >= ksplit*M*NPIX floats when ksplit > 1 */
 } dp_conv_gemm_params;
 int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
 

@@ -119,6 +119,35 @@ def test_conv_forward_dgrad_wgrad(ops, report, case):
     assert max(e_f, e_ep, e_acc, e_d, e_w, e_w2) < 2e-5, report['conv/' + name]
 
 
+def test_conv_fwd_dgrad_splitk(ops, report, monkeypatch):
+    """Forward / dgrad split-K (small pixel counts: 4x4 and 8x8 layers, small batches): engaged by the heuristic,
+    run-to-run deterministic, and equal to the unsplit kernel up to summation order."""
+    N, C1, C2, Cout, H = 4, 200, 56, 256, 8
+    xa, xb = rnd(N, C1, H, H, seed=1), rnd(N, C2, H, H, seed=2)
+    w = rnd(Cout, C1 + C2, 3, 3, seed=3, scale=0.02)
+    b = rnd(Cout, seed=4)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    wd, ldd = ops.pack_weight(w, 1)
+    dy = rnd(N, Cout, H, H, seed=5)
+    seen = []
+    real = ops._conv_ksplit
+    monkeypatch.setattr(ops, '_conv_ksplit', lambda p, d: (real(p, d), seen.append(p.ksplit))[0])
+    y1 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b).clone()
+    y2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b).clone()
+    d1 = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H)).clone()
+    assert seen and min(seen) >= 2, seen
+    assert torch.equal(y1, y2)
+    monkeypatch.setattr(ops, 'CONV_SPLITK_BLOCKS', 0)
+    y0 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b)
+    d0 = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H))
+    assert seen[-1] == 1
+    ref = ref_conv(torch.cat([xa, xb], 1), w, b, 1, 1, 0, False)
+    report['conv/splitk_fwd_dgrad'] = dict(fwd_vs_unsplit=relerr(y1, y0), dgrad_vs_unsplit=relerr(d1, d0),
+                                           fwd_vs_fp64=relerr(y1, ref), ksplit=seen[:3])
+    assert relerr(y1, y0) < 5e-6 and relerr(d1, d0) < 5e-6 and relerr(y1, ref) < 2e-5
+
+
 def test_conv_wgrad_splitk_large(ops, report):
     """Split-K path (many pixels): B*HW = 16384 pixels, deterministic across runs."""
     N, Cin, Cout, H = 16, 64, 96, 32
