@@ -42,7 +42,7 @@ class NtGemmParams(C.Structure):
                 ('batches', C.c_int), ('splits', C.c_int), ('p_per_split', C.c_int), ('tile', C.c_int),
                 ('batched', C.c_int),
                 ('out', C.c_void_p), ('o_bs', LL), ('ldo', C.c_int), ('accumulate', C.c_int),
-                ('alpha', C.c_float), ('_pad', C.c_int)]
+                ('alpha', C.c_float), ('merge', C.c_int), ('ocs', LL), ('col_bias', C.c_void_p)]
 
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL

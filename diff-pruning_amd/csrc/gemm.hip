@@ -455,7 +455,11 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
 #ifndef NT_BK
 #define NT_BK 16
 #endif
-template <int BM, int BN, bool STRADDLE>
+// MERGE (few input channels, e.g. conv_in / conv_out weight gradients): the kernel taps are folded into the column
+//   index, col = c*ntaps + tap, so one tile holds all C*ntaps columns instead of ntaps workgroups with C of BN
+//   columns each; merge bit 1 mirrors the taps (the gathered tensor is dy and the plain rows are x: the roles of the
+//   two operands swapped, for few OUTPUT channels).  Output element (row, c, tap) at row*ldo + c*ocs + tap.
+template <int BM, int BN, bool STRADDLE, bool MERGE = false>
 __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params p) {
     constexpr int BK = NT_BK;
     constexpr int LD = BK + 1;
@@ -480,8 +484,8 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
     const int HoWo = g.Ho * g.Wo;
     const int HsWs = g.Hs * g.Ws;
     const int batch = p.batched ? z : 0;
-    const int split = p.batched ? 0 : z / p.ntaps;
-    const int tap = p.batched ? 0 : z - split * p.ntaps;
+    const int split = p.batched ? 0 : (MERGE ? z : z / p.ntaps);
+    const int tap = (p.batched || MERGE) ? 0 : z - split * p.ntaps;
     const int ky = tap / g.kw;
     const int kx = tap - ky * g.kw;
     const int p_begin = split * p.p_per_split;
@@ -523,11 +527,25 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
             const bool v = pv && (m < p.M);
             ra[j] = dp_bload(rA, v ? (ab + (unsigned)m * astep) : DP_OOB);
         }
-        int off;
-        const bool tv = dp_gather(g, ho, wo, ky, kx, off) && pv;
         const unsigned pb1 = (unsigned)((long long)img * g.x1_img_stride * 4);
         const unsigned pb2 = (unsigned)((long long)img * g.x2_img_stride * 4);
         const int cb = n0 + r0;
+        if constexpr (MERGE) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int col = cb + RSTEP * j;
+                const int c = col / p.ntaps;
+                int t = col - c * p.ntaps;
+                if (p.merge & 2) t = p.ntaps - 1 - t;
+                const int tky = t / g.kw;
+                int o;
+                const bool v = dp_gather(g, ho, wo, tky, t - tky * g.kw, o) && pv && (col < p.NCOLS);
+                rb[j] = dp_bload(r1, v ? (pb1 + (unsigned)((c * HsWs + o) * 4)) : DP_OOB);
+            }
+            return;
+        }
+        int off;
+        const bool tv = dp_gather(g, ho, wo, ky, kx, off) && pv;
         if constexpr (!STRADDLE) {
             const __amdgpu_buffer_rsrc_t rs = rs_one;
             const unsigned o0 = (first_src ? pb1 : pb2) + (unsigned)(((first_src ? cb : cb - csplit) * HsWs + off) * 4);
@@ -590,8 +608,15 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
-                float* o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
+                float* o;
+                if constexpr (MERGE) {
+                    const int c = col / p.ntaps;
+                    o = outb + (long long)m * p.ldo + (long long)c * p.ocs + (col - c * p.ntaps);
+                } else {
+                    o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
+                }
                 float v = p.alpha * acc[tm][tn][r];
+                if (p.col_bias && split == 0) v += p.col_bias[col];
                 if (p.accumulate) v += *o;
                 *o = v;
             }
@@ -614,6 +639,12 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p.M <= 0 || p.NCOLS <= 0) return 0;
     if (!p.batched && (p.p_per_split <= 0 || (p.p_per_split & (NT_BK - 1)))) return (int)hipErrorInvalidValue;
+    if (p.merge) {               // NCOLS = C*ntaps merged columns, one source, 64x64 tiles, blockIdx.z = split
+        if (p.batched || p.X2 || p.splits <= 0) return (int)hipErrorInvalidValue;
+        dim3 grid((p.NCOLS + 63) / 64, (p.M + 63) / 64, p.splits);
+        hipLaunchKernelGGL((nt_gemm_kernel<64, 64, false, true>), grid, dim3(256), 0, st, p);
+        return DP_LAUNCH_CHECK();
+    }
     switch (p.tile) {
         case 0: return launch_nt_gemm<128, 128>(p, st);
         case 1: return launch_nt_gemm<64, 128>(p, st);

@@ -77,9 +77,18 @@ class UNetEngine:
         wp, ld = self.packs.get(name, w, 0)
         return ops.conv_forward(x, x2, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), **kw)
 
-    def _linear(self, name, x2d, **kw):
-        y = self._conv(name, ops.as4d(x2d), None, _SPEC1, **kw)
-        return y.view(y.shape[0], y.shape[1])
+    def _linear(self, name, x2d):
+        return ops.linear_forward(x2d, self.P[name + '.weight'], self.P.get(name + '.bias'))
+
+    def _linear_bwd(self, name, dy2d, x2d, *, need_dx=True, dx_out=None, dx_accumulate=False):
+        """Accumulate weight / bias gradients of nn.Linear `name`; return (or accumulate) the input gradient."""
+        w = self.P[name + '.weight']
+        ops.linear_wgrad(dy2d, x2d, self.G[name + '.weight'], accumulate=True)
+        if (name + '.bias') in self.P:
+            ops.colsum_accum(dy2d, dy2d.shape[0], dy2d.shape[1], 1, 0, self.G[name + '.bias'], True)
+        if not need_dx:
+            return None
+        return ops.linear_dgrad(dy2d, w, out=dx_out, accumulate=dx_accumulate)
 
     def _conv_bwd(self, name, dy, x, x2, spec, in_hw, *, need_dx=True, rows=None, dx_out=None, dx_accumulate=False,
                   alpha=1.0):
@@ -140,8 +149,7 @@ class UNetEngine:
         del dn2
         # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
         rows_h = ops.rowsum_nc(dh)
-        self._conv_bwd(pre + nm['temb'], ops.as4d(rows_h), ops.as4d(semb), None, _SPEC1, (1, 1), rows=rows_h,
-                       dx_out=ops.as4d(d_semb), dx_accumulate=True)
+        self._linear_bwd(pre + nm['temb'], rows_h, semb, dx_out=d_semb, dx_accumulate=True)
         dn1 = self._conv_bwd(pre + nm['conv1'], dh, n1, None, _SPEC3, hw, rows=rows_h)
         del dh
         if has_sc:
@@ -330,9 +338,8 @@ class UNetEngine:
         self._conv_bwd('conv_in', dx, sample, None, _SPEC3, None, need_dx=False)
         # time embedding MLP (embeddings.py:200-212)
         d_emb = ops.silu_bwd(emb, d_semb)
-        d_a1 = self._conv_bwd('time_embedding.linear_2', ops.as4d(d_emb), ops.as4d(a1), None, _SPEC1, (1, 1), rows=d_emb)
-        d_h1 = ops.silu_bwd(h1, d_a1.view(d_a1.shape[0], d_a1.shape[1]))
-        self._conv_bwd('time_embedding.linear_1', ops.as4d(d_h1), ops.as4d(t_emb), None, _SPEC1, None, need_dx=False,
-                       rows=d_h1)
+        d_a1 = self._linear_bwd('time_embedding.linear_2', d_emb, a1)
+        d_h1 = ops.silu_bwd(h1, d_a1)
+        self._linear_bwd('time_embedding.linear_1', d_h1, t_emb, need_dx=False)
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

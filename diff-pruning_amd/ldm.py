@@ -238,8 +238,8 @@ class LdmEngine(UNetEngine):
         self._ln_param_grads(tb + '.norm3', pws)
         # attn2 (context token): d o2[n, c] = sum_t dh2
         rows = ops.rowsum_nc(dh2)
-        dv2 = self._conv_bwd(tb + '.attn2.to_out.0', ops.as4d(rows), ops.as4d(v2), None, _SPEC1, (1, 1), rows=rows)
-        self._conv_bwd(tb + '.attn2.to_v', dv2, ops.as4d(ctx2d), None, _SPEC1, None, need_dx=False)
+        dv2 = self._linear_bwd(tb + '.attn2.to_out.0', rows, v2)
+        self._linear_bwd(tb + '.attn2.to_v', dv2, ctx2d, need_dx=False)
         # attn1
         do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, ai, H, W), None, _SPEC1, hw)
         do3 = do.view(N, ai, T)
@@ -365,8 +365,8 @@ class LdmEngine(UNetEngine):
                     self._conv_bwd(pre, dx, x, None, _SPEC3, None, need_dx=False)
         assert not sg
         d_emb = ops.silu_bwd(emb, d_semb)
-        d_a1 = self._conv_bwd('time_embed.2', ops.as4d(d_emb), ops.as4d(a1), None, _SPEC1, (1, 1), rows=d_emb)
-        d_h1 = ops.silu_bwd(h1, d_a1.view(d_a1.shape[0], d_a1.shape[1]))
-        self._conv_bwd('time_embed.0', ops.as4d(d_h1), ops.as4d(t_emb), None, _SPEC1, None, need_dx=False, rows=d_h1)
+        d_a1 = self._linear_bwd('time_embed.2', d_emb, a1)
+        d_h1 = ops.silu_bwd(h1, d_a1)
+        self._linear_bwd('time_embed.0', d_h1, t_emb, need_dx=False)
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

@@ -52,6 +52,8 @@ def _cg_name(p):
 def _nt_name(p):
     bn = _TILES[p.tile][1]
     straddle = bool(p.X2) and (p.g.c_split % bn) != 0
+    if p.merge:
+        return 'nt_gemm_kernel<64, 64, false, true>'
     return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if straddle else 'false')
 
 
@@ -110,7 +112,7 @@ def _conv_ksplit(p, device):
         return
     tiles = -(-p.M // 128) * -(-p.NPIX // 128)
     n_iter = p.ntaps * -(-p.C // 16)
-    s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // 8)
+    s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (8 if tiles >= 32 else 2))
     if s >= 2 and p.M >= 64:
         p.tile = 0 if p.M > 64 else 1
         p.ksplit = s
@@ -254,6 +256,11 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     assert gw.is_contiguous() and gw.numel() == Cout * Cin * taps
     ncols = Cin * taps
     P = N * Ho * Wo
+    few_in = x2 is None and taps > 1 and Cin * taps <= 64
+    few_out = (x2 is None and taps > 1 and Cout * taps <= 64 and spec.stride == 1 and not spec.ups
+               and 2 * spec.pad == spec.k - 1)
+    if WGRAD_MERGE_TAPS and (few_in or few_out):
+        return _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in)
     # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension
     # (N*Ho*Wo, up to 262144) supplies the parallelism; partial sums are reduced in a fixed order (deterministic).
     tile = 0 if Cout > 64 else 1
@@ -288,6 +295,51 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     return gw
 
 
+WGRAD_MERGE_TAPS = True
+
+
+def _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in):
+    """conv_in / conv_out weight gradients: with <= 7 channels on one side a per-tap tile would be ~3/128 full, so the
+    taps are folded into the tile columns (col = c*taps + tap).  few_in: rows = dy channels, columns gathered from x.
+    Otherwise (few output channels): rows = x channels, columns gathered from dy with mirrored taps."""
+    N, Cout, Ho, Wo = dy.shape
+    _, Cin, Hs, Ws = x.shape
+    taps = spec.k * spec.k
+    P = N * Ho * Wo
+    p = L.NtGemmParams()
+    if few_in:
+        rows, gat, M, Cg = dy, x, Cout, Cin
+        p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
+                    Cin, _chk_act(x), 0)
+        p.ldo, p.ocs, p.merge = Cin * taps, taps, 1
+    else:
+        rows, gat, M, Cg = x, dy, Cin, Cout
+        p.g = _geom(Hs, Ws, Ho, Wo, Ho, Wo, spec.k, 1, 1, spec.pad, spec.pad, 0, Cout, _chk_act(dy), 0)
+        p.ldo, p.ocs, p.merge = taps, Cin * taps, 3
+    tiles = -(-M // 64) * -(-(Cg * taps) // 64)
+    splits = max(1, min(WGRAD_BLOCKS // tiles, P // 512 if P >= 1024 else 1))
+    pps = (-(-P // splits) + 31) & ~31
+    splits = -(-P // pps)
+    p.A, p.a_bs, p.a_img_stride = _p(rows), 0, _chk_act(rows)
+    p.X1, p.X2, p.x_bs = _p(gat), None, 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(rows), _extent_bytes(gat), 0
+    p.M, p.C, p.NCOLS, p.ntaps, p.P = M, Cg, Cg * taps, taps, P
+    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, pps, 2, 0
+    p.alpha = alpha
+    n = gw.numel()
+    flops = 2.0 * Cout * Cin * taps * P
+    if splits == 1:
+        p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), flops), 'dp_nt_gemm(wgrad, merged taps)')
+    else:
+        ws = _workspace(splits * n, dy.device)
+        p.out, p.o_bs, p.accumulate = _p(ws), n, 0
+        L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), flops), 'dp_nt_gemm(wgrad, merged taps)')
+        L.check(_lib().dp_splitk_reduce(_p(ws), n, splits, _p(gw), n, 1 if accumulate else 0, _stream()),
+                'dp_splitk_reduce')
+    return gw
+
+
 # --------------------------------------------------------------------------------------------------
 # batched attention products on [B, C, T] (channel-major tokens)
 # --------------------------------------------------------------------------------------------------
@@ -295,12 +347,13 @@ def _bgeom(T, c_split):
     return _geom(1, T, 1, T, 1, T, 1, 1, 1, 0, 0, 0, c_split, 0, 0)
 
 
-def bmm_tn(a, b, alpha=1.0, out=None):
+def bmm_tn(a, b, alpha=1.0, out=None, accumulate=False):
     """out[z, m, n] = alpha * sum_k a[z, k, m] * b[z, k, n]      (QK^T: a=Q, b=K;  dP: a=dO, b=V)"""
     Z, K, M = a.shape
     _, K2, Nn = b.shape
     assert K2 == K and a.is_contiguous() and b.is_contiguous() and M % 4 == 0
     if out is None:
+        assert not accumulate
         out = torch.empty((Z, M, Nn), dtype=_f32, device=a.device)
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(a), K * M, M, 0
@@ -310,17 +363,20 @@ def bmm_tn(a, b, alpha=1.0, out=None):
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
-    p.alpha, p.post_scale = alpha, 1.0
+    p.alpha, p.post_scale, p.accumulate = alpha, 1.0, 1 if accumulate else 0
+    if Z == 1:
+        _conv_ksplit(p, a.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * Z * M * Nn * K), 'dp_conv_gemm(bmm_tn)')
     return out
 
 
-def bmm_nn(a, b, alpha=1.0, out=None):
+def bmm_nn(a, b, alpha=1.0, out=None, accumulate=False):
     """out[z, m, n] = alpha * sum_k a[z, m, k] * b[z, k, n]      (dV: a=dO, b=P;  dK: a=Q, b=dS)"""
     Z, M, K = a.shape
     _, K2, Nn = b.shape
     assert K2 == K and a.is_contiguous() and b.is_contiguous()
     if out is None:
+        assert not accumulate
         out = torch.empty((Z, M, Nn), dtype=_f32, device=a.device)
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(a), M * K, K, 1
@@ -330,13 +386,15 @@ def bmm_nn(a, b, alpha=1.0, out=None):
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
-    p.alpha, p.post_scale = alpha, 1.0
+    p.alpha, p.post_scale, p.accumulate = alpha, 1.0, 1 if accumulate else 0
+    if Z == 1:
+        _conv_ksplit(p, a.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * Z * M * Nn * K), 'dp_conv_gemm(bmm_nn)')
     return out
 
 
-def bmm_nt(a, b, alpha=1.0, out=None):
-    """out[z, m, n] = alpha * sum_k a[z, m, k] * b[z, n, k]      (P.V: a=V, b=P;  dQ: a=K, b=dS)"""
+def bmm_nt(a, b, alpha=1.0, out=None, col_bias=None):
+    """out[z, m, n] = alpha * sum_k a[z, m, k] * b[z, n, k] (+ col_bias[n])      (P.V: a=V, b=P;  dQ: a=K, b=dS)"""
     Z, M, K = a.shape
     _, Nn, K2 = b.shape
     assert K2 == K and a.is_contiguous() and b.is_contiguous()
@@ -351,9 +409,56 @@ def bmm_nt(a, b, alpha=1.0, out=None):
     p.batches, p.splits, p.p_per_split, p.batched = Z, 1, 0, 1
     p.tile = pick_tile(M, Nn, Z)
     p.out, p.o_bs, p.ldo, p.accumulate = _p(out), M * Nn, Nn, 0
-    p.alpha = alpha
+    p.alpha, p.col_bias = alpha, _p(col_bias)
     L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * Z * M * Nn * K), 'dp_nt_gemm(bmm_nt)')
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# nn.Linear on [N, C] rows (time embedding, time_emb_proj, single-token cross-attention).  x, W, dy are all row-major,
+# so each of the three products has a form whose tile loads are contiguous: forward = NT, dgrad = NN, wgrad = TN.
+# --------------------------------------------------------------------------------------------------
+def linear_forward(x, w, bias=None):
+    """y[n, o] = sum_i x[n, i] * w[o, i] + bias[o]"""
+    N, K = x.shape
+    Co = w.shape[0]
+    tile = pick_tile(N, Co, 1)
+    bm, bn, _ = _TILES[tile]
+    splits = min(8, K // 64)
+    if splits < 2 or -(-N // bm) * -(-Co // bn) >= 128:
+        return bmm_nt(x.unsqueeze(0), w.unsqueeze(0), col_bias=bias)[0]
+    # a handful of tiles with a long K loop is latency bound: split K over workgroups (partials reduced in fixed order)
+    assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    out = torch.empty((N, Co), dtype=_f32, device=x.device)
+    pps = (-(-K // splits) + 31) & ~31
+    splits = -(-K // pps)
+    p = L.NtGemmParams()
+    p.A, p.a_bs, p.a_img_stride = _p(x), 0, 0
+    p.X1, p.X2, p.x_bs = _p(w), None, 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = N * K * 4, Co * K * 4, 0
+    p.g = _bgeom(K, Co)
+    p.M, p.C, p.NCOLS, p.ntaps, p.P = N, Co, Co, 1, K
+    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, pps, tile, 0
+    p.alpha, p.col_bias, p.ldo = 1.0, _p(bias), Co
+    ws = _workspace(splits * N * Co, x.device)
+    p.out, p.o_bs, p.accumulate = _p(ws), N * Co, 0
+    L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * N * Co * K), 'dp_nt_gemm(linear)')
+    L.check(_lib().dp_splitk_reduce(_p(ws), N * Co, splits, _p(out), N * Co, 0, _stream()), 'dp_splitk_reduce')
+    return out
+
+
+def linear_dgrad(dy, w, out=None, accumulate=False):
+    """dx[n, i] (+)= sum_o dy[n, o] * w[o, i]"""
+    r = bmm_nn(dy.unsqueeze(0), w.unsqueeze(0), out=None if out is None else out.unsqueeze(0), accumulate=accumulate)
+    return r[0]
+
+
+def linear_wgrad(dy, x, gw, alpha=1.0, accumulate=True):
+    """gw[o, i] (+)= alpha * sum_n dy[n, o] * x[n, i]"""
+    if dy.shape[1] % 4:          # 16-byte operand rows needed by the m-contiguous A loader: odd pruned widths
+        return conv_wgrad(as4d(dy), as4d(x), None, gw, ConvSpec(1, 1, 0, 0), alpha=alpha, accumulate=accumulate)
+    bmm_tn(dy.unsqueeze(0), x.unsqueeze(0), alpha=alpha, out=gw.unsqueeze(0), accumulate=accumulate)
+    return gw
 
 
 # --------------------------------------------------------------------------------------------------

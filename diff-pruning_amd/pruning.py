@@ -25,9 +25,25 @@ from .graph import UNetGraph, LdmGraph, ChannelView, coupled_members, all_groups
 # --------------------------------------------------------------------------------------------------------
 # pruning functions (function.py:85-146, 168-207, 274-302): slice weights AND their accumulated grads
 # --------------------------------------------------------------------------------------------------------
+_index_cache = {}
+
+
+def _index_tensor(key, build, device):
+    """Small host->device index vectors recur across the members of one group (same channel count, same dropped
+    set): build and upload each once.  The cache is bounded and only ever holds immutable index tensors."""
+    k = (key, str(device))
+    t = _index_cache.get(k)
+    if t is None:
+        if len(_index_cache) > 256:
+            _index_cache.clear()
+        t = torch.tensor(build(), dtype=torch.long, device=device)
+        _index_cache[k] = t
+    return t
+
+
 def _keep(n, idxs, device):
-    drop = set(int(i) for i in idxs)
-    return torch.tensor([i for i in range(n) if i not in drop], dtype=torch.long, device=device)
+    drop = frozenset(int(i) for i in idxs)
+    return _index_tensor(('keep', n, drop), lambda: [i for i in range(n) if i not in drop], device)
 
 
 def _slice_param(layer, attr, dim, keep):
@@ -262,7 +278,7 @@ class TaylorImportance(Importance):
             if n_full == n0 and idxs[0] == 0 and idxs[-1] == n0 - 1:
                 ops.axpby(full, 1.0, score, 1.0)
             else:
-                ops.gather_add(full, torch.tensor(idxs, dtype=torch.long, device=dev), score)
+                ops.gather_add(full, _index_tensor(('idx', tuple(idxs)), lambda: idxs, dev), score)
             used += 1
         if self.multivariable is not None:
             if self.group_reduction == 'mean':
@@ -447,10 +463,8 @@ class MetaPruner:
             if ch_groups > 1:
                 gs = cur // ch_groups
                 per = n_pruned // ch_groups
-                parts = []
-                for c in range(ch_groups):
-                    parts.append(torch.argsort(imp_host[c * gs:(c + 1) * gs])[:per] + c * gs)
-                idxs = torch.cat(parts, 0)
+                order = torch.argsort(imp_host[:gs * ch_groups].view(ch_groups, gs), dim=1)[:, :per]
+                idxs = (order + torch.arange(ch_groups).view(-1, 1) * gs).reshape(-1)
             else:
                 idxs = torch.argsort(imp_host)[:(n_pruned // ch_groups)]
             idxs = idxs.tolist()

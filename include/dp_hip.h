@@ -58,7 +58,11 @@ int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
  * A element (m, pix=(img,r)) at A + z*a_bs + img*a_img_stride + m*HoWo + r;  NCOLS = number of channels c.
  * batched = 1: blockIdx.z = batch, output out[z*o_bs + m*ldo + c]  (ntaps must be 1);
  * batched = 0: blockIdx.z = split*ntaps + tap, partial sums to out[split*o_bs + m*ldo + c*ntaps + tap]
- *              (reduce with dp_splitk_reduce), or direct (+accumulate) when splits == 1. */
+ *              (reduce with dp_splitk_reduce), or direct (+accumulate) when splits == 1.
+ * merge != 0 (few channels on one side, conv_in / conv_out): one tile holds all C*ntaps columns; with bit 1 the plain
+ *              rows are the layer INPUT and the gathered operand is dy with mirrored taps (stride-1 'same' convs only).
+ * nn.Linear forward y[n][o] = sum_i x[n][i] W[o][i] + b[o] (embeddings.py:192-212, resnet.py:611) is the batched form
+ * with one batch: A = x, X1 = W (both row-major, reduction index contiguous), col_bias = b. */
 typedef struct dp_nt_gemm_params {
     const float* A; long long a_bs; long long a_img_stride;
     const float* X1; const float* X2; long long x_bs;
@@ -66,7 +70,9 @@ typedef struct dp_nt_gemm_params {
     dp_conv_geom g;
     int M, C, NCOLS, ntaps, P, batches, splits, p_per_split, tile, batched;   /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
     float* out; long long o_bs; int ldo; int accumulate;
-    float alpha; int _pad;
+    float alpha; int merge;                /* merge: bit 0 = taps folded into the columns (NCOLS = C*ntaps), bit 1 = mirrored taps */
+    long long ocs;                         /* merge: output element (row, c, tap) at row*ldo + c*ocs + tap */
+    const float* col_bias;                 /* optional [NCOLS]: added per output column by split 0 (nn.Linear bias), or NULL */
 } dp_nt_gemm_params;
 int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
 

@@ -88,6 +88,24 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     return gw
 
 
+def linear_forward(x, w, bias=None):
+    return F.linear(x, w, bias)
+
+
+def linear_dgrad(dy, w, out=None, accumulate=False):
+    r = dy @ w
+    if out is None:
+        return r
+    out.copy_(out + r if accumulate else r)
+    return out
+
+
+def linear_wgrad(dy, x, gw, alpha=1.0, accumulate=True):
+    r = alpha * (dy.t() @ x)
+    gw.copy_(gw + r if accumulate else r)
+    return gw
+
+
 def bmm_tn(a, b, alpha=1.0, out=None):
     r = alpha * torch.bmm(a.transpose(1, 2), b)
     if out is not None:

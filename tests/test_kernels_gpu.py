@@ -59,6 +59,9 @@ CONV_CASES = [
     ('s2_sym', 2, 24, 0, 40, 16, 3, 2, 1, 0),
     ('ups', 2, 24, 0, 40, 8, 3, 1, 1, 1),
     ('linear', 7, 100, 0, 90, 1, 1, 1, 0, 0),
+    ('in4_s2_asym', 3, 4, 0, 40, 16, 3, 2, 0, 0),
+    ('in3_ups', 2, 3, 0, 40, 8, 3, 1, 1, 1),
+    ('out7_odd', 3, 50, 0, 7, 12, 3, 1, 1, 0),
 ]
 
 
@@ -117,6 +120,27 @@ def test_conv_forward_dgrad_wgrad(ops, report, case):
     e_w2 = relerr(gw2, w.double().cpu() + 0.5 * wr.grad)
     report['conv/' + name] = dict(fwd=e_f, epilogue=e_ep, acc=e_acc, dgrad=e_d, wgrad=e_w, wgrad_acc=e_w2)
     assert max(e_f, e_ep, e_acc, e_d, e_w, e_w2) < 2e-5, report['conv/' + name]
+
+
+@pytest.mark.parametrize('shape', [(7, 100, 90), (256, 512, 256), (33, 37, 92), (5, 16, 3)], ids=str)
+def test_linear_fwd_dgrad_wgrad(ops, report, shape):
+    """nn.Linear on row-major [N, C]: NT forward (+bias), NN dgrad (+accumulate), TN wgrad (+accumulate, odd widths)."""
+    N, Ci, Co = shape
+    x, w, b, dy = rnd(N, Ci, seed=1), rnd(Co, Ci, seed=2, scale=Ci ** -0.5), rnd(Co, seed=3), rnd(N, Co, seed=4)
+    xd, wd, bd, dyd = (t.double().cpu() for t in (x, w, b, dy))
+    e_f = relerr(ops.linear_forward(x, w, b), xd @ wd.t() + bd)
+    e_f0 = relerr(ops.linear_forward(x, w, None), xd @ wd.t())
+    dx0 = rnd(N, Ci, seed=5)
+    dx = dx0.clone()
+    ops.linear_dgrad(dy, w, out=dx, accumulate=True)
+    e_d = relerr(dx, dx0.double().cpu() + dyd @ wd)
+    e_d0 = relerr(ops.linear_dgrad(dy, w), dyd @ wd)
+    gw0 = rnd(Co, Ci, seed=6)
+    gw = gw0.clone()
+    ops.linear_wgrad(dy, x, gw, accumulate=True)
+    e_w = relerr(gw, gw0.double().cpu() + dyd.t() @ xd)
+    report['linear/%dx%dx%d' % shape] = dict(fwd=e_f, fwd_nobias=e_f0, dgrad_acc=e_d, dgrad=e_d0, wgrad_acc=e_w)
+    assert max(e_f, e_f0, e_d, e_d0, e_w) < 2e-5
 
 
 def test_conv_fwd_dgrad_splitk(ops, report, monkeypatch):

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Per-shape table of the contraction launches in one sweep timestep (HIP events on the launch stream):
+which layer shapes lose the most time against a target rate.   python tools/profile_shapes.py [--batch 256]"""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import golden_common as gc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--target', type=float, default=125.0, help='TFLOP/s the "lost ms" column is priced against')
+args = ap.parse_args()
+ops = importlib.import_module('diff-pruning_amd.ops')
+unet = importlib.import_module('diff-pruning_amd.unet')
+diffusion = importlib.import_module('diff-pruning_amd.diffusion')
+sweep = importlib.import_module('diff-pruning_amd.sweep')
+cg, nt = ops._cg_name, ops._nt_name
+ops._cg_name = lambda p: 'cg M=%d C=%d N=%d taps=%d ks=%d z=%d' % (p.M, p.C, p.NPIX, p.ntaps, p.ksplit, p.batches)
+ops._nt_name = lambda p: 'nt M=%d NC=%d P=%d taps=%d sp=%d z=%d' % (p.M, p.NCOLS, p.P, p.ntaps, p.splits, p.batches)
+dev = torch.device('cuda')
+B = args.batch
+model = unet.UNet2DModel(**gc.CIFAR_CFG)
+gc.det_init_(model, 0)
+model = model.to(dev).eval()
+clean = torch.from_numpy(gc.det_clean((B, 3, 32, 32), 1)).to(dev)
+noise = torch.from_numpy(gc.det_noise((B, 3, 32, 32), 2)).to(dev)
+sweep.flatten_grads(model)
+step = sweep.HipSweepStep(model, diffusion.DDPMScheduler(), clean, noise, B * 3072, 'mse', B)
+step(0); step(1)
+torch.cuda.synchronize()
+agg = {}
+for rep in range(3):
+    ops._prof = []
+    step(2 + rep)
+    torch.cuda.synchronize()
+    log, ops._prof = ops._prof, None
+    for name, fl, st, en, ab in log:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += fl; a[2] += st.elapsed_time(en) * 1e-3
+rows = []
+for n, (c, fl, s) in agg.items():
+    lost = (s - fl / (args.target * 1e12)) / 3 * 1e3
+    rows.append((lost, n, c // 3, fl / s / 1e12, s / 3 * 1e3))
+rows.sort(reverse=True)
+print('%-52s %4s %8s %8s %8s' % ('shape', 'n', 'TFLOP/s', 'ms/step', 'lost ms'))
+for lost, n, c, tf, ms in rows[:45]:
+    print('%-52s %4d %8.1f %8.3f %8.3f' % (n, c, tf, ms, lost))
+print('total contraction ms/step %.2f, lost vs %.0f TF: %.2f' % (sum(r[4] for r in rows), args.target, sum(r[0] for r in rows)))
