@@ -3,5 +3,7 @@
 set -e
 cd "$(dirname "$0")/diff-pruning_amd"
 SRCS="csrc/gemm.hip csrc/norm.hip csrc/elementwise.hip csrc/importance.hip csrc/optim.hip csrc/transformer.hip"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I../include -o libdp_hip.so $SRCS
-echo "built $(pwd)/libdp_hip.so"
+# DP_EXTRA_FLAGS / DP_OUT: experiment builds (e.g. DP_EXTRA_FLAGS=-DDP_SCHED_PIPE DP_OUT=libdp_hip_exp.so, run with DP_HIP_LIB=...)
+OUT="${DP_OUT:-libdp_hip.so}"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I../include $DP_EXTRA_FLAGS -o "$OUT" $SRCS
+echo "built $(pwd)/$OUT"

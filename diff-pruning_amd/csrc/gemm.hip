@@ -9,6 +9,7 @@
 // to the other LDS buffer afterwards.  LDS images are laid out so that every ds_read_b32 /
 // ds_write_b32 lane group touches 32 distinct banks ([k][m] for m-contiguous operands, [m][BK+1]
 // for k-contiguous ones).
+#include <cstdlib>
 #include "dp_common.h"
 
 // Global -> LDS DMA for the lane-linear tiles of conv_gemm (A/B: same speed on the large shapes, +4..8 % on the 8x8 / 4x4
@@ -90,15 +91,84 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
     for (int ks = 0; ks < BK / 2; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < BK / 2) frag(ks + 1, a[cur ^ 1], b[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);      // keep the next k-step's LDS reads ahead of this k-step's MFMAs
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef DP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+}
+
+// Experiment knob: extra (unused) dynamic LDS per workgroup, to cap the workgroups resident per CU (DP_LDS_PAD bytes).
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the conv_gemm kernels.  C/D map of a 32x32 MFMA tile: col j = lane&31,
+// row i = (r&3) + 8*(r>>2) + 4*(lane>>5).  Sub-tile (tm, tn) of this wave starts at (row0 + tm*TMS, col0 + tn*TNS).
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int TMS, int TNS>
+__device__ __forceinline__ void conv_epilogue(const dp_conv_gemm_params& p, const f32x16 (&acc)[TM][TN], int row0, int col0,
+                                              int lane, int z, bool ksplit) {
+    const int HoWo = p.g.Ho * p.g.Wo;
+    if (ksplit) {
+        float* __restrict__ wsb = p.ws + (long long)z * p.M * p.NPIX;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int pix = col0 + tn * TNS + (lane & 31);
+            if (pix >= p.NPIX) continue;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = row0 + tm * TMS + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M) wsb[(long long)m * p.NPIX + pix] = acc[tm][tn][r];
+                }
+        }
+        return;
+    }
+    float* __restrict__ outb = p.out + (long long)z * p.o_bs;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pix = col0 + tn * TNS + (lane & 31);
+        if (pix >= p.NPIX) continue;
+        const int img = pix / HoWo;
+        const int r_in = pix - img * HoWo;
+        const long long obase = (long long)img * p.o_img_stride + r_in;
+        const long long rbase = (long long)img * p.r_img_stride + r_in;
+        const long long tbase = (long long)img * p.tadd_stride;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = row0 + tm * TMS + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[tm][tn][r];
+                if (p.bias) v += p.bias[m];
+                if (p.tadd) v += p.tadd[tbase + m];
+                if (p.res) v += p.res[rbase + (long long)m * HoWo];
+                v *= p.post_scale;
+                float* o = outb + obase + (long long)m * HoWo;
+                if (p.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+#ifdef DP_CLOCK_PROBE
+// Experiment build only: shader-clock / 100 MHz wall-clock ticks spent by workgroup (0,0,0) of the last conv_gemm launch.
+__device__ unsigned long long dp_clk[2];
+extern "C" int dp_debug_read_clock(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dp_clk), 16);
+}
+#endif
+
+static unsigned dp_lds_pad() {
+    static const unsigned pad = [] { const char* e = getenv("DP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    return pad;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -302,6 +372,9 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
         for (int j = 0; j < NB; ++j) Bs[(bk0 + BROWS * j) * BN + bn] = rb[j];
     };
 
+#ifdef DP_CLOCK_PROBE
+    const unsigned long long clk0 = clock64(), wclk0 = wall_clock64();
+#endif
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -343,62 +416,219 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     }
 
     // ---- epilogue.  C/D map of the 32x32 tile: col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    if (ksplit) {
-        float* __restrict__ wsb = p.ws + (long long)z * p.M * p.NPIX;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int pix = n0 + wn0 + tn * 32 + (lane & 31);
-            if (pix >= p.NPIX) continue;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < p.M) wsb[(long long)m * p.NPIX + pix] = acc[tm][tn][r];
-                }
-        }
-        return;
+#ifdef DP_CLOCK_PROBE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        dp_clk[0] = clock64() - clk0;
+        dp_clk[1] = wall_clock64() - wclk0;
     }
-    float* __restrict__ outb = p.out + (long long)z * p.o_bs;
+#endif
+    conv_epilogue<TM, TN, 32, 32>(p, acc, m0 + wm0, n0 + wn0, lane, z, ksplit);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_fast: the stride-1 / no-upsample / channels % 16 == 0 case (every resnet 3x3, shortcut, attention
+// projection and their dgrads; > 95 % of the conv_gemm time), 128x128 tile, same math and K order as conv_gemm_kernel.
+// Plain VALU instructions are not free next to the matrix pipe (tools/probe/mfma_valu.hip: ~1.7 cycles each, the
+// general loader spends ~100 per K tile = -9 %), so everything per-lane is hoisted out of the K loop:
+//   * A: two constant per-lane byte offsets; the K-tile row offset goes in the buffer instruction's scalar offset.
+//   * B: eight constant per-lane byte offsets (8 channels of one pixel); channel chunk and kernel tap move the SCALAR
+//        offset ((c0*HW + ky*Ws + kx)*4, the descriptor base is shifted back by the padding so it is never negative);
+//        zero padding = one precomputed tap-validity bit mask per lane -> 1 and + 1 cmp + 8 cndmask per K tile.
+//   * LDS destinations (M0) are scalar; fragment reads use the interleaved wave tile (sub-tiles 64 apart), whose
+//     k-step / sub-tile offsets all fit ds_read2st64_b32 immediates -> one address VGPR per operand.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
+    static_assert(BM == 128 && BN == 128, "fast path is tuned for the 128x128 tile");
+    constexpr int BK = 16;
+    constexpr int TM = 2, TN = 2;
+    constexpr int A_SZ = BK * BM;
+    constexpr int B_SZ = BK * BN;
+    constexpr int STAGE = A_SZ + B_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+
+    const ConvGeom& g = p.g;
+    const int HoWo = g.Ho * g.Wo;
+    const int HsWs = g.Hs * g.Ws;
+    const int C = p.C;
+    const int ntaps = p.ntaps;
+    const int nch = C / BK;
+    const int nIterAll = ntaps * nch;
+    const bool ksplit = p.ksplit > 1;
+    const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
+    const int it0 = ksplit ? z * per : 0;
+    const int nIter = ksplit ? max(0, min(per, nIterAll - it0)) : nIterAll;
+    const int zb = ksplit ? 0 : z;
+
+    const float* __restrict__ Ab = p.A + (long long)zb * p.a_bs;
+    const float* __restrict__ X1 = p.X1 + (long long)zb * p.x_bs;
+    const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)zb * p.x_bs : X1;
+    const int shift = g.pad_t * g.Ws + g.pad_l;                  // descriptor bases moved back by the padding
+    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(Ab, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t r1 = dp_rsrc(X1 - shift, p.x1_bytes + 4u * (unsigned)shift);
+    const __amdgpu_buffer_rsrc_t r2 = dp_rsrc(X2 - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
+    const int ch_split = p.X2 ? g.c_split / BK : nch;            // chunks [0, ch_split) come from X1
+
+    // ---- per-lane constants
+    // A: element e = tid + 256*j of the [16][128] tile, 4 floats each: row k = e/32, column 4*(e%32)
+    unsigned a_voff[2];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int pix = n0 + wn0 + tn * 32 + (lane & 31);
-        if (pix >= p.NPIX) continue;
-        const int img = pix / HoWo;
-        const int r_in = pix - img * HoWo;
-        const long long obase = (long long)img * p.o_img_stride + r_in;
-        const long long rbase = (long long)img * p.r_img_stride + r_in;
-        const long long tbase = (long long)img * p.tadd_stride;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = p.alpha * acc[tm][tn][r];
-                if (p.bias) v += p.bias[m];
-                if (p.tadd) v += p.tadd[tbase + m];
-                if (p.res) v += p.res[rbase + (long long)m * HoWo];
-                v *= p.post_scale;
-                float* o = outb + obase + (long long)m * HoWo;
-                if (p.accumulate) v += *o;
-                *o = v;
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + 256 * j;
+        const int k = e >> 5;
+        const int m = m0 + 4 * (e & 31);
+        a_voff[j] = (m < p.lda) ? (unsigned)((k * p.lda + m) * 4) : DP_OOB;
+    }
+    const unsigned a_row_bytes = (unsigned)p.lda * 4u;
+    // B: pixel column bn, rows bk0 + 2*j
+    const int bn = tid & (BN - 1);
+    const int bk0 = tid >> 7;
+    const int bpix = n0 + bn;
+    const bool bpv = bpix < p.NPIX;
+    unsigned b_pix1, b_pix2, vmask = 0;
+    {
+        const int pp = bpv ? bpix : 0;
+        const int img = pp / HoWo;
+        const int r = pp - img * HoWo;
+        const int ho = r / g.Wo;
+        const int wo = r - ho * g.Wo;
+        const unsigned lin = (unsigned)(ho * g.Ws + wo + bk0 * HsWs);
+        b_pix1 = (unsigned)((long long)img * g.x1_img_stride) + lin;
+        b_pix2 = (unsigned)((long long)img * g.x2_img_stride) + lin;
+        if (bpv)
+            for (int t = 0; t < ntaps; ++t) {
+                const int ky = t / g.kw;
+                int off;
+                if (dp_gather(g, ho, wo, ky, t - ky * g.kw, off)) vmask |= 1u << t;
             }
+    }
+    unsigned b_voff[8];
+    auto set_source = [&](bool first) {
+        const unsigned b = first ? b_pix1 : b_pix2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b_voff[j] = (b + (unsigned)(2 * j * HsWs)) * 4u;
+    };
+
+    // ---- scalar K-tile state: chunk ch (16 channels), tap (ky, kx)
+    int ch = it0 / ntaps;
+    int tap = it0 - ch * ntaps;
+    int ky = tap / g.kw;
+    int kx = tap - ky * g.kw;
+    bool first = ch < ch_split;
+    set_source(first);
+
+    float* const ldsA = smem + 4 * (wave * 64);                 // + buf*STAGE + 1024*j   (float4 per lane)
+    float* const ldsB = smem + A_SZ + bk0 * 0 + (wave & 1) * 64 + (wave >> 1) * BN;   // row bk0 = wave>>1, cols (wave&1)*64..
+
+    auto dma_tile = [&](int buf) {
+        float* As = ldsA + buf * STAGE;
+        float* Bs = ldsB + buf * STAGE;
+        const unsigned a_soff = (unsigned)(tap * C + ch * BK) * a_row_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = a_voff[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
+        }
+        const unsigned b_soff = (unsigned)(((first ? ch : ch - ch_split) * BK) * HsWs + ky * g.Ws + kx) * 4u;
+        const bool tv = (vmask >> tap) & 1u;
+        const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned o = tv ? b_voff[j] : DP_OOB;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(Bs + 2 * j * BN), 4, (int)o, (int)b_soff, 0, 0);
+        }
+    };
+    auto advance = [&]() {                                       // next K tile (chunk outer, tap inner)
+        ++tap; ++kx;
+        if (kx == g.kw) { kx = 0; ++ky; }
+        if (tap == ntaps) {
+            tap = 0; ky = 0; kx = 0; ++ch;
+            if (first && ch >= ch_split && ch < nch) { first = false; set_source(false); }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int li = lane & 31, lk = lane >> 5;
+    const float* fragA = smem + lk * BM + wr * 32 + li;
+    const float* fragB = smem + A_SZ + lk * BN + wc * 32 + li;
+
+    if (nIter > 0) {
+        dma_tile(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < nIter; ++it) {
+            const int buf = it & 1;
+            // prefetch of tile it+1 (on the last iteration the current tile again: harmless, no predicate needed)
+            if (it + 1 < nIter) advance();
+            dma_tile(buf ^ 1);
+            const float* Af = fragA + buf * STAGE;
+            const float* Bf = fragB + buf * STAGE;
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { a[0][t] = Af[64 * t]; b[0][t] = Bf[64 * t]; }
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < BK / 2) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        a[cur ^ 1][t] = Af[(ks + 1) * 2 * BM + 64 * t];
+                        b[cur ^ 1][t] = Bf[(ks + 1) * 2 * BN + 64 * t];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
     }
+    conv_epilogue<TM, TN, 64, 64>(p, acc, m0 + wr * 32, n0 + wc * 32, lane, z, ksplit);
 }
 
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
+    if constexpr (BM == 128 && BN == 128) {
+        static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
+        const dp_conv_geom& g = p.g;
+        if (!no_fast && !p.a_kc && g.stride == 1 && g.sden == 1 && g.ups == 0 && (p.C % 16) == 0 && p.ntaps <= 32 &&
+            (!p.X2 || (g.c_split % 16) == 0) && g.Hs == g.Hv && g.Ws == g.Wv) {
+            hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128>), grid, dim3(256), dp_lds_pad(), st, p);
+            return DP_LAUNCH_CHECK();
+        }
+    }
     // a K-chunk of 16 channels can straddle the concat boundary only when c_split is not a multiple of 16
     const bool straddle = p.X2 != nullptr && (p.g.c_split % 16) != 0;
     if (p.a_kc) {
-        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, p);
-        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, p);
+        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, true>), grid, dim3(256), dp_lds_pad(), st, p);
+        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, false>), grid, dim3(256), dp_lds_pad(), st, p);
     } else {
-        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, p);
-        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, p);
+        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
+        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, false>), grid, dim3(256), dp_lds_pad(), st, p);
     }
     return DP_LAUNCH_CHECK();
 }
@@ -629,8 +859,8 @@ static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
     const int gz = p.batched ? p.batches : p.splits * p.ntaps;
     dim3 grid((p.NCOLS + BN - 1) / BN, (p.M + BM - 1) / BM, gz > 0 ? gz : 1);
     const bool straddle = p.X2 != nullptr && (p.g.c_split % BN) != 0;     // an N-tile may span both concat sources
-    if (straddle) hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), 0, st, p);
-    else          hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), 0, st, p);
+    if (straddle) hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), dp_lds_pad(), st, p);
+    else          hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), dp_lds_pad(), st, p);
     return DP_LAUNCH_CHECK();
 }
 
@@ -642,7 +872,7 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
     if (p.merge) {               // NCOLS = C*ntaps merged columns, one source, 64x64 tiles, blockIdx.z = split
         if (p.batched || p.X2 || p.splits <= 0) return (int)hipErrorInvalidValue;
         dim3 grid((p.NCOLS + 63) / 64, (p.M + 63) / 64, p.splits);
-        hipLaunchKernelGGL((nt_gemm_kernel<64, 64, false, true>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((nt_gemm_kernel<64, 64, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
         return DP_LAUNCH_CHECK();
     }
     switch (p.tile) {

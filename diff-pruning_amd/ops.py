@@ -6,6 +6,7 @@ contiguous (stride(1) == H*W) while stride(0) -- the image stride -- is free, so
 larger buffer are passed without copies.
 """
 import ctypes as C
+import os
 import math
 import torch
 
@@ -44,6 +45,10 @@ def _run(call, name, flops, abytes=0.0):
 
 
 def _cg_name(p):
+    g = p.g
+    if (p.tile == 0 and not p.a_kc and g.stride == 1 and g.sden == 1 and g.ups == 0 and p.C % 16 == 0 and p.ntaps <= 32
+            and (not p.X2 or g.c_split % 16 == 0) and g.Hs == g.Hv and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST')):
+        return 'conv_gemm_fast_kernel<128, 128>'        # same dispatch rule as launch_conv_gemm (csrc/gemm.hip)
     straddle = bool(p.X2) and (p.g.c_split % 16) != 0
     return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[p.tile], 'true' if p.a_kc else 'false',
                                              'true' if straddle else 'false')

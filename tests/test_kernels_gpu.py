@@ -62,6 +62,10 @@ CONV_CASES = [
     ('in4_s2_asym', 3, 4, 0, 40, 16, 3, 2, 0, 0),
     ('in3_ups', 2, 3, 0, 40, 8, 3, 1, 1, 1),
     ('out7_odd', 3, 50, 0, 7, 12, 3, 1, 1, 0),
+    ('fast_sq', 3, 128, 0, 128, 8, 3, 1, 1, 0),
+    ('fast_cat', 2, 64, 32, 144, 16, 3, 1, 1, 0),
+    ('fast_1x1_cat', 5, 32, 48, 96, 12, 1, 1, 0, 0),
+    ('fast_tail', 3, 80, 0, 200, 10, 3, 1, 1, 0),
 ]
 
 
