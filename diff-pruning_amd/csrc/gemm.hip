@@ -854,11 +854,176 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// nt_gemm_fast: weight gradients of the stride-1 convolutions whose pixel rows are powers of two (every CIFAR / LSUN /
+// LDM resnet and attention layer), 128x128 tile, same math, split-K ranges and summation order as nt_gemm_kernel.
+// A K tile = 16 consecutive pixels of one image (HoWo % 16 == 0), so image / row / column of the tile are scalars and a
+// lane's pixel is (ho0 + lk / Wo, wo0 + lk % Wo) with lane-constant second terms:
+//   * 8 + 8 constant per-lane byte offsets (4 rows x 16 pixels per DMA instruction), tile position in the scalar offset;
+//   * zero padding: 2 adds + 2 unsigned compares per K tile, then 8 cndmask on the gathered operand only;
+//   * global -> LDS DMA into a [row/4][4 rows x 16 pixels + 1 pad dword] image: each instruction writes 64 consecutive
+//     dwords, the pad dword per 4-row group makes the 32-lane fragment reads hit 32 distinct banks, and the k-step
+//     offsets are ds_read immediates (no address arithmetic, no register staging, no ds_write).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_params p) {
+    constexpr int BM = 128, BN = 128, BK = 16;
+    constexpr int TM = 2, TN = 2;
+    constexpr int GRP = 4 * BK + 1;                 // dwords per 4-row group
+    constexpr int OP_SZ = (BM / 4) * GRP;           // 2080 dwords per operand tile
+    constexpr int STAGE = 2 * OP_SZ;
+    __shared__ float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+
+    const ConvGeom& g = p.g;
+    const int HoWo = g.Ho * g.Wo;
+    const int HsWs = g.Hs * g.Ws;
+    const int split = z / p.ntaps;
+    const int tap = z - split * p.ntaps;
+    const int ky = tap / g.kw;
+    const int kx = tap - ky * g.kw;
+    const int p_begin = split * p.p_per_split;
+    const int p_end = min(p_begin + p.p_per_split, p.P);
+    const int nIter = (p_end > p_begin) ? (p_end - p_begin) / BK : 0;
+
+    const bool first_src = (!p.X2) || n0 < g.c_split;
+    const float* __restrict__ Xs = first_src ? p.X1 : p.X2;
+    const int cofs = first_src ? 0 : g.c_split;
+    const long long xs_img = first_src ? g.x1_img_stride : g.x2_img_stride;
+    const int shift = g.pad_t * g.Ws + g.pad_l;
+    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rB = dp_rsrc(Xs - shift, (first_src ? p.x1_bytes : p.x2_bytes) + 4u * (unsigned)shift);
+
+    // ---- per-lane constants: pixel lk of the K tile, row sub of each 4-row group; this wave owns groups wave*8 .. +7
+    const int lk = lane & 15, sub = lane >> 4;
+    const int dho = lk / g.Wo, wol = lk - dho * g.Wo;
+    const int hc = dho + ky - g.pad_t;
+    const int wc = wol + kx - g.pad_l;
+    unsigned a_voff[8], b_voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = 4 * (wave * 8 + j) + sub;
+        const int m = m0 + row;
+        a_voff[j] = (m < p.M) ? (unsigned)((m * HoWo + lk) * 4) : DP_OOB;
+        const int c = n0 + row;
+        b_voff[j] = (c < p.NCOLS) ? (unsigned)(((c - cofs) * HsWs + (dho + ky) * g.Ws + wol + kx) * 4) : DP_OOB;
+    }
+    float* const ldsW = smem + wave * 8 * GRP;      // this wave's first group, operand A of stage 0
+
+    auto dma_tile = [&](int it, int buf) {
+        const int pp0 = p_begin + it * BK;
+        const int img = pp0 / HoWo;
+        const int r0 = pp0 - img * HoWo;
+        const int ho0 = r0 / g.Wo;
+        const int wo0 = r0 - ho0 * g.Wo;
+        const unsigned a_soff = (unsigned)((long long)img * p.a_img_stride + r0) * 4u;
+        const unsigned b_soff = (unsigned)((long long)img * xs_img + ho0 * g.Ws + wo0) * 4u;
+        const bool v = ((unsigned)(ho0 + hc) < (unsigned)g.Hs) && ((unsigned)(wo0 + wc) < (unsigned)g.Ws);
+        float* As = ldsW + buf * STAGE;
+        float* Bs = As + OP_SZ;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned o = a_voff[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + j * GRP), 4, (int)o, (int)a_soff, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned o = v ? b_voff[j] : DP_OOB;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (dp_lds_void*)(Bs + j * GRP), 4, (int)o, (int)b_soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int li = lane & 31, lkk = lane >> 5;
+    auto rowoff = [](int row) { return (row >> 2) * GRP + (row & 3) * BK; };
+    const float* fragA0 = smem + rowoff(wm0 + li) + lkk;
+    const float* fragA1 = smem + rowoff(wm0 + 32 + li) + lkk;
+    const float* fragB0 = smem + OP_SZ + rowoff(wn0 + li) + lkk;
+    const float* fragB1 = smem + OP_SZ + rowoff(wn0 + 32 + li) + lkk;
+
+    if (nIter > 0) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < nIter; ++it) {
+            const int buf = it & 1;
+            dma_tile(it + 1 < nIter ? it + 1 : it, buf ^ 1);       // last iteration: reloads the current tile (harmless)
+            const int bo = buf * STAGE;
+            float a[2][TM], b[2][TN];
+            a[0][0] = fragA0[bo]; a[0][1] = fragA1[bo]; b[0][0] = fragB0[bo]; b[0][1] = fragB1[bo];
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < BK / 2) {
+                    const int o = bo + 2 * (ks + 1);
+                    a[cur ^ 1][0] = fragA0[o]; a[cur ^ 1][1] = fragA1[o];
+                    b[cur ^ 1][0] = fragB0[o]; b[cur ^ 1][1] = fragB1[o];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ outb = p.out + (long long)split * p.o_bs + tap;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn0 + tn * 32 + (lane & 31);
+        if (col >= p.NCOLS) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float* o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
+                float v = p.alpha * acc[tm][tn][r];
+                if (p.accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
 template <int BM, int BN>
 static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
     const int gz = p.batched ? p.batches : p.splits * p.ntaps;
     dim3 grid((p.NCOLS + BN - 1) / BN, (p.M + BM - 1) / BM, gz > 0 ? gz : 1);
     const bool straddle = p.X2 != nullptr && (p.g.c_split % BN) != 0;     // an N-tile may span both concat sources
+    if constexpr (BM == 128 && BN == 128) {
+        static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
+        const dp_conv_geom& g = p.g;
+        const int HoWo = g.Ho * g.Wo;
+        if (!no_fast && !p.batched && !p.merge && !straddle && !p.col_bias && g.stride == 1 && g.sden == 1 && g.ups == 0 &&
+            g.Wo > 0 && ((g.Wo % 16) == 0 || (16 % g.Wo) == 0) && (HoWo % 16) == 0 && (p.P % 16) == 0 &&
+            (p.p_per_split % 16) == 0 && g.Hs == g.Hv && g.Ws == g.Wv) {
+            hipLaunchKernelGGL(nt_gemm_fast_kernel, grid, dim3(256), dp_lds_pad(), st, p);
+            return DP_LAUNCH_CHECK();
+        }
+    }
     if (straddle) hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), dp_lds_pad(), st, p);
     else          hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), dp_lds_pad(), st, p);
     return DP_LAUNCH_CHECK();

@@ -59,6 +59,11 @@ def _nt_name(p):
     straddle = bool(p.X2) and (p.g.c_split % bn) != 0
     if p.merge:
         return 'nt_gemm_kernel<64, 64, false, true>'
+    g = p.g
+    if (p.tile == 0 and not p.batched and not straddle and not p.col_bias and g.stride == 1 and g.sden == 1 and g.ups == 0
+            and g.Wo > 0 and (g.Wo % 16 == 0 or 16 % g.Wo == 0) and (g.Ho * g.Wo) % 16 == 0 and p.P % 16 == 0
+            and p.p_per_split % 16 == 0 and g.Hs == g.Hv and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST')):
+        return 'nt_gemm_fast_kernel'                      # same dispatch rule as launch_nt_gemm (csrc/gemm.hip)
     return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if straddle else 'false')
 
 

@@ -66,6 +66,9 @@ CONV_CASES = [
     ('fast_cat', 2, 64, 32, 144, 16, 3, 1, 1, 0),
     ('fast_1x1_cat', 5, 32, 48, 96, 12, 1, 1, 0, 0),
     ('fast_tail', 3, 80, 0, 200, 10, 3, 1, 1, 0),
+    ('fast_cat128', 2, 128, 64, 96, 16, 3, 1, 1, 0),
+    ('fast_4x4', 20, 64, 0, 80, 4, 3, 1, 1, 0),
+    ('fast_w2', 9, 32, 0, 70, 2, 3, 1, 1, 0),
 ]
 
 
