@@ -13,9 +13,10 @@ A "step" is one sweep timestep over one batch.  value = (images processed by all
 ms_per_step is the sweep-only time per timestep.  fp32 everywhere (the reference's dtype).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (conv_gemm_kernel<128,128,false>: conv3x3/1x1 forward + dgrad), algorithmic FLOP per
+  roofline     dominant kernel (conv_gemm_fast_kernel<128,128>: conv3x3/1x1 forward + dgrad), algorithmic FLOP per
                launch / average launch duration, measured with HIP events on the launch stream in an instrumented step
-               after the timed region, against the 157.3 TFLOP/s fp32 MFMA peak.
+               after the timed region (weight-gradient stream overlap switched off there, so every kernel is timed
+               alone), against the 157.3 TFLOP/s fp32 MFMA peak.
   cpu_baseline the oracle (CPU restatement of the reference path) timed on this box's host cores, bounded sample.
 """
 import argparse
@@ -126,6 +127,7 @@ def main():
         model2 = model2.to(dev).eval()
         sweep.flatten_grads(model2)
         step2 = sweep.HipSweepStep(model2, sched, clean, noise, world * B * clean[0].numel(), 'mse', world * B)
+        step2.eng.overlap_wgrad = False      # per-kernel durations: one kernel on the GPU at a time
         step2(0)
         torch.cuda.synchronize()
         ops._prof = []
@@ -142,7 +144,7 @@ def main():
         dom = max(agg, key=lambda n: agg[n][2])
         cnt, fl, sec, ab = agg[dom]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs of this same command, profiles/round1_pmc_bench_traffic.json); KB -> bytes.
+        # WRITE_SIZE in separate runs of this same command, profiles/round1_pmc_bench_traffic.json, aggregated by tools/pmc_aggregate.py); KB -> bytes.
         # FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on gfx950 (MI355X_MICROARCH.md, HBM section).
         traffic = None
         try:
@@ -178,6 +180,7 @@ def main():
                        'global_batch': world * B, 'image': '3x32x32', 'parallelism': 'dp%d (batch shards)' % world,
                        'sweep_only_images_per_s': imgs / t_sweep, 'tail_ms': (t_total - t_sweep) * 1e3,
                        'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
+                       'wgrad_stream_overlap': bool(step.eng.overlap_wgrad),
                        'pruned_groups': len(pr.records), 'params_after': n_params_after,
                        'loss_first_last': [loss_vals[0], loss_vals[-1]]},
             'roofline': roof, 'cpu_baseline': cpu,

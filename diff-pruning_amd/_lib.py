@@ -42,7 +42,8 @@ class NtGemmParams(C.Structure):
                 ('batches', C.c_int), ('splits', C.c_int), ('p_per_split', C.c_int), ('tile', C.c_int),
                 ('batched', C.c_int),
                 ('out', C.c_void_p), ('o_bs', LL), ('ldo', C.c_int), ('accumulate', C.c_int),
-                ('alpha', C.c_float), ('merge', C.c_int), ('ocs', LL), ('col_bias', C.c_void_p)]
+                ('alpha', C.c_float), ('merge', C.c_int), ('ocs', LL),
+                ('o_tap_stride', LL), ('o_col_stride', C.c_int), ('_pad2', C.c_int), ('col_bias', C.c_void_p)]
 
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL
@@ -53,6 +54,7 @@ SIGNATURES = {
     'dp_conv_gemm': [C.POINTER(ConvGemmParams), _vp],
     'dp_nt_gemm': [C.POINTER(NtGemmParams), _vp],
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
+    'dp_splitk_reduce_taps': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp],
     'dp_pack_weight': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _vp],
     'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,

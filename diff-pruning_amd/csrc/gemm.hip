@@ -827,7 +827,8 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
     }
 
     const int zo = p.batched ? z : split;
-    float* __restrict__ outb = p.out + (long long)zo * p.o_bs + tap;
+    const int o_cs = p.o_col_stride ? p.o_col_stride : p.ntaps;          // defaults: torch [Cout][Cin][kh][kw] layout
+    float* __restrict__ outb = p.out + (long long)zo * p.o_bs + (long long)tap * (p.o_tap_stride ? p.o_tap_stride : 1);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn0 + tn * 32 + (lane & 31);
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
                     const int c = col / p.ntaps;
                     o = outb + (long long)m * p.ldo + (long long)c * p.ocs + (col - c * p.ntaps);
                 } else {
-                    o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
+                    o = outb + (long long)m * p.ldo + (long long)col * o_cs;
                 }
                 float v = p.alpha * acc[tm][tn][r];
                 if (p.col_bias && split == 0) v += p.col_bias[col];
@@ -988,7 +989,8 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
         }
     }
 
-    float* __restrict__ outb = p.out + (long long)split * p.o_bs + tap;
+    const int o_cs = p.o_col_stride ? p.o_col_stride : p.ntaps;
+    float* __restrict__ outb = p.out + (long long)split * p.o_bs + (long long)tap * (p.o_tap_stride ? p.o_tap_stride : 1);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn0 + tn * 32 + (lane & 31);
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
-                float* o = outb + (long long)m * p.ldo + (long long)col * p.ntaps;
+                float* o = outb + (long long)m * p.ldo + (long long)col * o_cs;
                 float v = p.alpha * acc[tm][tn][r];
                 if (p.accumulate) v += *o;
                 *o = v;
@@ -1058,6 +1060,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int k = 0; k < splits; ++k) s += ws[(long long)k * stride + i];
         out[i] = accumulate ? out[i] + s : s;
     }
+}
+
+// tap-major partials ws[s][tap][m*C + c] (written coalesced by the weight-gradient kernels) -> out[(m*C + c)*ntaps + tap]
+__global__ __launch_bounds__(256) void splitk_reduce_taps_kernel(const float* __restrict__ ws, long long stride, int splits,
+                                                                 float* __restrict__ out, long long mc, int ntaps,
+                                                                 int accumulate) {
+    const long long n = mc * ntaps;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(long long)k * stride + j];
+        const long long tap = j / mc;
+        const long long o = (j - tap * mc) * ntaps + tap;
+        out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
+extern "C" int dp_splitk_reduce_taps(const float* ws, long long stride, int splits, float* out, long long mc, int ntaps,
+                                     int accumulate, void* stream) {
+    if (mc <= 0 || ntaps <= 0) return 0;
+    long long nb = (mc * ntaps + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splitk_reduce_taps_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits,
+                       out, mc, ntaps, accumulate);
+    return DP_LAUNCH_CHECK();
 }
 
 extern "C" int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate,

@@ -11,6 +11,8 @@ Layout: activations are channel-major planes [N, C, H, W] with a free image stri
 (unet_2d_blocks.py:2035) is never materialised: GroupNorm and the 1x1 shortcut read both halves in
 place (two-source gather), and the concat gradient is handed to its two producers as channel-slice views.
 """
+import os
+
 import torch
 
 from . import ops
@@ -53,6 +55,11 @@ class UNetEngine:
         self.P = None      # name -> parameter tensor (device)
         self.G = None      # name -> gradient accumulation buffer (device), same shapes
         self.ctx = None
+        # Weight / bias gradients do not feed the backward chain: they run on a second HIP stream, so their MFMA work
+        # fills the CUs while the main stream is in the HBM-bound GroupNorm / reduction kernels and in the launch
+        # ramp / tail of its contraction kernels.  Same kernels, same accumulation order -> same bits.
+        self.overlap_wgrad = not os.environ.get('DP_NO_OVERLAP')
+        self._side = None
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -90,17 +97,43 @@ class UNetEngine:
             return None
         return ops.linear_dgrad(dy2d, w, out=dx_out, accumulate=dx_accumulate)
 
+    def _side_stream(self, *tensors):
+        """Fork: returns the side stream (ordered after everything enqueued so far on the current stream) or None.
+        `tensors` are read by the side-stream work: the allocator must not recycle them before that work is done."""
+        if not self.overlap_wgrad or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=tensors[0].device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._side)
+        return self._side
+
+    def _join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _conv_bwd(self, name, dy, x, x2, spec, in_hw, *, need_dx=True, rows=None, dx_out=None, dx_accumulate=False,
                   alpha=1.0):
         """Accumulate weight / bias gradients of conv `name`; return gradient w.r.t. its (virtual) input."""
         w = self.P[name + '.weight']
-        ops.conv_wgrad(dy, x, x2, self.G[name + '.weight'], spec, alpha=alpha, accumulate=True)
-        if (name + '.bias') in self.P:
-            if rows is None:
-                rows = ops.rowsum_nc(dy)
-            if alpha != 1.0:
-                rows = ops.axpby(rows, alpha, torch.empty_like(rows), 0.0)
-            ops.colsum_accum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'], True)
+
+        def param_grads(rows):
+            ops.conv_wgrad(dy, x, x2, self.G[name + '.weight'], spec, alpha=alpha, accumulate=True)
+            if (name + '.bias') in self.P:
+                if rows is None:
+                    rows = ops.rowsum_nc(dy)
+                if alpha != 1.0:
+                    rows = ops.axpby(rows, alpha, torch.empty_like(rows), 0.0)
+                ops.colsum_accum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'], True)
+
+        side = self._side_stream(dy, x, x2, rows)
+        if side is None:
+            param_grads(rows)
+        else:
+            with torch.cuda.stream(side):
+                param_grads(rows)
         if not need_dx:
             return None
         wd, ldd = self.packs.get(name, w, 1)
@@ -341,5 +374,6 @@ class UNetEngine:
         d_a1 = self._linear_bwd('time_embedding.linear_2', d_emb, a1)
         d_h1 = ops.silu_bwd(h1, d_a1)
         self._linear_bwd('time_embedding.linear_1', d_h1, t_emb, need_dx=False)
+        self._join_side()
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

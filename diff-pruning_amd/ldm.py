@@ -368,5 +368,6 @@ class LdmEngine(UNetEngine):
         d_a1 = self._linear_bwd('time_embed.2', d_emb, a1)
         d_h1 = ops.silu_bwd(h1, d_a1)
         self._linear_bwd('time_embed.0', d_h1, t_emb, need_dx=False)
+        self._join_side()
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

@@ -72,12 +72,17 @@ typedef struct dp_nt_gemm_params {
     float* out; long long o_bs; int ldo; int accumulate;
     float alpha; int merge;                /* merge: bit 0 = taps folded into the columns (NCOLS = C*ntaps), bit 1 = mirrored taps */
     long long ocs;                         /* merge: output element (row, c, tap) at row*ldo + c*ocs + tap */
+    long long o_tap_stride; int o_col_stride; int _pad2;   /* 0 = defaults (1, ntaps); (M*NCOLS, 1) with ldo = NCOLS gives
+                                              tap-major partials [tap][m][c] whose stores are contiguous */
     const float* col_bias;                 /* optional [NCOLS]: added per output column by split 0 (nn.Linear bias), or NULL */
 } dp_nt_gemm_params;
 int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
 
 /* out[i] (+)= sum_s ws[s*stride + i], fixed summation order (deterministic split-K epilogue). */
 int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate, void* stream);
+/* same for tap-major partials ws[s][tap][mc] -> out[mc][ntaps] (the torch weight layout) */
+int dp_splitk_reduce_taps(const float* ws, long long stride, int splits, float* out, long long mc, int ntaps,
+                          int accumulate, void* stream);
 
 /* Weight packing for dp_conv_gemm's A operand.  W is a torch Conv2d/Linear weight [Co][Ci][taps].
  * mode 0 (forward): dst[(tap*Ci + ci)*ld + co] = W[co][ci][tap],            ld = roundup4(Co)

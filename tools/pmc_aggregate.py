@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection.csv files into {kernel: {counter: {avg_kb|avg, n}}} (per-launch averages).
+    python tools/pmc_aggregate.py OUT.json DIR [DIR ...]
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (MI355X_MICROARCH.md, HBM section) -> key 'avg_kb'."""
+import collections, csv, glob, json, os, re, sys
+
+
+def clean(name):
+    name = re.sub(r'^void\s+', '', name)
+    return re.sub(r'\((dp_\w+|[\w\s\*,:<>]+)?\)\s*$', '', name).strip()
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            per_dispatch = collections.defaultdict(float)
+            names = {}
+            for r in csv.DictReader(open(f)):
+                key = (r['Dispatch_Id'], r['Counter_Name'])
+                per_dispatch[key] += float(r['Counter_Value'])       # summed over XCDs / instances
+                names[r['Dispatch_Id']] = clean(r['Kernel_Name'])
+            for (disp, ctr), v in per_dispatch.items():
+                a = agg[names[disp]][ctr]
+                a[0] += 1
+                a[1] += v
+    res = {}
+    for k, cs in agg.items():
+        if k.startswith('at::') or len(k) > 160:
+            continue
+        res[k] = {c: {('avg_kb' if c.endswith('_SIZE') else 'avg'): v / n, 'n': n} for c, (n, v) in cs.items()}
+    json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
+    print('wrote', out, len(res), 'kernels')
+
+
+if __name__ == '__main__':
+    main()
