@@ -11,7 +11,8 @@ __device__ __forceinline__ float wg_f(float w, float g, int mode) {
     const float p = w * g;
     if (mode == 0) { const float a = fabsf(p); return a * a; }   // (w*dw).abs().pow(2)
     if (mode == 1) return fabsf(p);
-    return p;                                                   // mode 2: signed, abs after the sum
+    if (mode == 4) return g * g;                                 // Fisher: dw.pow(2)
+    return p;                                                   // mode 2: signed, abs after the sum; mode 5: signed
 }
 
 __global__ __launch_bounds__(256) void wg_rows_kernel(const float* __restrict__ w, const float* __restrict__ g, int R,

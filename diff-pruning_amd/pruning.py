@@ -214,6 +214,7 @@ class Importance(abc.ABC):
 
 
 _MODES = {'sum_sq': 0, 'sum_abs': 1, 'abs_sum': 2}
+_F_SQ, _F_ABS, _F_SIGNED, _F_GN_ABS, _F_GRAD_SQ, _F_SUM = 0, 1, 2, 3, 4, 5      # dp_wg_reduce modes (include/dp_hip.h)
 
 
 class TaylorImportance(Importance):
@@ -289,12 +290,36 @@ class TaylorImportance(Importance):
         return score
 
 
-class MagnitudeImportance(Importance):
-    """L-p norm of the weights per channel (importance.py:59-126), p = 2, mean reduction + mean normaliser.
-    Not gradient based; provided for API completeness of ddpm_prune.py:64 (host arithmetic on tiny vectors)."""
+class _GradCriterion(Importance):
+    """Shared driver of the gradient criteria selectable in ddpm_exp/prune.py:193-208: every member contributes
+    sum over its other dims of f(w, g) (one or two dp_wg_reduce passes), length-mismatched members are dropped, members
+    are summed, optionally |.| at the end.  conv_modes / gn_modes: dp_wg_reduce modes accumulated per member."""
+    conv_modes = (_F_SQ,)
+    gn_modes = (_F_ABS,)
+    final_abs = False
 
-    def __init__(self, p=2, group_reduction='mean', normalizer='mean'):
-        self.p, self.group_reduction, self.normalizer = p, group_reduction, normalizer
+    def __init__(self, group_reduction='mean', normalizer='mean'):      # accepted and unused, as in the reference
+        self.group_reduction, self.normalizer = group_reduction, normalizer
+        self._scratch = None
+
+    def _member_score(self, layer, kind):
+        w, g = layer.weight.data, layer.weight.grad
+        if g is None:
+            raise RuntimeError('%s needs accumulated gradients (run the sweep before pruner.step())' % type(self).__name__)
+        g = g.data
+        if kind == 'gn':
+            w, g, dim, modes = w.reshape(-1, 1), g.reshape(-1, 1), 0, self.gn_modes
+        else:
+            dim, modes = (0 if kind == 'out' else 1), self.conv_modes
+        n_full = w.shape[dim]
+        full = torch.empty(n_full, dtype=torch.float32, device=w.device)
+        if dim == 1:
+            need = w.numel() // w.shape[0]
+            if self._scratch is None or self._scratch.numel() < need or self._scratch.device != w.device:
+                self._scratch = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=w.device)
+        for i, m in enumerate(modes):
+            ops.wg_reduce(w.contiguous(), g.contiguous(), dim, m, full, i > 0, self._scratch)
+        return full, n_full
 
     @torch.no_grad()
     def __call__(self, group, ch_groups=1):
@@ -302,18 +327,96 @@ class MagnitudeImportance(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
+            if kind is None or kind == 'ln':
+                continue
             layer = dep.target.module
-            if kind == 'out':
-                terms.append(layer.weight.data[idxs].flatten(1).abs().pow(self.p).sum(1))
-            elif kind == 'in':
-                terms.append(layer.weight.data.transpose(0, 1).flatten(1)[idxs].abs().pow(self.p).sum(1))
+            if kind == 'gn' and (not layer.affine or not self.gn_modes):
+                continue
+            terms.append((layer, kind, idxs))
         if not terms:
             return None
-        n0 = len(terms[0])
-        imp = torch.stack([t for t in terms if len(t) == n0], 0)
-        imp = imp.mean(0) if self.group_reduction == 'mean' else imp.sum(0)
-        imp = imp ** (1.0 / self.p)
-        return imp / imp.mean() if self.normalizer == 'mean' else imp
+        n0 = len(terms[0][2])
+        dev = terms[0][0].weight.device
+        score = torch.zeros(n0, dtype=torch.float32, device=dev)
+        self._used = 0
+        for layer, kind, idxs in terms:
+            if len(idxs) != n0:
+                continue
+            full, n_full = self._member_score(layer, kind)
+            if n_full == n0 and idxs[0] == 0 and idxs[-1] == n0 - 1:
+                ops.axpby(full, 1.0, score, 1.0)
+            else:
+                ops.gather_add(full, _index_tensor(('idx', tuple(idxs)), lambda: idxs, dev), score)
+            self._used += 1
+        if self.final_abs:           # |score|: signed row "sum" over one column with the abs-after-sum mode
+            out = torch.empty_like(score)
+            ops.wg_reduce(score.view(-1, 1), torch.ones_like(score).view(-1, 1), 0, _F_SIGNED, out, False)
+            score = out
+        return score
+
+
+class FullTaylorImportance(_GradCriterion):
+    """importance.py:482-548: order 1: sum w*g; order 2: sum w*g + sum (w*g)^2; |.| after the members are summed."""
+    final_abs = True
+
+    def __init__(self, order=1, group_reduction='mean', normalizer='mean'):
+        super().__init__(group_reduction, normalizer)
+        if order not in (1, 2):
+            raise ValueError('order must be 1 or 2')
+        self.order = order
+        self.conv_modes = (_F_SUM,) if order == 1 else (_F_SUM, _F_SQ)
+        self.gn_modes = self.conv_modes
+
+
+class AbsTaylorImportance(_GradCriterion):
+    """importance.py:611-670: sum |w*g| per member, plain sum over members."""
+    conv_modes = (_F_ABS,)
+    gn_modes = (_F_ABS,)
+
+    def __init__(self, order=1, group_reduction='mean', normalizer='mean'):
+        super().__init__(group_reduction, normalizer)
+
+
+class FisherImportance(_GradCriterion):
+    """importance.py:715-781: conv / linear members sum g^2, GroupNorm members (w*g)^2."""
+    conv_modes = (_F_GRAD_SQ,)
+    gn_modes = (_F_SQ,)
+
+
+class MagnitudeImportance(_GradCriterion):
+    """importance.py:59-126: sum |w|^p per conv / linear member (GroupNorm members carry no term: the vendored class only
+    matches BatchNorm), mean over members, divided by its mean.  p = 2 runs on the fused reduction with g := w."""
+    conv_modes = (_F_ABS,)
+    gn_modes = ()
+
+    def __init__(self, p=2, group_reduction='mean', normalizer='mean'):
+        super().__init__(group_reduction, normalizer)
+        if p != 2:
+            raise NotImplementedError('MagnitudeImportance: only p = 2 (the reference default) is built')
+        self.p = p
+
+    def _member_score(self, layer, kind):
+        w = layer.weight.data.contiguous()
+        dim = 0 if kind == 'out' else 1
+        n_full = w.shape[dim]
+        full = torch.empty(n_full, dtype=torch.float32, device=w.device)
+        if dim == 1:
+            need = w.numel() // w.shape[0]
+            if self._scratch is None or self._scratch.numel() < need or self._scratch.device != w.device:
+                self._scratch = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=w.device)
+        ops.wg_reduce(w, w, dim, _F_ABS, full, False, self._scratch)          # |w*w| = |w|^2
+        return full, n_full
+
+    @torch.no_grad()
+    def __call__(self, group, ch_groups=1):
+        score = super().__call__(group, ch_groups)
+        if score is None:
+            return None
+        if self.group_reduction == 'mean':
+            ops.axpby(score, 0.0, score, 1.0 / self._used)
+        if self.normalizer == 'mean':
+            ops.axpby(score, 0.0, score, 1.0 / float(score.mean()))
+        return score
 
 
 class RandomImportance(Importance):
@@ -323,6 +426,8 @@ class RandomImportance(Importance):
 
 
 importance = SimpleNamespace(Importance=Importance, TaylorImportance=TaylorImportance,
+                             FullTaylorImportance=FullTaylorImportance, AbsTaylorImportance=AbsTaylorImportance,
+                             FisherImportance=FisherImportance,
                              MagnitudeImportance=MagnitudeImportance, RandomImportance=RandomImportance)
 
 

@@ -148,7 +148,9 @@ int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H,
 /* Taylor-importance reductions  (ddpm_exp/torch_pruning/importance.py:375-434).
  * Weight viewed as [R][C][T]; dim = 0: out[r] = sum_{c,t} f(w*g); dim = 1: out[c] = sum_{r,t} f(w*g);
  * mode 0: f = (w g)^2 (vendored), mode 1: f = |w g| (sum_abs), mode 2: signed sum then |.| (abs_sum),
- * mode 3: out[i] = |w_i g_i| (GroupNorm member; R = channels, C = T = 1).
+ * mode 3: out[i] = |w_i g_i| (GroupNorm member; R = channels, C = T = 1),
+ * mode 4: f = g^2 (FisherImportance, importance.py:715-781), mode 5: signed sum, no |.| (FullTaylorImportance,
+ * importance.py:482-548: the absolute value is taken after the members are summed).
  * out[i] = (accumulate ? out[i] : 0) + value.  `scratch` (>= C*T floats) is required for dim == 1. */
 int dp_wg_reduce(const float* w, const float* g, int R, int C, int T, int dim, int mode, float* out, int accumulate,
                  float* scratch, void* stream);

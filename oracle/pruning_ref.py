@@ -6,8 +6,15 @@ pruned index lists recorded from the reference's vendored ddpm_exp/torch_pruning
 that ddpm_prune.py:60,66 calls; that package is not under /root/reference and is unpinned
 (requirements.txt:7) -> for those two modes: PARITY UNPINNED (checked only against this restatement).
 
+The sibling criteria selectable in ddpm_exp/prune.py:193-208 ('full1', 'full2', 'abs', 'fisher', 'magnitude') are
+pinned against tests/golden/tiny_criteria.json (scores + masks of a whole sequential prune per criterion).
+
 Reference lines followed (relative to /root/reference/ddpm_exp/torch_pruning):
   importance.py:375-434                    TaylorImportance.__call__ (vendored: sum of (w*g)^2; GN |w*g|)
+  importance.py:482-548                    FullTaylorImportance (order 1: sum w*g, order 2: + sum (w*g)^2; |sum over members|)
+  importance.py:611-670                    AbsTaylorImportance (sum |w*g|)
+  importance.py:715-781                    FisherImportance (sum g^2; GN (w*g)^2)
+  importance.py:59-126                     MagnitudeImportance (sum |w|^p, no GN term, mean over members, / mean)
   pruner/algorithms/metapruner.py:196-254  prune_local: target count, GroupNorm sub-group selection
   pruner/function.py:85-146,168-207,274-302  conv / linear / groupnorm slicing (weights AND grads)
 
@@ -25,9 +32,25 @@ def member_terms(w, g, kind, idxs, mode='sum_sq'):
     elif kind == 'in':
         wg = (w.transpose(0, 1).flatten(1)[idxs] * g.transpose(0, 1).flatten(1)[idxs])
     elif kind == 'gn':
-        return (w[idxs] * g[idxs]).abs()
+        p = w[idxs] * g[idxs]
+        if mode == 'full1':
+            return p
+        if mode == 'full2':
+            return p + p.pow(2)
+        if mode == 'fisher':
+            return p.pow(2)
+        return p.abs()
     else:
         raise ValueError(kind)
+    if mode == 'full1':
+        return wg.sum(1)
+    if mode == 'full2':
+        return wg.sum(1) + wg.pow(2).sum(1)
+    if mode == 'abs':
+        return wg.abs().sum(1)
+    if mode == 'fisher':
+        gg = g[idxs].flatten(1) if kind == 'out' else g.transpose(0, 1).flatten(1)[idxs]
+        return gg.pow(2).sum(1)
     if mode == 'sum_sq':
         return wg.abs().pow(2).sum(1)
     if mode == 'sum_abs':
@@ -49,7 +72,27 @@ def taylor_score(P, G, members, mode='sum_sq'):
         return None
     n0 = len(terms[0])
     aligned = [t for t in terms if len(t) == n0]
-    return torch.stack(aligned, dim=0).sum(0)
+    tot = torch.stack(aligned, dim=0).sum(0)
+    return tot.abs() if mode in ('full1', 'full2') else tot
+
+
+@torch.no_grad()
+def magnitude_score(P, members, p=2):
+    """importance.py:59-126 (group_reduction='mean', normalizer='mean'): GroupNorm members contribute nothing (the
+    vendored class only matches prune_batchnorm_out_channels)."""
+    terms = []
+    for pre, kind, idxs in members:
+        idxs = sorted(idxs)
+        w = P[pre + '.weight']
+        if kind == 'out':
+            terms.append(w[idxs].flatten(1).abs().pow(p).sum(1))
+        elif kind == 'in':
+            terms.append(w.transpose(0, 1).flatten(1).abs().pow(p).sum(1)[idxs])
+    if not terms:
+        return None
+    n0 = len(terms[0])
+    imp = torch.stack([t for t in terms if len(t) == n0], dim=0).mean(0)
+    return imp / imp.mean()
 
 
 def select_pruned(score, cur_out, init_out, ratio, ch_groups, round_to=None):

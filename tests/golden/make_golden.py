@@ -96,9 +96,9 @@ def dump_group(group, names):
     return mem
 
 
-def make_pruner(model, H, ratio=0.3):
+def make_pruner(model, H, ratio=0.3, imp=None):
     ex = {'sample': torch.randn(1, model.config.in_channels, H, H), 'timestep': torch.ones((1,)).long()}
-    imp = tp.importance.TaylorImportance()
+    imp = imp if imp is not None else tp.importance.TaylorImportance()
     return tp.pruner.MagnitudePruner(model, ex, importance=imp, iterative_steps=1, channel_groups={},
                                      ch_sparsity=ratio, ignored_layers=[model.conv_out]), ex
 
@@ -133,9 +133,9 @@ def grad_stats(model):
     return st
 
 
-def prune_run(model, H, ratio=0.3):
+def prune_run(model, H, ratio=0.3, imp=None):
     """pruner.step(interactive=True) loop of ddpm_prune.py:108-116, recording every group."""
-    pruner, ex = make_pruner(model, H, ratio)
+    pruner, ex = make_pruner(model, H, ratio, imp)
     pruner.current_step += 1          # what MetaPruner.step() does first (metapruner.py:155)
     names = name_of(model)
     rec = []
@@ -271,6 +271,31 @@ def do_tiny():
     print('tiny ok: groups', len(table), 'pruned groups', len(rec), 'params', nparams, 'early steps', len(losses2))
 
 
+def do_criteria():
+    """The sibling criteria selectable in ddpm_exp/prune.py:193-208 on the tiny UNet after a 4-step sweep:
+    per-group score vectors and pruned index lists of the whole sequential prune, one run per criterion."""
+    cfg = gc.TINY_CFG
+    H = cfg['sample_size']
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((2, 3, H, H), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, H, H), 2))
+    crits = dict(full1=lambda: tp.importance.FullTaylorImportance(order=1),
+                 full2=lambda: tp.importance.FullTaylorImportance(order=2),
+                 abs=lambda: tp.importance.AbsTaylorImportance(),
+                 fisher=lambda: tp.importance.FisherImportance(),
+                 magnitude=lambda: tp.importance.MagnitudeImportance())
+    out = {}
+    for name, mk in crits.items():
+        model = build_ref_unet(cfg, 5)
+        sweep(model, sched, clean, noise, 4)
+        rec = prune_run(model, H, 0.3, mk())
+        out[name] = dict(groups=[dict(root=r['root'], ch_groups=r['ch_groups'], pruned=compress(r['pruned']),
+                                      score=r['score']) for r in rec],
+                         params_after=int(sum(p.numel() for p in model.parameters())))
+        print('criterion', name, 'groups', len(rec), 'params', out[name]['params_after'])
+    json.dump(out, open(os.path.join(HERE, 'tiny_criteria.json'), 'w'))
+
+
 def do_groups():
     out = {}
     cfg = gc.CIFAR_CFG
@@ -314,6 +339,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria']
     for w in what:
         globals()['do_' + w]()

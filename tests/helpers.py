@@ -49,7 +49,7 @@ def relerr(a, ref):
 
 
 def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ignored=('conv_out',), gn_groups=None,
-                        round_to=None):
+                        round_to=None, mode='sum_sq'):
     """Run the oracle's score / select / slice arithmetic over the PRODUCT's group enumeration (host logic that is
     itself pinned against the reference's group tables).  P/G: {name: tensor} dicts, modified in place.
     Returns a list of dict(root, ch_groups, score, pruned, margin)."""
@@ -63,7 +63,8 @@ def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ig
 
     for root, members in graph_mod.all_groups(graph, chan, ignored):
         mem = [(m.name, m.kind, list(m.idxs)) for m in members]
-        score = R.taylor_score(P, G, [m for m in mem if m[1] != 'ln'])
+        mem_s = [m for m in mem if m[1] != 'ln']
+        score = R.magnitude_score(P, mem_s) if mode == 'magnitude' else R.taylor_score(P, G, mem_s, mode)
         if score is None:
             continue
         ch_groups = (gn_groups or cfg['norm_num_groups']) if any(k == 'gn' for _, k, _ in mem) else 1

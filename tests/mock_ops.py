@@ -237,7 +237,13 @@ def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
         v = p.abs()
     else:
         q = p.flatten(1) if dim == 0 else p.transpose(0, 1).flatten(1)
-        v = q.abs().pow(2).sum(1) if mode == 0 else (q.abs().sum(1) if mode == 1 else q.sum(1).abs())
+        if mode == 4:
+            gq = g.flatten(1) if dim == 0 else g.transpose(0, 1).flatten(1)
+            v = gq.pow(2).sum(1)
+        elif mode == 5:
+            v = q.sum(1)
+        else:
+            v = q.abs().pow(2).sum(1) if mode == 0 else (q.abs().sum(1) if mode == 1 else q.sum(1).abs())
     out.copy_(out + v if accumulate else v)
     return out
 

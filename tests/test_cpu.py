@@ -115,6 +115,35 @@ def test_oracle_prune_masks_match_reference_tiny():
     assert float((y2 - torch.from_numpy(gc.b64_to_f32(fx['fwd_after']))).abs().max()) < 5e-6
 
 
+CRITERIA = ['full1', 'full2', 'abs', 'fisher', 'magnitude']
+
+
+def _expand(ranges):
+    return [i for a, b in ranges for i in range(a, b)]
+
+
+@pytest.mark.parametrize('crit', CRITERIA)
+def test_oracle_sibling_criteria_match_reference_tiny(crit):
+    """FullTaylor(order 1, 2) / AbsTaylor / Fisher / Magnitude (ddpm_exp/prune.py:193-208): scores and masks of the
+    whole sequential prune of the tiny UNet against the vectors recorded from the vendored classes."""
+    from oracle import diffusion_ref as D
+    cfg = gc.TINY_CFG
+    P = oracle_params(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    D.taylor_sweep(P, cfg, clean, noise, 4)
+    fx = load_json('tiny_criteria.json')[crit]
+    Pd = {n: p.detach().clone() for n, p in P.items()}
+    Gd = {n: p.grad.clone() for n, p in P.items()}
+    rec = oracle_prune_replay(Pd, Gd, cfg, 0.3, pkg('graph'), mode=crit)
+    assert len(rec) == len(fx['groups'])
+    for mine, ref in zip(rec, fx['groups']):
+        assert mine['root'] == ref['root'] and mine['ch_groups'] == ref['ch_groups']
+        assert relerr(mine['score'], gc.b64_to_f32(ref['score'])) < 2e-5, (crit, ref['root'])
+        assert mine['pruned'] == _expand(ref['pruned']), (crit, ref['root'], mine['margin'])
+    assert sum(t.numel() for t in Pd.values()) == fx['params_after']
+
+
 def test_oracle_early_exit_step_count():
     from oracle import diffusion_ref as D
     cfg = gc.TINY_CFG
@@ -341,6 +370,26 @@ def test_prune_flow_on_mocked_kernels_matches_reference_masks(mocked, monkeypatc
     # pruned model still runs forward + backward through the engine
     res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1)
     assert np.isfinite(res['losses'][0])
+
+
+@pytest.mark.parametrize('crit', CRITERIA)
+def test_sibling_criteria_flow_on_mocked_kernels(mocked, monkeypatch, crit):
+    """The product's criterion classes (host logic + mocked reductions) reproduce the reference's masks."""
+    sweep, pruning = pkg('sweep'), pkg('pruning')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = gc.TINY_CFG
+    fx = load_json('tiny_criteria.json')[crit]
+    model = _cpu_model(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=4)
+    imp = dict(full1=lambda: pruning.FullTaylorImportance(order=1), full2=lambda: pruning.FullTaylorImportance(order=2),
+               abs=pruning.AbsTaylorImportance, fisher=pruning.FisherImportance, magnitude=pruning.MagnitudeImportance)[crit]()
+    pr = sweep.prune_model(model, 0.3, importance=imp)
+    assert [r[3] for r in pr.records] == [_expand(g['pruned']) for g in fx['groups']]
+    for r, g in zip(pr.records, fx['groups']):
+        assert relerr(r[2], gc.b64_to_f32(g['score'])) < 2e-5, (crit, g['root'])
+    assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
 # ------------------------------------------------------------------------------------------------ LDM (row a17)

@@ -105,6 +105,31 @@ def test_tiny_prune_masks_bit_exact_and_post_prune_forward(report):
     assert e < 1e-5
 
 
+@pytest.mark.parametrize('crit', ['full1', 'full2', 'abs', 'fisher', 'magnitude'])
+def test_sibling_criteria_masks_bit_exact(report, crit):
+    """FullTaylor(order 1/2) / AbsTaylor / Fisher / Magnitude importance (ddpm_exp/prune.py:193-208) on the HIP reductions:
+    every group's mask identical to the vendored reference classes, scores within fp32 tolerance."""
+    pruning, sweep = pkg('pruning'), pkg('sweep')
+    fx = load_json('tiny_criteria.json')[crit]
+    model = make_model(gc.TINY_CFG, 5)
+    clean, noise = _inputs(2, 16)
+    _run_sweep(model, clean, noise, 4)
+    imp = dict(full1=lambda: pruning.FullTaylorImportance(order=1), full2=lambda: pruning.FullTaylorImportance(order=2),
+               abs=pruning.AbsTaylorImportance, fisher=pruning.FisherImportance, magnitude=pruning.MagnitudeImportance)[crit]()
+    pr = sweep.prune_model(model, 0.3, importance=imp)
+    assert len(pr.records) == len(fx['groups'])
+    worst, mism = 0.0, []
+    for (root, chg, score, pruned), ref in zip(pr.records, fx['groups']):
+        assert root == ref['root'] and chg == ref['ch_groups']
+        worst = max(worst, relerr(score, torch.from_numpy(gc.b64_to_f32(ref['score']))))
+        if pruned != [i for a, b in ref['pruned'] for i in range(a, b)]:
+            mism.append(root)
+    report['e2e/criterion_' + crit] = dict(groups=len(pr.records), score_rel_worst=worst, mask_mismatches=mism)
+    assert not mism, mism
+    assert worst < 1e-4
+    assert sum(p.numel() for p in model.parameters()) == fx['params_after']
+
+
 def test_diff_pruning_early_exit_step(report):
     cfg = gc.TINY_CFG
     fx = load_json('tiny_prune.json')['early_exit']
