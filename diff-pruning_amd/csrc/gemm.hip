@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 
 
 // ------------------------------------------------------------------------------------------------
-// conv_gemm_fast: the stride-1 / no-upsample / channels % 16 == 0 case (every resnet 3x3, shortcut, attention
+// conv_gemm_fast: the stride-1 / no-upsample case, any channel count and concat split (every resnet 3x3, shortcut, attention
 // projection and their dgrads; > 95 % of the conv_gemm time), 128x128 tile, same math and K order as conv_gemm_kernel.
 // Plain VALU instructions are not free next to the matrix pipe (tools/probe/mfma_valu.hip: ~1.7 cycles each, the
 // general loader spends ~100 per K tile = -9 %), so everything per-lane is hoisted out of the K loop:
@@ -440,9 +440,14 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
-    static_assert(BM == 128 && BN == 128, "fast path is tuned for the 128x128 tile");
+    // BM = 128: waves 2x2, each 64x64 as interleaved 32x32 sub-tiles (64 apart).  BM = 96 (pruned widths such as 90 or
+    // 180 channels lose 30 % of a 128-row tile): waves 1x4, each all 96 rows x 32 columns.
+    static_assert((BM == 128 || BM == 96) && BN == 128, "fast path tiles: 128x128, 96x128");
     constexpr int BK = 16;
-    constexpr int TM = 2, TN = 2;
+    constexpr int WAVES_M = (BM == 128) ? 2 : 1;
+    constexpr int TM = BM / 32 / WAVES_M, TN = BN / 32 / (4 / WAVES_M);
+    constexpr int TMS = (BM == 128) ? 64 : 32, TNS = 64;        // sub-tile strides inside the workgroup tile
+    constexpr int A_F4 = BK * BM / 4;                           // float4 elements of the A tile (512 or 384)
     constexpr int A_SZ = BK * BM;
     constexpr int B_SZ = BK * BN;
     constexpr int STAGE = A_SZ + B_SZ;
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wrow = (BM == 128) ? (wave >> 1) * 32 : 0;        // first row / column of this wave's sub-tile 0
+    const int wcol = (BM == 128) ? (wave & 1) * 32 : wave * 32;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int z = blockIdx.z;
@@ -461,7 +467,10 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
     const int HsWs = g.Hs * g.Ws;
     const int C = p.C;
     const int ntaps = p.ntaps;
-    const int nch = C / BK;
+    // channel chunks of 16 per concat source; the last chunk of a source may be narrower (pruned widths)
+    const int C1 = p.X2 ? g.c_split : C;
+    const int nch1 = (C1 + BK - 1) / BK;
+    const int nch = nch1 + (C - C1 + BK - 1) / BK;
     const int nIterAll = ntaps * nch;
     const bool ksplit = p.ksplit > 1;
     const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
@@ -476,17 +485,21 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
     const __amdgpu_buffer_rsrc_t rA = dp_rsrc(Ab, p.a_bytes);
     const __amdgpu_buffer_rsrc_t r1 = dp_rsrc(X1 - shift, p.x1_bytes + 4u * (unsigned)shift);
     const __amdgpu_buffer_rsrc_t r2 = dp_rsrc(X2 - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
-    const int ch_split = p.X2 ? g.c_split / BK : nch;            // chunks [0, ch_split) come from X1
+    auto chunk_width = [&](int c) {                              // valid channels of chunk c
+        const int left = (c < nch1) ? C1 - c * BK : (C - C1) - (c - nch1) * BK;
+        return left < BK ? left : BK;
+    };
 
     // ---- per-lane constants
-    // A: element e = tid + 256*j of the [16][128] tile, 4 floats each: row k = e/32, column 4*(e%32)
-    unsigned a_voff[2];
+    // A: element e = tid + 256*j of the [16][BM] tile, 4 floats each: row k = e/(BM/4), column 4*(e%(BM/4))
+    unsigned a_voff[2], a_base[2];
+    int a_k[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = tid + 256 * j;
-        const int k = e >> 5;
-        const int m = m0 + 4 * (e & 31);
-        a_voff[j] = (m < p.lda) ? (unsigned)((k * p.lda + m) * 4) : DP_OOB;
+        a_k[j] = e / (BM / 4);
+        const int m = m0 + 4 * (e - a_k[j] * (BM / 4));
+        a_base[j] = (e < A_F4 && m < p.lda) ? (unsigned)((a_k[j] * p.lda + m) * 4) : DP_OOB;
     }
     const unsigned a_row_bytes = (unsigned)p.lda * 4u;
     // B: pixel column bn, rows bk0 + 2*j
@@ -512,19 +525,27 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
             }
     }
     unsigned b_voff[8];
-    auto set_source = [&](bool first) {
+    // (re)build the per-lane offsets for a chunk of `cw` valid channels from source `first`: rows beyond cw are
+    // permanently out of range (zeros), so the K loop itself carries no channel test.  Runs only when the source or the
+    // width changes (at most 4 times per workgroup).
+    auto set_chunk = [&](bool first, int cw) {
         const unsigned b = first ? b_pix1 : b_pix2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b_voff[j] = (b + (unsigned)(2 * j * HsWs)) * 4u;
+        for (int j = 0; j < 8; ++j) b_voff[j] = (bk0 + 2 * j < cw) ? (b + (unsigned)(2 * j * HsWs)) * 4u : DP_OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_voff[j] = (a_k[j] < cw) ? a_base[j] : DP_OOB;
     };
 
     // ---- scalar K-tile state: chunk ch (16 channels), tap (ky, kx)
-    int ch = it0 / ntaps;
+    // (uniform integer divisions are expanded on the VALU: pin the results back to SGPRs, or every buffer instruction
+    //  that takes them as its scalar offset gets wrapped in a waterfall loop)
+    int ch = __builtin_amdgcn_readfirstlane(it0 / ntaps);
     int tap = it0 - ch * ntaps;
-    int ky = tap / g.kw;
+    int ky = __builtin_amdgcn_readfirstlane(tap / g.kw);
     int kx = tap - ky * g.kw;
-    bool first = ch < ch_split;
-    set_source(first);
+    bool first = ch < nch1;
+    int cw = (ch < nch) ? chunk_width(ch) : BK;
+    set_chunk(first, cw);
 
     float* const ldsA = smem + 4 * (wave * 64);                 // + buf*STAGE + 1024*j   (float4 per lane)
     float* const ldsB = smem + A_SZ + bk0 * 0 + (wave & 1) * 64 + (wave >> 1) * BN;   // row bk0 = wave>>1, cols (wave&1)*64..
@@ -532,14 +553,16 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
     auto dma_tile = [&](int buf) {
         float* As = ldsA + buf * STAGE;
         float* Bs = ldsB + buf * STAGE;
-        const unsigned a_soff = (unsigned)(tap * C + ch * BK) * a_row_bytes;
+        const int cbase = first ? ch * BK : C1 + (ch - nch1) * BK;       // first channel of the chunk in the concat order
+        const unsigned a_soff = (unsigned)(tap * C + cbase) * a_row_bytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (256 * j + 64 * wave >= A_F4) continue;          // BM = 96: the second pass belongs to waves 0 and 1 only
             unsigned o = a_voff[j];
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
         }
-        const unsigned b_soff = (unsigned)(((first ? ch : ch - ch_split) * BK) * HsWs + ky * g.Ws + kx) * 4u;
+        const unsigned b_soff = (unsigned)(((first ? ch : ch - nch1) * BK) * HsWs + ky * g.Ws + kx) * 4u;
         const bool tv = (vmask >> tap) & 1u;
         const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
 #pragma unroll
@@ -554,7 +577,11 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
         if (kx == g.kw) { kx = 0; ++ky; }
         if (tap == ntaps) {
             tap = 0; ky = 0; kx = 0; ++ch;
-            if (first && ch >= ch_split && ch < nch) { first = false; set_source(false); }
+            if (ch < nch) {
+                const bool f = ch < nch1;
+                const int w = chunk_width(ch);
+                if (f != first || w != cw) { first = f; cw = w; set_chunk(f, w); }
+            }
         }
     };
 
@@ -567,8 +594,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int li = lane & 31, lk = lane >> 5;
-    const float* fragA = smem + lk * BM + wr * 32 + li;
-    const float* fragB = smem + A_SZ + lk * BN + wc * 32 + li;
+    const float* fragA = smem + lk * BM + wrow + li;
+    const float* fragB = smem + A_SZ + lk * BN + wcol + li;
 
     if (nIter > 0) {
         dma_tile(0);
@@ -583,16 +610,17 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
             const float* Bf = fragB + buf * STAGE;
             float a[2][TM], b[2][TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { a[0][t] = Af[64 * t]; b[0][t] = Bf[64 * t]; }
+            for (int t = 0; t < TM; ++t) a[0][t] = Af[TMS * t];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[0][t] = Bf[TNS * t];
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int cur = ks & 1;
                 if (ks + 1 < BK / 2) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        a[cur ^ 1][t] = Af[(ks + 1) * 2 * BM + 64 * t];
-                        b[cur ^ 1][t] = Bf[(ks + 1) * 2 * BN + 64 * t];
-                    }
+                    for (int t = 0; t < TM; ++t) a[cur ^ 1][t] = Af[(ks + 1) * 2 * BM + TMS * t];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) b[cur ^ 1][t] = Bf[(ks + 1) * 2 * BN + TNS * t];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -606,17 +634,21 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
             __syncthreads();
         }
     }
-    conv_epilogue<TM, TN, 64, 64>(p, acc, m0 + wr * 32, n0 + wc * 32, lane, z, ksplit);
+    conv_epilogue<TM, TN, TMS, TNS>(p, acc, m0 + wrow, n0 + wcol, lane, z, ksplit);
+}
+
+static bool conv_fast_ok(const dp_conv_gemm_params& p) {
+    static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
+    const dp_conv_geom& g = p.g;
+    return !no_fast && !p.a_kc && g.stride == 1 && g.sden == 1 && g.ups == 0 && p.ntaps <= 32 && g.Hs == g.Hv &&
+           g.Ws == g.Wv;
 }
 
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
     if constexpr (BM == 128 && BN == 128) {
-        static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
-        const dp_conv_geom& g = p.g;
-        if (!no_fast && !p.a_kc && g.stride == 1 && g.sden == 1 && g.ups == 0 && (p.C % 16) == 0 && p.ntaps <= 32 &&
-            (!p.X2 || (g.c_split % 16) == 0) && g.Hs == g.Hv && g.Ws == g.Wv) {
+        if (conv_fast_ok(p)) {
             hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128>), grid, dim3(256), dp_lds_pad(), st, p);
             return DP_LAUNCH_CHECK();
         }
@@ -664,6 +696,14 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
     if (p.a_kc && p.ntaps != 1) return (int)hipErrorInvalidValue;
     int e;
     switch (p.tile) {
+        case 3:                                                  // 96x128: fast kernel only, else the 128x128 path
+            if (conv_fast_ok(p)) {
+                dim3 grid((p.NPIX + 127) / 128, (p.M + 95) / 96, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
+                hipLaunchKernelGGL((conv_gemm_fast_kernel<96, 128>), grid, dim3(256), dp_lds_pad(), st, p);
+                e = DP_LAUNCH_CHECK();
+                break;
+            }
+            [[fallthrough]];
         case 0: e = launch_conv_gemm<128, 128>(p, st); break;
         case 1: e = launch_conv_gemm<64, 128>(p, st); break;
         case 2: e = launch_conv_gemm<64, 64>(p, st); break;
@@ -867,9 +907,15 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
 //     dwords, the pad dword per 4-row group makes the 32-lane fragment reads hit 32 distinct banks, and the k-step
 //     offsets are ds_read immediates (no address arithmetic, no register staging, no ds_write).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_params p) {
-    constexpr int BM = 128, BN = 128, BK = 16;
-    constexpr int TM = 2, TN = 2;
+// NW = 4: 128x128 tile, waves 2x2 of 64x64.  NW = 3: 96x96 tile, 192 threads, wave w = rows [32w, 32w+32) x 96 columns
+// (pruned widths: 90 or 180 channels fill 49 % of 128x128 tiles, 88 % of 96x96 ones).
+// Two concat sources with ANY split: the tile columns are *virtual* channels v -- source 1 padded to a multiple of 4
+// (C1p), then source 2 -- so every 4-row DMA group reads one source (scalar descriptor choice), and the epilogue maps
+// v back to the real channel.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_params p) {
+    constexpr int BM = 32 * NW, BN = 32 * NW, BK = 16;
+    constexpr int TM = (NW == 4) ? 2 : 1, TN = (NW == 4) ? 2 : 3;
     constexpr int GRP = 4 * BK + 1;                 // dwords per 4-row group
     constexpr int OP_SZ = (BM / 4) * GRP;           // 2080 dwords per operand tile
     constexpr int STAGE = 2 * OP_SZ;
@@ -878,7 +924,8 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (NW == 4) ? (wave >> 1) * 64 : wave * 32;
+    const int wn0 = (NW == 4) ? (wave & 1) * 64 : 0;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int z = blockIdx.z;
@@ -894,13 +941,12 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
     const int p_end = min(p_begin + p.p_per_split, p.P);
     const int nIter = (p_end > p_begin) ? (p_end - p_begin) / BK : 0;
 
-    const bool first_src = (!p.X2) || n0 < g.c_split;
-    const float* __restrict__ Xs = first_src ? p.X1 : p.X2;
-    const int cofs = first_src ? 0 : g.c_split;
-    const long long xs_img = first_src ? g.x1_img_stride : g.x2_img_stride;
+    const int C1 = p.X2 ? g.c_split : p.NCOLS;                   // channels of source 1
+    const int C1p = p.X2 ? ((C1 + 3) & ~3) : p.NCOLS;            // virtual index of source 2's first channel
     const int shift = g.pad_t * g.Ws + g.pad_l;
     const __amdgpu_buffer_rsrc_t rA = dp_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rB = dp_rsrc(Xs - shift, (first_src ? p.x1_bytes : p.x2_bytes) + 4u * (unsigned)shift);
+    const __amdgpu_buffer_rsrc_t rB1 = dp_rsrc(p.X1 - shift, p.x1_bytes + 4u * (unsigned)shift);
+    const __amdgpu_buffer_rsrc_t rB2 = dp_rsrc((p.X2 ? p.X2 : p.X1) - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
 
     // ---- per-lane constants: pixel lk of the K tile, row sub of each 4-row group; this wave owns groups wave*8 .. +7
     const int lk = lane & 15, sub = lane >> 4;
@@ -913,8 +959,11 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
         const int row = 4 * (wave * 8 + j) + sub;
         const int m = m0 + row;
         a_voff[j] = (m < p.M) ? (unsigned)((m * HoWo + lk) * 4) : DP_OOB;
-        const int c = n0 + row;
-        b_voff[j] = (c < p.NCOLS) ? (unsigned)(((c - cofs) * HsWs + (dho + ky) * g.Ws + wol + kx) * 4) : DP_OOB;
+        const int v = n0 + row;                                  // virtual channel -> (source, channel in source)
+        const bool s1 = v < C1p;
+        const int cs = s1 ? v : v - C1p;
+        const bool cv = s1 ? (v < C1) : (C1 + cs < p.NCOLS);
+        b_voff[j] = cv ? (unsigned)((cs * HsWs + (dho + ky) * g.Ws + wol + kx) * 4) : DP_OOB;
     }
     float* const ldsW = smem + wave * 8 * GRP;      // this wave's first group, operand A of stage 0
 
@@ -925,7 +974,8 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
         const int ho0 = r0 / g.Wo;
         const int wo0 = r0 - ho0 * g.Wo;
         const unsigned a_soff = (unsigned)((long long)img * p.a_img_stride + r0) * 4u;
-        const unsigned b_soff = (unsigned)((long long)img * xs_img + ho0 * g.Ws + wo0) * 4u;
+        const unsigned b_soff1 = (unsigned)((long long)img * g.x1_img_stride + ho0 * g.Ws + wo0) * 4u;
+        const unsigned b_soff2 = (unsigned)((long long)img * g.x2_img_stride + ho0 * g.Ws + wo0) * 4u;
         const bool v = ((unsigned)(ho0 + hc) < (unsigned)g.Hs) && ((unsigned)(wo0 + wc) < (unsigned)g.Ws);
         float* As = ldsW + buf * STAGE;
         float* Bs = As + OP_SZ;
@@ -939,7 +989,9 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
         for (int j = 0; j < 8; ++j) {
             unsigned o = v ? b_voff[j] : DP_OOB;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (dp_lds_void*)(Bs + j * GRP), 4, (int)o, (int)b_soff, 0, 0);
+            const bool s1 = n0 + 4 * (wave * 8 + j) < C1p;       // scalar: the whole 4-row group is in one source
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s1 ? rB1 : rB2, (dp_lds_void*)(Bs + j * GRP), 4, (int)o,
+                                                     (int)(s1 ? b_soff1 : b_soff2), 0, 0);
         }
     };
 
@@ -953,10 +1005,12 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
 
     const int li = lane & 31, lkk = lane >> 5;
     auto rowoff = [](int row) { return (row >> 2) * GRP + (row & 3) * BK; };
-    const float* fragA0 = smem + rowoff(wm0 + li) + lkk;
-    const float* fragA1 = smem + rowoff(wm0 + 32 + li) + lkk;
-    const float* fragB0 = smem + OP_SZ + rowoff(wn0 + li) + lkk;
-    const float* fragB1 = smem + OP_SZ + rowoff(wn0 + 32 + li) + lkk;
+    const float* fragA[TM];
+    const float* fragB[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fragA[t] = smem + rowoff(wm0 + 32 * t + li) + lkk;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) fragB[t] = smem + OP_SZ + rowoff(wn0 + 32 * t + li) + lkk;
 
     if (nIter > 0) {
         dma_tile(0, 0);
@@ -967,14 +1021,19 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
             dma_tile(it + 1 < nIter ? it + 1 : it, buf ^ 1);       // last iteration: reloads the current tile (harmless)
             const int bo = buf * STAGE;
             float a[2][TM], b[2][TN];
-            a[0][0] = fragA0[bo]; a[0][1] = fragA1[bo]; b[0][0] = fragB0[bo]; b[0][1] = fragB1[bo];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[0][t] = fragA[t][bo];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[0][t] = fragB[t][bo];
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int cur = ks & 1;
                 if (ks + 1 < BK / 2) {
                     const int o = bo + 2 * (ks + 1);
-                    a[cur ^ 1][0] = fragA0[o]; a[cur ^ 1][1] = fragA1[o];
-                    b[cur ^ 1][0] = fragB0[o]; b[cur ^ 1][1] = fragB1[o];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) a[cur ^ 1][t] = fragA[t][o];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) b[cur ^ 1][t] = fragB[t][o];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -993,8 +1052,9 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
     float* __restrict__ outb = p.out + (long long)split * p.o_bs + (long long)tap * (p.o_tap_stride ? p.o_tap_stride : 1);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + wn0 + tn * 32 + (lane & 31);
-        if (col >= p.NCOLS) continue;
+        const int vcol = n0 + wn0 + tn * 32 + (lane & 31);
+        const int col = (vcol < C1p) ? vcol : C1 + (vcol - C1p);
+        if ((vcol < C1p && vcol >= C1) || col >= p.NCOLS) continue;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -1010,19 +1070,30 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_p
     }
 }
 
+static bool nt_fast_ok(const dp_nt_gemm_params& p) {
+    static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
+    const dp_conv_geom& g = p.g;
+    const int HoWo = g.Ho * g.Wo;
+    return !no_fast && !p.batched && !p.merge && !p.col_bias && g.stride == 1 && g.sden == 1 && g.ups == 0 && g.Wo > 0 &&
+           ((g.Wo % 16) == 0 || (16 % g.Wo) == 0) && (HoWo % 16) == 0 && (p.P % 16) == 0 && (p.p_per_split % 16) == 0 &&
+           g.Hs == g.Hv && g.Ws == g.Wv;
+}
+
 template <int BM, int BN>
 static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
     const int gz = p.batched ? p.batches : p.splits * p.ntaps;
     dim3 grid((p.NCOLS + BN - 1) / BN, (p.M + BM - 1) / BM, gz > 0 ? gz : 1);
     const bool straddle = p.X2 != nullptr && (p.g.c_split % BN) != 0;     // an N-tile may span both concat sources
     if constexpr (BM == 128 && BN == 128) {
-        static const bool no_fast = getenv("DP_NO_FAST") != nullptr;
-        const dp_conv_geom& g = p.g;
-        const int HoWo = g.Ho * g.Wo;
-        if (!no_fast && !p.batched && !p.merge && !straddle && !p.col_bias && g.stride == 1 && g.sden == 1 && g.ups == 0 &&
-            g.Wo > 0 && ((g.Wo % 16) == 0 || (16 % g.Wo) == 0) && (HoWo % 16) == 0 && (p.P % 16) == 0 &&
-            (p.p_per_split % 16) == 0 && g.Hs == g.Hv && g.Ws == g.Wv) {
-            hipLaunchKernelGGL(nt_gemm_fast_kernel, grid, dim3(256), dp_lds_pad(), st, p);
+        if (nt_fast_ok(p)) {
+            const int ncv = p.X2 ? ((p.g.c_split + 3) & ~3) + (p.NCOLS - p.g.c_split) : p.NCOLS;   // virtual columns
+            if (p.tile == 3) {
+                dim3 g96((ncv + 95) / 96, (p.M + 95) / 96, gz > 0 ? gz : 1);
+                hipLaunchKernelGGL(nt_gemm_fast_kernel<3>, g96, dim3(192), dp_lds_pad(), st, p);
+            } else {
+                dim3 g128((ncv + 127) / 128, (p.M + 127) / 128, gz > 0 ? gz : 1);
+                hipLaunchKernelGGL(nt_gemm_fast_kernel<4>, g128, dim3(256), dp_lds_pad(), st, p);
+            }
             return DP_LAUNCH_CHECK();
         }
     }
@@ -1043,6 +1114,7 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
         return DP_LAUNCH_CHECK();
     }
     switch (p.tile) {
+        case 3:                                                  // 96x96: fast kernel only, else as tile 0
         case 0: return launch_nt_gemm<128, 128>(p, st);
         case 1: return launch_nt_gemm<64, 128>(p, st);
         case 2: return launch_nt_gemm<64, 64>(p, st);

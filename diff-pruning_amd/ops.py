@@ -44,27 +44,43 @@ def _run(call, name, flops, abytes=0.0):
     return r
 
 
-def _cg_name(p):
+def _conv_fast_ok(p):
+    """Same rule as conv_fast_ok() in csrc/gemm.hip: the stride-1 / no-upsample loader applies."""
     g = p.g
-    if (p.tile == 0 and not p.a_kc and g.stride == 1 and g.sden == 1 and g.ups == 0 and p.C % 16 == 0 and p.ntaps <= 32
-            and (not p.X2 or g.c_split % 16 == 0) and g.Hs == g.Hv and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST')):
-        return 'conv_gemm_fast_kernel<128, 128>'        # same dispatch rule as launch_conv_gemm (csrc/gemm.hip)
+    return (not p.a_kc and g.stride == 1 and g.sden == 1 and g.ups == 0 and p.ntaps <= 32 and g.Hs == g.Hv
+            and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST'))
+
+
+def _prefer_tile96(p):
+    """Pruned widths (90, 180, ... output channels) waste up to 30 % of a 128-row tile: use the 96x128 fast kernel
+    when it covers M with fewer padded rows."""
+    if p.tile == 0 and p.M > 64 and _conv_fast_ok(p) and -(-p.M // 96) * 96 < -(-p.M // 128) * 128:
+        p.tile = 3
+
+
+def _cg_name(p):
+    if p.tile in (0, 3) and _conv_fast_ok(p):
+        return 'conv_gemm_fast_kernel<%s>' % ('128, 128' if p.tile == 0 else '96, 128')
     straddle = bool(p.X2) and (p.g.c_split % 16) != 0
-    return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[p.tile], 'true' if p.a_kc else 'false',
+    return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[0 if p.tile == 3 else p.tile], 'true' if p.a_kc else 'false',
                                              'true' if straddle else 'false')
 
 
+def _nt_fast_geom_ok(g, P, batched=False, merge=False, col_bias=False):
+    """Same rule as nt_fast_ok() in csrc/gemm.hip (p_per_split is always a multiple of 32 here)."""
+    return (not batched and not merge and not col_bias and g.stride == 1 and g.sden == 1 and g.ups == 0 and g.Wo > 0
+            and (g.Wo % 16 == 0 or 16 % g.Wo == 0) and (g.Ho * g.Wo) % 16 == 0 and P % 16 == 0
+            and g.Hs == g.Hv and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST'))
+
+
 def _nt_name(p):
-    bn = _TILES[p.tile][1]
-    straddle = bool(p.X2) and (p.g.c_split % bn) != 0
     if p.merge:
         return 'nt_gemm_kernel<64, 64, false, true>'
-    g = p.g
-    if (p.tile == 0 and not p.batched and not straddle and not p.col_bias and g.stride == 1 and g.sden == 1 and g.ups == 0
-            and g.Wo > 0 and (g.Wo % 16 == 0 or 16 % g.Wo == 0) and (g.Ho * g.Wo) % 16 == 0 and p.P % 16 == 0
-            and p.p_per_split % 16 == 0 and g.Hs == g.Hv and g.Ws == g.Wv and not os.environ.get('DP_NO_FAST')):
-        return 'nt_gemm_fast_kernel'                      # same dispatch rule as launch_nt_gemm (csrc/gemm.hip)
-    return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[p.tile], 'true' if straddle else 'false')
+    if p.tile in (0, 3) and _nt_fast_geom_ok(p.g, p.P, p.batched, p.merge, bool(p.col_bias)) and p.p_per_split % 16 == 0:
+        return 'nt_gemm_fast_kernel<%d>' % (4 if p.tile == 0 else 3)
+    t = 0 if p.tile == 3 else p.tile
+    straddle = bool(p.X2) and (p.g.c_split % _TILES[t][1]) != 0
+    return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[t], 'true' if straddle else 'false')
 
 
 def _chk_act(x):
@@ -124,7 +140,8 @@ def _conv_ksplit(p, device):
     n_iter = p.ntaps * -(-p.C // 16)
     s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (8 if tiles >= 32 else 2))
     if s >= 2 and p.M >= 64:
-        p.tile = 0 if p.M > 64 else 1
+        if p.tile != 3:
+            p.tile = 0 if p.M > 64 else 1
         p.ksplit = s
         p.ws = _p(_workspace(s * p.M * p.NPIX, device))
 
@@ -196,6 +213,7 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
                 C1 if x2 is not None else Cin, s1, s2)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = Cout, Cin, N * Ho * Wo, spec.k * spec.k, 1
     p.tile = pick_tile(Cout, N * Ho * Wo)
+    _prefer_tile96(p)
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, post_scale
     p.bias = _p(bias)
@@ -229,6 +247,7 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.g = _geom(Hv, Wv, Ho, Wo, Ho, Wo, spec.k, 1, spec.stride, padp, padp, 0, Cout, sd, 0)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = Cin, Cout, N * Hv * Wv, spec.k * spec.k, 1
     p.tile = pick_tile(Cin, N * Hv * Wv)
+    _prefer_tile96(p)
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, 1.0
     p.accumulate = 1 if accumulate else 0
@@ -274,8 +293,16 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
         return _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in)
     # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension
     # (N*Ho*Wo, up to 262144) supplies the parallelism; partial sums are reduced in a fixed order (deterministic).
+    geom = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
+                 C1 if x2 is not None else Cin, s1, s2)
     tile = 0 if Cout > 64 else 1
     bm, bn, _ = _TILES[tile]
+    if tile == 0 and _nt_fast_geom_ok(geom, P):
+        # pruned widths (90, 180, ...): 96x96 tiles when they cover [Cout x Cin] with clearly less padding
+        a96 = (-(-Cout // 96) * 96) * (-(-Cin // 96) * 96)
+        a128 = (-(-Cout // 128) * 128) * (-(-Cin // 128) * 128)
+        if a96 < 0.9 * a128:
+            tile, bm, bn = 3, 96, 96
     tiles = -(-Cout // bm) * -(-Cin // bn) * taps
     splits = max(1, min(WGRAD_BLOCKS // tiles, P // 512 if P >= 1024 else 1))     # floor: never spill into a 2nd round
     if max_splits is not None:
@@ -287,8 +314,7 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
     p.A, p.a_bs, p.a_img_stride = _p(dy), 0, sd
     p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
     p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(dy), _extent_bytes(x), _extent_bytes(x2)
-    p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
-                C1 if x2 is not None else Cin, s1, s2)
+    p.g = geom
     p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, taps, P
     p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, pps, tile, 0
     p.alpha = alpha

@@ -41,7 +41,7 @@ typedef struct dp_conv_gemm_params {
     const float* X1; const float* X2; long long x_bs;
     unsigned a_bytes, x1_bytes, x2_bytes, _pad0;   /* readable extent of A / X1 / X2 (per batch), each < 2 GiB */
     dp_conv_geom g;
-    int M, C, NPIX, ntaps, batches, tile;      /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64 */
+    int M, C, NPIX, ntaps, batches, tile;      /* tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 96x128 (stride-1 fast kernel; else as 0) */
     float* out; long long o_img_stride; long long o_bs;
     float alpha; float post_scale;
     const float* bias; const float* tadd; long long tadd_stride;

@@ -69,6 +69,11 @@ CONV_CASES = [
     ('fast_cat128', 2, 128, 64, 96, 16, 3, 1, 1, 0),
     ('fast_4x4', 20, 64, 0, 80, 4, 3, 1, 1, 0),
     ('fast_w2', 9, 32, 0, 70, 2, 3, 1, 1, 0),
+    ('t96_pruned', 3, 90, 0, 90, 16, 3, 1, 1, 0),
+    ('t96_cat', 2, 180, 90, 180, 8, 3, 1, 1, 0),
+    ('t96_1x1', 4, 359, 0, 180, 8, 1, 1, 0, 0),
+    ('t96_cat_odd', 3, 181, 91, 180, 16, 3, 1, 1, 0),
+    ('nt_straddle', 2, 130, 70, 256, 8, 3, 1, 1, 0),
 ]
 
 
