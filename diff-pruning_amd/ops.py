@@ -52,10 +52,10 @@ def _conv_fast_ok(p):
 
 
 def _prefer_tile96(p):
-    """Pruned widths (90, 180, ... output channels) waste up to 30 % of a 128-row tile: use the 96x128 fast kernel
-    when it covers M with fewer padded rows."""
-    if p.tile == 0 and p.M > 64 and _conv_fast_ok(p) and -(-p.M // 96) * 96 < -(-p.M // 128) * 128:
-        p.tile = 3
+    """Stride-1 convolutions with more than 64 output channels run on the fast kernels; pruned widths (90, 180, ...
+    output channels) waste up to 30 % of a 128-row tile, so the 96x128 variant is taken when it pads fewer rows."""
+    if p.M > 64 and _conv_fast_ok(p):        # the fast kernels beat the smaller general tiles whenever they apply
+        p.tile = 3 if -(-p.M // 96) * 96 < -(-p.M // 128) * 128 else 0
 
 
 def _cg_name(p):
