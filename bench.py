@@ -13,7 +13,7 @@ A "step" is one sweep timestep over one batch.  value = (images processed by all
 ms_per_step is the sweep-only time per timestep.  fp32 everywhere (the reference's dtype).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (conv_gemm_fast_kernel<128,128>: conv3x3/1x1 forward + dgrad), algorithmic FLOP per
+  roofline     dominant kernel (conv_gemm_fast_kernel<128,128,false>: conv3x3/1x1 forward + dgrad), algorithmic FLOP per
                launch / average launch duration, measured with HIP events on the launch stream in an instrumented step
                after the timed region (weight-gradient stream overlap switched off there, so every kernel is timed
                alone), against the 157.3 TFLOP/s fp32 MFMA peak.
@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the timestep from a captured hipGraph')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -98,6 +99,9 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    if args.graph:
+        step.capture()
+        step(0)
     flat.zero_()
     barrier()
     t0 = time.perf_counter()
@@ -180,7 +184,7 @@ def main():
                        'global_batch': world * B, 'image': '3x32x32', 'parallelism': 'dp%d (batch shards)' % world,
                        'sweep_only_images_per_s': imgs / t_sweep, 'tail_ms': (t_total - t_sweep) * 1e3,
                        'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
-                       'wgrad_stream_overlap': bool(step.eng.overlap_wgrad),
+                       'wgrad_stream_overlap': bool(step.eng.overlap_wgrad), 'hipgraph': bool(args.graph),
                        'pruned_groups': len(pr.records), 'params_after': n_params_after,
                        'loss_first_last': [loss_vals[0], loss_vals[-1]]},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -438,8 +438,12 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 //   * LDS destinations (M0) are scalar; fragment reads use the interleaved wave tile (sub-tiles 64 apart), whose
 //     k-step / sub-tile offsets all fit ds_read2st64_b32 immediates -> one address VGPR per operand.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
+#ifndef DP_FAST_MINBLOCKS
+#define DP_FAST_MINBLOCKS 4
+#endif
+// TAILS = false: every chunk is 16 channels wide (C % 16 == 0, split % 16 == 0): the K-tile bookkeeping is one scalar compare.
+template <int BM, int BN, bool TAILS>
+__global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
     // BM = 128: waves 2x2, each 64x64 as interleaved 32x32 sub-tiles (64 apart).  BM = 96 (pruned widths such as 90 or
     // 180 channels lose 30 % of a 128-row tile): waves 1x4, each all 96 rows x 32 columns.
     static_assert((BM == 128 || BM == 96) && BN == 128, "fast path tiles: 128x128, 96x128");
@@ -577,7 +581,9 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_fast_kernel(const dp_conv_ge
         if (kx == g.kw) { kx = 0; ++ky; }
         if (tap == ntaps) {
             tap = 0; ky = 0; kx = 0; ++ch;
-            if (ch < nch) {
+            if constexpr (!TAILS) {
+                if (first && ch == nch1 && ch < nch) { first = false; set_chunk(false, BK); }
+            } else if (ch < nch) {
                 const bool f = ch < nch1;
                 const int w = chunk_width(ch);
                 if (f != first || w != cw) { first = f; cw = w; set_chunk(f, w); }
@@ -644,12 +650,17 @@ static bool conv_fast_ok(const dp_conv_gemm_params& p) {
            g.Ws == g.Wv;
 }
 
+static bool conv_fast_tails(const dp_conv_gemm_params& p) {
+    return (p.C % 16) != 0 || (p.X2 && (p.g.c_split % 16) != 0);
+}
+
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
     if constexpr (BM == 128 && BN == 128) {
         if (conv_fast_ok(p)) {
-            hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128>), grid, dim3(256), dp_lds_pad(), st, p);
+            if (conv_fast_tails(p)) hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
+            else                    hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128, false>), grid, dim3(256), dp_lds_pad(), st, p);
             return DP_LAUNCH_CHECK();
         }
     }
@@ -699,7 +710,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         case 3:                                                  // 96x128: fast kernel only, else the 128x128 path
             if (conv_fast_ok(p)) {
                 dim3 grid((p.NPIX + 127) / 128, (p.M + 95) / 96, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
-                hipLaunchKernelGGL((conv_gemm_fast_kernel<96, 128>), grid, dim3(256), dp_lds_pad(), st, p);
+                hipLaunchKernelGGL((conv_gemm_fast_kernel<96, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
                 e = DP_LAUNCH_CHECK();
                 break;
             }
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(256, 4) void nt_gemm_kernel(const dp_nt_gemm_params
 // Two concat sources with ANY split: the tile columns are *virtual* channels v -- source 1 padded to a multiple of 4
 // (C1p), then source 2 -- so every 4-row DMA group reads one source (scalar descriptor choice), and the epilogue maps
 // v back to the real channel.
-template <int NW>
+template <int NW, bool TWO>
 __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_params p) {
     constexpr int BM = 32 * NW, BN = 32 * NW, BK = 16;
     constexpr int TM = (NW == 4) ? 2 : 1, TN = (NW == 4) ? 2 : 3;
@@ -989,7 +1000,7 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
         for (int j = 0; j < 8; ++j) {
             unsigned o = v ? b_voff[j] : DP_OOB;
             asm volatile("" : "+v"(o));
-            const bool s1 = n0 + 4 * (wave * 8 + j) < C1p;       // scalar: the whole 4-row group is in one source
+            const bool s1 = !TWO || n0 + 4 * (wave * 8 + j) < C1p;      // scalar: the whole 4-row group is in one source
             __builtin_amdgcn_raw_ptr_buffer_load_lds(s1 ? rB1 : rB2, (dp_lds_void*)(Bs + j * GRP), 4, (int)o,
                                                      (int)(s1 ? b_soff1 : b_soff2), 0, 0);
         }
@@ -1089,10 +1100,12 @@ static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
             const int ncv = p.X2 ? ((p.g.c_split + 3) & ~3) + (p.NCOLS - p.g.c_split) : p.NCOLS;   // virtual columns
             if (p.tile == 3) {
                 dim3 g96((ncv + 95) / 96, (p.M + 95) / 96, gz > 0 ? gz : 1);
-                hipLaunchKernelGGL(nt_gemm_fast_kernel<3>, g96, dim3(192), dp_lds_pad(), st, p);
+                if (p.X2) hipLaunchKernelGGL((nt_gemm_fast_kernel<3, true>), g96, dim3(192), dp_lds_pad(), st, p);
+                else      hipLaunchKernelGGL((nt_gemm_fast_kernel<3, false>), g96, dim3(192), dp_lds_pad(), st, p);
             } else {
                 dim3 g128((ncv + 127) / 128, (p.M + 127) / 128, gz > 0 ? gz : 1);
-                hipLaunchKernelGGL(nt_gemm_fast_kernel<4>, g128, dim3(256), dp_lds_pad(), st, p);
+                if (p.X2) hipLaunchKernelGGL((nt_gemm_fast_kernel<4, true>), g128, dim3(256), dp_lds_pad(), st, p);
+                else      hipLaunchKernelGGL((nt_gemm_fast_kernel<4, false>), g128, dim3(256), dp_lds_pad(), st, p);
             }
             return DP_LAUNCH_CHECK();
         }

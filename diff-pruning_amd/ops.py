@@ -19,7 +19,14 @@ def _lib():
     return L.load()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (every launcher takes it).  The raw query is ~20x cheaper on the host than
+    building a torch.cuda.Stream object, and it is called ~1000 times per timestep."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -60,7 +67,8 @@ def _prefer_tile96(p):
 
 def _cg_name(p):
     if p.tile in (0, 3) and _conv_fast_ok(p):
-        return 'conv_gemm_fast_kernel<%s>' % ('128, 128' if p.tile == 0 else '96, 128')
+        tails = p.tile == 3 or p.C % 16 != 0 or (bool(p.X2) and p.g.c_split % 16 != 0)
+        return 'conv_gemm_fast_kernel<%s, %s>' % ('128, 128' if p.tile == 0 else '96, 128', 'true' if tails else 'false')
     straddle = bool(p.X2) and (p.g.c_split % 16) != 0
     return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[0 if p.tile == 3 else p.tile], 'true' if p.a_kc else 'false',
                                              'true' if straddle else 'false')
@@ -77,7 +85,7 @@ def _nt_name(p):
     if p.merge:
         return 'nt_gemm_kernel<64, 64, false, true>'
     if p.tile in (0, 3) and _nt_fast_geom_ok(p.g, p.P, p.batched, p.merge, bool(p.col_bias)) and p.p_per_split % 16 == 0:
-        return 'nt_gemm_fast_kernel<%d>' % (4 if p.tile == 0 else 3)
+        return 'nt_gemm_fast_kernel<%d, %s>' % (4 if p.tile == 0 else 3, 'true' if p.X2 else 'false')
     t = 0 if p.tile == 3 else p.tile
     straddle = bool(p.X2) and (p.g.c_split % _TILES[t][1]) != 0
     return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[t], 'true' if straddle else 'false')
