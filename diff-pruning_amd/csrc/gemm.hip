@@ -10,7 +10,18 @@
 // ds_write_b32 lane group touches 32 distinct banks ([k][m] for m-contiguous operands, [m][BK+1]
 // for k-contiguous ones).
 #include <cstdlib>
+#include <type_traits>
 #include "dp_common.h"
+
+// compile-time unrolled loop: f(std::integral_constant<int, J>) for J in [0, N) -- the LDS-DMA builtins need constant
+// instruction offsets
+template <int J, int N, class F>
+__device__ __forceinline__ void dp_static_for(F&& f) {
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        dp_static_for<J + 1, N>(f);
+    }
+}
 
 // Global -> LDS DMA for the lane-linear tiles of conv_gemm (A/B: same speed on the large shapes, +4..8 % on the 8x8 / 4x4
 // resolution layers, 16 fewer VGPRs -> 5 wavefronts/SIMD); compile with -UDP_LDSDMA ... to get the register-staged path.
@@ -113,6 +124,14 @@ template <int TM, int TN, int TMS, int TNS>
 __device__ __forceinline__ void conv_epilogue(const dp_conv_gemm_params& p, const f32x16 (&acc)[TM][TN], int row0, int col0,
                                               int lane, int z, bool ksplit) {
     const int HoWo = p.g.Ho * p.g.Wo;
+#ifdef DP_EXP_NOEPI      // experiment: price the epilogue (keeps the accumulators alive, stores nothing in practice)
+    {
+        float s = 0.f;
+        for (int tm = 0; tm < TM; ++tm) for (int tn = 0; tn < TN; ++tn) for (int r = 0; r < 16; ++r) s += acc[tm][tn][r];
+        if (s == 1.2345e30f) p.out[0] = s;
+        return;
+    }
+#endif
     if (ksplit) {
         float* __restrict__ wsb = p.ws + (long long)z * p.M * p.NPIX;
 #pragma unroll
@@ -485,7 +504,11 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     const float* __restrict__ Ab = p.A + (long long)zb * p.a_bs;
     const float* __restrict__ X1 = p.X1 + (long long)zb * p.x_bs;
     const float* __restrict__ X2 = p.X2 ? p.X2 + (long long)zb * p.x_bs : X1;
-    const int shift = g.pad_t * g.Ws + g.pad_l;                  // descriptor bases moved back by the padding
+    // descriptor bases moved back by the padding (never-negative scalar offsets) and by IMM_MAX bytes: the 8 B-tile
+    // loads of a lane land 1 KB apart in LDS, so 4 of them share one M0 and differ in the 12-bit instruction offset --
+    // which the hardware adds to the memory address too; the per-lane offsets carry the compensation (IMM_MAX - imm).
+    constexpr unsigned IMM_MAX = 3 * 1024;
+    const int shift = g.pad_t * g.Ws + g.pad_l + (int)(IMM_MAX / 4);
     const __amdgpu_buffer_rsrc_t rA = dp_rsrc(Ab, p.a_bytes);
     const __amdgpu_buffer_rsrc_t r1 = dp_rsrc(X1 - shift, p.x1_bytes + 4u * (unsigned)shift);
     const __amdgpu_buffer_rsrc_t r2 = dp_rsrc(X2 - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
@@ -535,21 +558,33 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     auto set_chunk = [&](bool first, int cw) {
         const unsigned b = first ? b_pix1 : b_pix2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b_voff[j] = (bk0 + 2 * j < cw) ? (b + (unsigned)(2 * j * HsWs)) * 4u : DP_OOB;
+        for (int j = 0; j < 8; ++j)
+            b_voff[j] = (bk0 + 2 * j < cw) ? (b + (unsigned)(2 * j * HsWs)) * 4u + (IMM_MAX - 1024u * (j & 3)) : DP_OOB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) a_voff[j] = (a_k[j] < cw) ? a_base[j] : DP_OOB;
     };
 
-    // ---- scalar K-tile state: chunk ch (16 channels), tap (ky, kx)
+    // ---- scalar K-tile state: chunk ch (16 channels), tap, and the two scalar byte offsets, advanced incrementally
+    //      (every scalar instruction here sits in front of this wave's DMA issue: ~45 of them cost 4 % of the kernel)
     // (uniform integer divisions are expanded on the VALU: pin the results back to SGPRs, or every buffer instruction
     //  that takes them as its scalar offset gets wrapped in a waterfall loop)
     int ch = __builtin_amdgcn_readfirstlane(it0 / ntaps);
     int tap = it0 - ch * ntaps;
-    int ky = __builtin_amdgcn_readfirstlane(tap / g.kw);
-    int kx = tap - ky * g.kw;
+    int kx;
     bool first = ch < nch1;
     int cw = (ch < nch) ? chunk_width(ch) : BK;
     set_chunk(first, cw);
+    const unsigned a_tap_step = (unsigned)C * a_row_bytes;
+    const unsigned b_row_step = (unsigned)(g.Ws - g.kw) * 4u;
+    unsigned a_soff, b_soff;
+    auto chunk_offsets = [&]() {                                 // offsets of (ch, tap): full recompute (rare)
+        const int ky = __builtin_amdgcn_readfirstlane(tap / g.kw);
+        kx = tap - ky * g.kw;
+        const int cbase = first ? ch * BK : C1 + (ch - nch1) * BK;       // first channel of the chunk in the concat order
+        a_soff = (unsigned)(tap * C + cbase) * a_row_bytes;
+        b_soff = (unsigned)(((first ? ch : ch - nch1) * BK) * HsWs + ky * g.Ws + kx) * 4u;
+    };
+    chunk_offsets();
 
     float* const ldsA = smem + 4 * (wave * 64);                 // + buf*STAGE + 1024*j   (float4 per lane)
     float* const ldsB = smem + A_SZ + bk0 * 0 + (wave & 1) * 64 + (wave >> 1) * BN;   // row bk0 = wave>>1, cols (wave&1)*64..
@@ -557,8 +592,6 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     auto dma_tile = [&](int buf) {
         float* As = ldsA + buf * STAGE;
         float* Bs = ldsB + buf * STAGE;
-        const int cbase = first ? ch * BK : C1 + (ch - nch1) * BK;       // first channel of the chunk in the concat order
-        const unsigned a_soff = (unsigned)(tap * C + cbase) * a_row_bytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (256 * j + 64 * wave >= A_F4) continue;          // BM = 96: the second pass belongs to waves 0 and 1 only
@@ -566,21 +599,23 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
         }
-        const unsigned b_soff = (unsigned)(((first ? ch : ch - nch1) * BK) * HsWs + ky * g.Ws + kx) * 4u;
         const bool tv = (vmask >> tap) & 1u;
         const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        dp_static_for<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             unsigned o = tv ? b_voff[j] : DP_OOB;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(Bs + 2 * j * BN), 4, (int)o, (int)b_soff, 0, 0);
-        }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(Bs + 8 * (j >> 2) * BN), 4, (int)o, (int)b_soff,
+                                                     1024 * (j & 3), 0);
+        });
     };
     auto advance = [&]() {                                       // next K tile (chunk outer, tap inner)
         ++tap; ++kx;
-        if (kx == g.kw) { kx = 0; ++ky; }
+        a_soff += a_tap_step;
+        b_soff += 4u;
+        if (kx == g.kw) { kx = 0; b_soff += b_row_step; }
         if (tap == ntaps) {
-            tap = 0; ky = 0; kx = 0; ++ch;
+            tap = 0; ++ch;
             if constexpr (!TAILS) {
                 if (first && ch == nch1 && ch < nch) { first = false; set_chunk(false, BK); }
             } else if (ch < nch) {
@@ -588,6 +623,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
                 const int w = chunk_width(ch);
                 if (f != first || w != cw) { first = f; cw = w; set_chunk(f, w); }
             }
+            chunk_offsets();
         }
     };
 
@@ -610,8 +646,12 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
         for (int it = 0; it < nIter; ++it) {
             const int buf = it & 1;
             // prefetch of tile it+1 (on the last iteration the current tile again: harmless, no predicate needed)
+#ifndef DP_EXP_NOADV
             if (it + 1 < nIter) advance();
+#endif
+#ifndef DP_EXP_NODMA
             dma_tile(buf ^ 1);
+#endif
             const float* Af = fragA + buf * STAGE;
             const float* Bf = fragB + buf * STAGE;
             float a[2][TM], b[2][TN];
@@ -954,8 +994,12 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
 
     const int C1 = p.X2 ? g.c_split : p.NCOLS;                   // channels of source 1
     const int C1p = p.X2 ? ((C1 + 3) & ~3) : p.NCOLS;            // virtual index of source 2's first channel
-    const int shift = g.pad_t * g.Ws + g.pad_l;
-    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(p.A, p.a_bytes);
+    // The 8 DMA groups of a lane are GRP dwords apart in LDS: one M0 per operand, the 12-bit instruction offset picks
+    // the group.  The hardware adds that offset to the memory address too: bases are moved back by IMM_MAX bytes and the
+    // per-lane offsets carry (IMM_MAX - imm).
+    constexpr unsigned IMM_MAX = 7 * GRP * 4;
+    const int shift = g.pad_t * g.Ws + g.pad_l + (int)(IMM_MAX / 4);
+    const __amdgpu_buffer_rsrc_t rA = dp_rsrc(p.A - IMM_MAX / 4, p.a_bytes + IMM_MAX);
     const __amdgpu_buffer_rsrc_t rB1 = dp_rsrc(p.X1 - shift, p.x1_bytes + 4u * (unsigned)shift);
     const __amdgpu_buffer_rsrc_t rB2 = dp_rsrc((p.X2 ? p.X2 : p.X1) - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
 
@@ -969,12 +1013,12 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
     for (int j = 0; j < 8; ++j) {
         const int row = 4 * (wave * 8 + j) + sub;
         const int m = m0 + row;
-        a_voff[j] = (m < p.M) ? (unsigned)((m * HoWo + lk) * 4) : DP_OOB;
+        a_voff[j] = (m < p.M) ? (unsigned)((m * HoWo + lk) * 4) + (IMM_MAX - (unsigned)(j * GRP * 4)) : DP_OOB;
         const int v = n0 + row;                                  // virtual channel -> (source, channel in source)
         const bool s1 = v < C1p;
         const int cs = s1 ? v : v - C1p;
         const bool cv = s1 ? (v < C1) : (C1 + cs < p.NCOLS);
-        b_voff[j] = cv ? (unsigned)((cs * HsWs + (dho + ky) * g.Ws + wol + kx) * 4) : DP_OOB;
+        b_voff[j] = cv ? (unsigned)((cs * HsWs + (dho + ky) * g.Ws + wol + kx) * 4) + (IMM_MAX - (unsigned)(j * GRP * 4)) : DP_OOB;
     }
     float* const ldsW = smem + wave * 8 * GRP;      // this wave's first group, operand A of stage 0
 
@@ -990,20 +1034,20 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
         const bool v = ((unsigned)(ho0 + hc) < (unsigned)g.Hs) && ((unsigned)(wo0 + wc) < (unsigned)g.Ws);
         float* As = ldsW + buf * STAGE;
         float* Bs = As + OP_SZ;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        dp_static_for<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             unsigned o = a_voff[j];
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + j * GRP), 4, (int)o, (int)a_soff, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)As, 4, (int)o, (int)a_soff, j * GRP * 4, 0);
+        });
+        dp_static_for<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             unsigned o = v ? b_voff[j] : DP_OOB;
             asm volatile("" : "+v"(o));
             const bool s1 = !TWO || n0 + 4 * (wave * 8 + j) < C1p;      // scalar: the whole 4-row group is in one source
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(s1 ? rB1 : rB2, (dp_lds_void*)(Bs + j * GRP), 4, (int)o,
-                                                     (int)(s1 ? b_soff1 : b_soff2), 0, 0);
-        }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s1 ? rB1 : rB2, (dp_lds_void*)Bs, 4, (int)o,
+                                                     (int)(s1 ? b_soff1 : b_soff2), j * GRP * 4, 0);
+        });
     };
 
     f32x16 acc[TM][TN];

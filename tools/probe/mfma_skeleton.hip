@@ -5,7 +5,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
-template <bool LDSR, bool BAR, bool DMA>
+template <bool LDSR, bool BAR, bool DMA, bool STREAM = false>
 __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float* out, int iters) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 4096];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -17,14 +17,17 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float
   const int li = lane & 31, lk = lane >> 5;
   const float* fragA = smem + lk * 128 + (wave >> 1) * 32 + li;
   const float* fragB = smem + 2048 + lk * 128 + (wave & 1) * 32 + li;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 24, 0x00020000);
+  // STREAM: every workgroup walks its own 144 x 8 KB slice of a 1.2 GB buffer (B tiles straight from HBM, like the real
+  // kernel's activations); otherwise all reads hit a 4 MB cache-resident window.
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, STREAM ? 0x7fffffff : (1 << 24), 0x00020000);
   unsigned voff4 = (unsigned)(tid * 16), voff = (unsigned)(tid * 4);
   float ra = 1e-9f * tid, rb = 1.f;
   for (int it = 0; it < iters; ++it) {
     const int buf = it & 1;
     if (DMA) {
       float* As = smem + (buf ^ 1) * 4096 + wave * 256;
-      const unsigned soff = (unsigned)(((it * 37 + blockIdx.x) & 255) * 16384);
+      const unsigned soff = STREAM ? (unsigned)(((blockIdx.x & 1023) * 144 + (it % 144)) * 8192u)
+                                   : (unsigned)(((it * 37 + blockIdx.x) & 255) * 16384);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         unsigned o = voff4 + j * 4096; asm volatile("" : "+v"(o));
@@ -59,14 +62,14 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
   out[blockIdx.x * 256 + tid] = s;
 }
-template <bool L, bool B, bool D>
+template <bool L, bool B, bool D, bool S = false>
 void run(const float* src, float* out, const char* name, int blocks) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 144;
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<L, B, D>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    hipLaunchKernelGGL((k<L, B, D, S>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
@@ -76,13 +79,14 @@ void run(const float* src, float* out, const char* name, int blocks) {
 }
 int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
-  float *src, *out; (void)hipMalloc(&src, 1 << 24); (void)hipMemset(src, 0, 1 << 24); (void)hipMalloc(&out, 8192 * 256 * 4);
+  float *src, *out; (void)hipMalloc(&src, 1300u << 20); (void)hipMemset(src, 0, 1300u << 20); (void)hipMalloc(&out, 8192 * 256 * 4);
   for (int blocks : {1024, 2048, 8192}) {
     run<false, false, false>(src, out, "MFMA only", blocks);
     run<true, false, false>(src, out, "+ LDS fragment reads", blocks);
     run<true, true, false>(src, out, "+ LDS reads + barrier", blocks);
     run<true, true, true>(src, out, "+ LDS reads + barrier + global->LDS DMA", blocks);
     run<false, true, true>(src, out, "barrier + DMA, no LDS reads", blocks);
+    run<true, true, true, true>(src, out, "+ LDS + barrier + DMA streaming from HBM", blocks);
   }
   return 0;
 }
