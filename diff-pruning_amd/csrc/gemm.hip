@@ -120,6 +120,64 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 // Epilogue shared by the conv_gemm kernels.  C/D map of a 32x32 MFMA tile: col j = lane&31,
 // row i = (r&3) + 8*(r>>2) + 4*(lane>>5).  Sub-tile (tm, tn) of this wave starts at (row0 + tm*TMS, col0 + tn*TNS).
 // ------------------------------------------------------------------------------------------------
+// One 32x32 sub-tile (16 values per lane), 8 values at a time.  FULL: all 32 rows are < M.  The optional operands are
+// tested once per half sub-tile and the 8 loads of an operand are issued before the first use: a null test plus a
+// load + wait per element made the epilogue a chain of ~64 dependent memory latencies per lane.  Rows >= M (partial
+// tiles) load from a clamped row and skip the store.
+template <bool FULL>
+__device__ __forceinline__ void conv_epilogue_tile(const dp_conv_gemm_params& p, const f32x16& acc, int mrow0, int lane,
+                                                   float* __restrict__ optr, const float* __restrict__ rptr,
+                                                   const float* __restrict__ tptr, int HoWo) {
+    const int mb = mrow0 + 4 * (lane >> 5);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v[8];
+        int mc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            mc[q] = FULL ? m : min(m, p.M - 1);
+            v[q] = p.alpha * acc[r];
+        }
+        if (p.bias) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = p.bias[mc[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+        }
+        if (tptr) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = tptr[mc[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+        }
+        if (rptr) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = rptr[(long long)mc[q] * HoWo];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= p.post_scale;
+        if (p.accumulate) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = optr[(long long)mc[q] * HoWo];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            if (FULL || mb + (r & 3) + 8 * (r >> 2) < p.M) optr[(long long)mc[q] * HoWo] = v[q];
+        }
+    }
+}
+
 template <int TM, int TN, int TMS, int TNS>
 __device__ __forceinline__ void conv_epilogue(const dp_conv_gemm_params& p, const f32x16 (&acc)[TM][TN], int row0, int col0,
                                               int lane, int z, bool ksplit) {
@@ -155,24 +213,14 @@ __device__ __forceinline__ void conv_epilogue(const dp_conv_gemm_params& p, cons
         if (pix >= p.NPIX) continue;
         const int img = pix / HoWo;
         const int r_in = pix - img * HoWo;
-        const long long obase = (long long)img * p.o_img_stride + r_in;
-        const long long rbase = (long long)img * p.r_img_stride + r_in;
-        const long long tbase = (long long)img * p.tadd_stride;
+        float* optr = outb + (long long)img * p.o_img_stride + r_in;
+        const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
+        const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + tm * TMS + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = p.alpha * acc[tm][tn][r];
-                if (p.bias) v += p.bias[m];
-                if (p.tadd) v += p.tadd[tbase + m];
-                if (p.res) v += p.res[rbase + (long long)m * HoWo];
-                v *= p.post_scale;
-                float* o = outb + obase + (long long)m * HoWo;
-                if (p.accumulate) v += *o;
-                *o = v;
-            }
+            const int mrow0 = row0 + tm * TMS;
+            if (mrow0 + 32 <= p.M) conv_epilogue_tile<true>(p, acc[tm][tn], mrow0, lane, optr, rptr, tptr, HoWo);
+            else if (mrow0 < p.M)  conv_epilogue_tile<false>(p, acc[tm][tn], mrow0, lane, optr, rptr, tptr, HoWo);
         }
     }
 }
