@@ -28,6 +28,27 @@ RES_LDM = dict(norm1='.in_layers.0', conv1='.in_layers.2', temb='.emb_layers.1',
                conv2='.out_layers.3', shortcut='.skip_connection')
 
 
+def _low_priority_stream(device):
+    """Side stream for the weight-gradient work at the LOWEST HIP priority: the backward chain on the main stream gets
+    the CUs first, the side stream fills what is left.  torch only exposes priorities <= 0, so the stream is created
+    through the HIP runtime and wrapped; any failure falls back to a plain torch stream."""
+    if os.environ.get('DP_SIDE_PRIORITY', '1') == '0':
+        return torch.cuda.Stream(device=device)
+    try:
+        import ctypes as C
+        hip = C.CDLL('libamdhip64.so')
+        least, greatest = C.c_int(0), C.c_int(0)
+        if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0:
+            raise OSError('hipDeviceGetStreamPriorityRange')
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            if hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), least) != 0:      # 1 = hipStreamNonBlocking
+                raise OSError('hipStreamCreateWithPriority')
+        return torch.cuda.ExternalStream(h.value, device=device)
+    except (OSError, AttributeError, RuntimeError):
+        return torch.cuda.Stream(device=device)
+
+
 class _Packs:
     """Cache of packed (m-contiguous) weight operands, keyed by the identity + version of the source tensor."""
 
@@ -103,7 +124,7 @@ class UNetEngine:
         if not self.overlap_wgrad or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=tensors[0].device)
+            self._side = _low_priority_stream(tensors[0].device)
         self._side.wait_stream(torch.cuda.current_stream())
         for t in tensors:
             if t is not None:
