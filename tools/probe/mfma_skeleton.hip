@@ -5,7 +5,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
-template <bool LDSR, bool BAR, bool DMA, bool STREAM = false>
+template <bool LDSR, bool BAR, bool DMA, bool STREAM = false, bool SAMEA = false>
 __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float* out, int iters) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 4096];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -28,10 +28,11 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float
       float* As = smem + (buf ^ 1) * 4096 + wave * 256;
       const unsigned soff = STREAM ? (unsigned)(((blockIdx.x & 1023) * 144 + (it % 144)) * 8192u)
                                    : (unsigned)(((it * 37 + blockIdx.x) & 255) * 16384);
+      const unsigned soffA = SAMEA ? (unsigned)((it % 144) * 8192u) : soff;   // SAMEA: every workgroup reads the same A tile
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         unsigned o = voff4 + j * 4096; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(As + 1024 * j), 16, (int)o, (int)soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(As + 1024 * j), 16, (int)o, (int)soffA, 0, 0);
       }
       float* Bs = smem + (buf ^ 1) * 4096 + 2048 + (wave & 1) * 64 + (wave >> 1) * 128;
 #pragma unroll
@@ -62,14 +63,14 @@ __global__ __launch_bounds__(256, 4) void k(const float* __restrict__ src, float
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
   out[blockIdx.x * 256 + tid] = s;
 }
-template <bool L, bool B, bool D, bool S = false>
+template <bool L, bool B, bool D, bool S = false, bool SA = false>
 void run(const float* src, float* out, const char* name, int blocks) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 144;
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<L, B, D, S>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    hipLaunchKernelGGL((k<L, B, D, S, SA>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
@@ -87,6 +88,7 @@ int main() {
     run<true, true, true>(src, out, "+ LDS reads + barrier + global->LDS DMA", blocks);
     run<false, true, true>(src, out, "barrier + DMA, no LDS reads", blocks);
     run<true, true, true, true>(src, out, "+ LDS + barrier + DMA streaming from HBM", blocks);
+    run<true, true, true, true, true>(src, out, "  same, A tile shared by all workgroups", blocks);
   }
   return 0;
 }
