@@ -59,6 +59,9 @@ SIGNATURES = {
     'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _vp],
     'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
                               _vp, _ll, _vp, _vp],
+    'dp_groupnorm_silu_fwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp, _vp],
+    'dp_groupnorm_silu_bwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
+                                    _vp, _ll, _vp, _i, _vp, _vp],
     'dp_colsum_accum': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     'dp_rowsum_nc': [_vp, _ll, _i, _i, _i, _vp, _vp],
     'dp_silu_fwd': [_vp, _vp, _ll, _vp],

@@ -381,6 +381,211 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     return DP_LAUNCH_CHECK();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split GroupNorm for FEW, LARGE groups (256x256 images at batch 4: N*G = 128 groups of 1 MB -- one workgroup per group
+// leaves half of the CUs idle and the rest latency bound).  Work unit = one slice of one channel plane:
+//   forward : part  -> (slice mean, slice M2)            combine (Chan's parallel variance, fixed order) -> stats
+//             apply -> y = silu?((x - mean) * rstd * gamma + beta)
+//   backward: part  -> (sum dy, sum dy*xhat) per slice   combine -> pws[n][c] and the group terms a, b
+//             apply -> dx
+// All vec4 (HW % 4 == 0, 16-byte aligned planes); slice length = HW / S floats, a multiple of 4.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_split_part_fwd_kernel(GnSrc src, int C, int HW, int S, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int nc = blockIdx.x, sl = blockIdx.y;
+    const int n = nc / C, c = nc - n * C;
+    const int len4 = HW / S / 4;
+    const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < len4; i += 256) { const float4 v = xp[i]; s += (v.x + v.y) + (v.z + v.w); }
+    const float mean = dp_block_sum_256(s, red) / (float)(len4 * 4);
+    float q = 0.f;
+    for (int i = threadIdx.x; i < len4; i += 256) {
+        const float4 v = xp[i];
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+    }
+    q = dp_block_sum_256(q, red);
+    if (threadIdx.x == 0) {
+        part[((long long)nc * S + sl) * 2 + 0] = mean;
+        part[((long long)nc * S + sl) * 2 + 1] = q;
+    }
+}
+
+// one thread per (n, group): combine the cpg*S equally sized slices in ascending order
+__global__ void gn_split_combine_fwd_kernel(const float* __restrict__ part, int NG, int cpg, int S, int HW, float eps,
+                                            float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    const float* p = part + (long long)i * cpg * S * 2;
+    const float cnt = (float)(HW / S);
+    float mean = p[0], m2 = p[1], k = 1.f;
+    for (int j = 1; j < cpg * S; ++j) {
+        const float d = p[2 * j] - mean;
+        k += 1.f;
+        mean += d / k;
+        m2 += p[2 * j + 1] + d * d * cnt * (k - 1.f) / k;
+    }
+    stats[(long long)i * 2 + 0] = mean;
+    stats[(long long)i * 2 + 1] = 1.0f / sqrtf(m2 / (cnt * k) + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_split_apply_fwd_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int C, int HW, int G, int S,
+                                                                 int silu, const float* __restrict__ stats,
+                                                                 float* __restrict__ y, long long y_img_stride) {
+    const int nc = blockIdx.x, sl = blockIdx.y;
+    const int n = nc / C, c = nc - n * C;
+    const int g = c / (C / G);
+    const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    const int len4 = HW / S / 4;
+    const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
+    float4* yp = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c * HW) + (long long)sl * len4;
+    for (int i = threadIdx.x; i < len4; i += 256) {
+        const float4 v = xp[i];
+        float4 o;
+        o.x = (v.x - mean) * rstd * ga + be; o.y = (v.y - mean) * rstd * ga + be;
+        o.z = (v.z - mean) * rstd * ga + be; o.w = (v.w - mean) * rstd * ga + be;
+        if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+        yp[i] = o;
+    }
+}
+
+extern "C" int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride,
+                                           long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
+                                           int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
+                                           int slices, float* ws, void* stream) {
+    if (N <= 0 || C <= 0) return 0;
+    if (C % G || slices <= 0 || HW % (4 * slices) || !ws) return (int)hipErrorInvalidValue;
+    if (((x1_img_stride | x2_img_stride | y_img_stride) % 4) || (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16))
+        return (int)hipErrorInvalidValue;
+    GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_split_part_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, C, HW, slices, ws);
+    hipLaunchKernelGGL(gn_split_combine_fwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, N * G, C / G, slices, HW, eps,
+                       stats);
+    hipLaunchKernelGGL(gn_split_apply_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, C, HW, G, slices, silu,
+                       stats, y, y_img_stride);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void gn_split_part_bwd_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ stats,
+                                                                const float* __restrict__ dz, long long dz_img_stride, int C,
+                                                                int HW, int G, int S, int silu, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int nc = blockIdx.x, sl = blockIdx.y;
+    const int n = nc / C, c = nc - n * C;
+    const int g = c / (C / G);
+    const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    const int len4 = HW / S / 4;
+    const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
+    const float4* dp = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c * HW) + (long long)sl * len4;
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < len4; i += 256) {
+        const float4 xv = xp[i];
+        float4 d = dp[i];
+        const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+        if (silu) {
+            d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
+            d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+        }
+        a1 += (d.x + d.y) + (d.z + d.w);
+        a2 += (d.x * hx + d.y * hy) + (d.z * hz + d.w * hw);
+    }
+    a1 = dp_block_sum_256(a1, red);
+    a2 = dp_block_sum_256(a2, red);
+    if (threadIdx.x == 0) {
+        part[((long long)nc * S + sl) * 2 + 0] = a1;
+        part[((long long)nc * S + sl) * 2 + 1] = a2;
+    }
+}
+
+// one thread per (n, group): channel sums -> pws, group terms a/M, b/M -> ab[(n*G+g)*2]
+__global__ void gn_split_combine_bwd_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int NG, int G,
+                                            int C, int S, int HW, float* __restrict__ pws, float* __restrict__ ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    const int cpg = C / G;
+    const int n = i / G, g = i - n * G;
+    float a = 0.f, b = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const int c = g * cpg + cl;
+        const float* p = part + ((long long)n * C + c) * S * 2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < S; ++j) { s1 += p[2 * j]; s2 += p[2 * j + 1]; }
+        pws[((long long)n * C + c) * 2 + 0] = s1;
+        pws[((long long)n * C + c) * 2 + 1] = s2;
+        a += gamma[c] * s1;
+        b += gamma[c] * s2;
+    }
+    const float invM = 1.0f / (float)(cpg * HW);
+    ab[(long long)i * 2 + 0] = a * invM;
+    ab[(long long)i * 2 + 1] = b * invM;
+}
+
+__global__ __launch_bounds__(256) void gn_split_apply_bwd_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ stats,
+                                                                 const float* __restrict__ ab, const float* __restrict__ dz,
+                                                                 long long dz_img_stride, int C, int HW, int G, int S, int silu,
+                                                                 float* __restrict__ dx, long long dx_img_stride,
+                                                                 const float* __restrict__ add1, long long add1_s,
+                                                                 const float* __restrict__ add2, long long add2_s) {
+    const int nc = blockIdx.x, sl = blockIdx.y;
+    const int n = nc / C, c = nc - n * C;
+    const int g = c / (C / G);
+    const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
+    const float a = ab[((long long)n * G + g) * 2 + 0], b = ab[((long long)n * G + g) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    const int len4 = HW / S / 4;
+    const long long off4 = (long long)sl * len4;
+    const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + off4;
+    const float4* dp = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c * HW) + off4;
+    float4* op = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c * HW) + off4;
+    const float4* a1p = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c * HW) + off4 : nullptr;
+    const float4* a2p = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c * HW) + off4 : nullptr;
+    for (int i = threadIdx.x; i < len4; i += 256) {
+        const float4 xv = xp[i];
+        float4 d = dp[i];
+        const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+        if (silu) {
+            d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
+            d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+        }
+        float4 v;
+        v.x = rstd * (ga * d.x - a - hx * b); v.y = rstd * (ga * d.y - a - hy * b);
+        v.z = rstd * (ga * d.z - a - hz * b); v.w = rstd * (ga * d.w - a - hw * b);
+        if (a1p) { const float4 t = a1p[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (a2p) { const float4 t = a2p[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        op[i] = v;
+    }
+}
+
+extern "C" int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride,
+                                           long long x2_img_stride, const float* gamma, const float* beta, const float* stats,
+                                           const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
+                                           float* dx, long long dx_img_stride, const float* add1, long long add1_img_stride,
+                                           const float* add2, long long add2_img_stride, float* pws, int slices, float* ws,
+                                           void* stream) {
+    if (N <= 0 || C <= 0) return 0;
+    if (C % G || slices <= 0 || HW % (4 * slices) || !ws) return (int)hipErrorInvalidValue;
+    if (((x1_img_stride | x2_img_stride | dz_img_stride | dx_img_stride | add1_img_stride | add2_img_stride) % 4) ||
+        (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)add1 | (uintptr_t)add2) % 16))
+        return (int)hipErrorInvalidValue;
+    GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
+    hipStream_t st = (hipStream_t)stream;
+    float* ab = ws + (long long)N * C * slices * 2;               // ws: [N*C*slices*2] partials, then [N*G*2] group terms
+    hipLaunchKernelGGL(gn_split_part_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, dz, dz_img_stride,
+                       C, HW, G, slices, silu, ws);
+    hipLaunchKernelGGL(gn_split_combine_bwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, gamma, N * G, G, C, slices, HW,
+                       pws, ab);
+    hipLaunchKernelGGL(gn_split_apply_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, ab, dz,
+                       dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride);
+    return DP_LAUNCH_CHECK();
+}
+
 // out[c] (+)= sum_n ws[(n*C + c)*wstride + woff].  64 channels per workgroup (coalesced across lanes), the rows are
 // split over the 4 wavefronts and combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ ws, int N, int C, int wstride, int woff,

@@ -512,6 +512,21 @@ def linear_wgrad(dy, x, gw, alpha=1.0, accumulate=True):
 # --------------------------------------------------------------------------------------------------
 # normalisation / elementwise
 # --------------------------------------------------------------------------------------------------
+GN_SPLIT_GROUPS = 1024       # fewer (n, group) pairs than this and planes >= 1024 pixels: slice the channel planes
+
+
+def _gn_slices(N, G, HW, tensors, strides):
+    """Number of slices per channel plane for the split GroupNorm path, or 0 for the one-workgroup-per-group kernels."""
+    if GN_SPLIT_GROUPS <= 0 or N * G >= GN_SPLIT_GROUPS or HW < 1024 or HW % 4:
+        return 0
+    if any(t is not None and t.data_ptr() % 16 for t in tensors) or any(s % 4 for s in strides):
+        return 0
+    s = 1
+    while s < 32 and HW // (2 * s) >= 4096 and HW % (8 * s) == 0:
+        s *= 2
+    return s
+
+
 def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None):
     s1 = _chk_act(x)
     N, C1, H, W = x.shape
@@ -523,8 +538,16 @@ def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None):
     if out is None:
         out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
     stats = torch.empty((N * G, 2), dtype=_f32, device=x.device)
+    so = _chk_act(out)
+    sl = _gn_slices(N, G, H * W, (x, x2, out), (s1, s2, so))
+    if sl:
+        ws = _workspace(N * Cc * sl * 2, x.device)
+        L.check(_lib().dp_groupnorm_silu_fwd_split(_p(x), _p(x2), C1, s1, s2, _p(gamma), _p(beta), N, Cc, H * W, G, eps,
+                                                   1 if silu else 0, _p(out), so, _p(stats), sl, _p(ws), _stream()),
+                'dp_groupnorm_silu_fwd_split')
+        return out, stats
     L.check(_lib().dp_groupnorm_silu_fwd(_p(x), _p(x2), C1, s1, s2, _p(gamma), _p(beta), N, Cc, H * W, G, eps,
-                                         1 if silu else 0, _p(out), _chk_act(out), _p(stats), _stream()),
+                                         1 if silu else 0, _p(out), so, _p(stats), _stream()),
             'dp_groupnorm_silu_fwd')
     return out, stats
 
@@ -541,6 +564,17 @@ def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=Non
     if out is None:
         out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
     pws = torch.empty((N, Cc, 2), dtype=_f32, device=x.device)
+    sd, so = _chk_act(dz), _chk_act(out)
+    sa1 = _chk_act(add1) if add1 is not None else 0
+    sa2 = _chk_act(add2) if add2 is not None else 0
+    sl = _gn_slices(N, G, H * W, (x, x2, dz, out, add1, add2), (s1, s2, sd, so, sa1, sa2))
+    if sl:
+        ws = _workspace(N * Cc * sl * 2 + N * G * 2, x.device)
+        L.check(_lib().dp_groupnorm_silu_bwd_split(_p(x), _p(x2), C1, s1, s2, _p(gamma), _p(beta), _p(stats), _p(dz), sd,
+                                                   N, Cc, H * W, G, 1 if silu else 0, _p(out), so, _p(add1), sa1,
+                                                   _p(add2), sa2, _p(pws), sl, _p(ws), _stream()),
+                'dp_groupnorm_silu_bwd_split')
+        return out, pws
     L.check(_lib().dp_groupnorm_silu_bwd(_p(x), _p(x2), C1, s1, s2, _p(gamma), _p(beta), _p(stats), _p(dz), _chk_act(dz),
                                          N, Cc, H * W, G, 1 if silu else 0, _p(out), _chk_act(out),
                                          _p(add1), (_chk_act(add1) if add1 is not None else 0),

@@ -109,6 +109,19 @@ int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long lo
                           const float* add1, long long add1_img_stride, const float* add2, long long add2_img_stride,
                           float* pws, void* stream);
 
+/* The same two operations for FEW, LARGE groups (e.g. 256x256 images at batch 4: N*G = 128 groups of 1 MB): the work unit
+ * is one of `slices` equal slices of one channel plane, partial statistics go through ws and are combined in a fixed
+ * order (Chan's parallel variance in the forward).  Requires HW % (4*slices) == 0 and 16-byte aligned planes.
+ * ws: forward >= N*C*slices*2 floats, backward >= N*C*slices*2 + N*G*2 floats. */
+int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
+                                const float* gamma, const float* beta, int N, int C, int HW, int G, float eps, int silu,
+                                float* y, long long y_img_stride, float* stats, int slices, float* ws, void* stream);
+int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
+                                const float* gamma, const float* beta, const float* stats, const float* dz,
+                                long long dz_img_stride, int N, int C, int HW, int G, int silu, float* dx,
+                                long long dx_img_stride, const float* add1, long long add1_img_stride, const float* add2,
+                                long long add2_img_stride, float* pws, int slices, float* ws, void* stream);
+
 /* out[c*ostride] (+)= sum_n ws[(n*C + c)*wstride + woff]   (deterministic, n ascending) */
 int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate, void* stream);
 

@@ -219,7 +219,8 @@ def test_bmm_variants(ops, report, Z, M, K, N):
 
 
 @pytest.mark.parametrize('N,C1,C2,H,G,silu', [(2, 32, 0, 8, 8, True), (3, 128, 0, 32, 32, True), (2, 100, 92, 4, 32, True),
-                                             (2, 64, 0, 16, 32, False), (1, 128, 0, 128, 32, True), (2, 32, 0, 3, 8, True)])
+                                             (2, 64, 0, 16, 32, False), (1, 128, 0, 128, 32, True), (2, 32, 0, 3, 8, True),
+                                             (2, 48, 80, 64, 16, True), (1, 20, 44, 32, 8, True), (2, 64, 0, 256, 32, False)])
 def test_groupnorm(ops, report, N, C1, C2, H, G, silu):
     xa = rnd(N, C1, H, H, seed=1) + 0.3
     xb = rnd(N, C2, H, H, seed=2) if C2 else None
