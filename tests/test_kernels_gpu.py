@@ -275,6 +275,9 @@ def test_softmax_silu_misc(ops, report):
     a = rnd(4, 6, 8, 8, seed=7)
     rows = ops.rowsum_nc(a[:, 1:5])
     e6 = relerr(rows, a[:, 1:5].double().cpu().sum((2, 3)))
+    for shp, sl in (((3, 5, 64, 64), slice(1, 4)), ((2, 3, 67, 67), slice(0, 3)), ((2, 4, 5, 3), slice(1, 3))):
+        b = rnd(*shp, seed=17)          # workgroup-per-plane / unaligned / tiny planes
+        e6 = max(e6, relerr(ops.rowsum_nc(b[:, sl]), b[:, sl].double().cpu().sum((2, 3))))
     up = rnd(2, 3, 8, 8, seed=8)
     e7 = relerr(ops.downsum2x2(up), F.avg_pool2d(up.double().cpu(), 2) * 4)
     y = rnd(300, seed=9)
