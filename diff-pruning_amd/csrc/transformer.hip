@@ -4,64 +4,94 @@
 // Reference: ldm_exp/ldm/modules/attention.py:37-46 (GEGLU), :196-212 (BasicTransformerBlock LayerNorms).
 #include "dp_common.h"
 
-// stats[(n*T + t)*2 + {0,1}] = {mean, rstd} over the C channels of token t
+// stats[(n*T + t)*2 + {0,1}] = {mean, rstd} over the C channels of token t.
+// Workgroup = 64 consecutive tokens x 4 channel groups (wavefront w walks channels w, w+4, ...): every access is a
+// contiguous 256-byte run of tokens, the channel loop is 4x shorter and carries two independent load streams per lane
+// (one thread per token with 3 serial passes over up to 960 channels was latency bound: 31 % of an LDM step).
+// Variance in one pass around the token's first channel as the shift (stable: the shifted mean is small).
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long x_img_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int N,
                                                      int C, int T, float eps, float* __restrict__ y, long long y_img_stride,
                                                      float* __restrict__ stats) {
-    const long long tok = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tok >= (long long)N * T) return;
-    const int n = (int)(tok / T);
-    const int t = (int)(tok - (long long)n * T);
+    __shared__ float r1[4][64], r2[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const long long tok = (long long)blockIdx.x * 64 + tl;
+    const bool valid = tok < (long long)N * T;
+    const long long tk = valid ? tok : 0;
+    const int n = (int)(tk / T);
+    const int t = (int)(tk - (long long)n * T);
     const float* xp = x + (long long)n * x_img_stride + t;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += xp[(long long)c * T];
-    const float mean = s / (float)C;
-    float q = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = xp[(long long)c * T] - mean;
-        q += d * d;
+    const float k = xp[0];
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int c = cg;
+    for (; c + 4 < C; c += 8) {
+        const float v0 = xp[(long long)c * T] - k, v1 = xp[(long long)(c + 4) * T] - k;
+        s0 += v0; q0 += v0 * v0;
+        s1 += v1; q1 += v1 * v1;
     }
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    stats[tok * 2 + 0] = mean;
-    stats[tok * 2 + 1] = rstd;
+    if (c < C) { const float v0 = xp[(long long)c * T] - k; s0 += v0; q0 += v0 * v0; }
+    r1[cg][tl] = s0 + s1;
+    r2[cg][tl] = q0 + q1;
+    __syncthreads();
+    const float ms = ((r1[0][tl] + r1[1][tl]) + (r1[2][tl] + r1[3][tl])) / (float)C;
+    const float var = fmaxf(((r2[0][tl] + r2[1][tl]) + (r2[2][tl] + r2[3][tl])) / (float)C - ms * ms, 0.f);
+    const float mean = k + ms;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!valid) return;
+    if (cg == 0) {
+        stats[tok * 2 + 0] = mean;
+        stats[tok * 2 + 1] = rstd;
+    }
     float* yp = y + (long long)n * y_img_stride + t;
-    for (int c = 0; c < C; ++c) yp[(long long)c * T] = (xp[(long long)c * T] - mean) * rstd * gamma[c] + beta[c];
+    for (c = cg; c < C; c += 4) yp[(long long)c * T] = (xp[(long long)c * T] - mean) * rstd * gamma[c] + beta[c];
 }
 
 extern "C" int dp_layernorm_fwd(const float* x, long long x_img_stride, const float* gamma, const float* beta, int N, int C,
                                 int T, float eps, float* y, long long y_img_stride, float* stats, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, gamma, beta, N, C, T, eps, y, y_img_stride, stats);
     return DP_LAUNCH_CHECK();
 }
 
-// dx = rstd * (gamma*dy - mean_c(gamma*dy) - xhat * mean_c(gamma*dy*xhat))  (+ add)
+// dx = rstd * (gamma*dy - mean_c(gamma*dy) - xhat * mean_c(gamma*dy*xhat))  (+ add)      (same 64 x 4 decomposition)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long long x_img_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
                                                      const float* __restrict__ dy, long long dy_img_stride, int N, int C,
                                                      int T, float* __restrict__ dx, long long dx_img_stride,
                                                      const float* __restrict__ add, long long add_img_stride) {
-    const long long tok = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tok >= (long long)N * T) return;
-    const int n = (int)(tok / T);
-    const int t = (int)(tok - (long long)n * T);
-    const float mean = stats[tok * 2 + 0], rstd = stats[tok * 2 + 1];
+    __shared__ float r1[4][64], r2[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const long long tok = (long long)blockIdx.x * 64 + tl;
+    const bool valid = tok < (long long)N * T;
+    const long long tk = valid ? tok : 0;
+    const int n = (int)(tk / T);
+    const int t = (int)(tk - (long long)n * T);
+    const float mean = stats[tk * 2 + 0], rstd = stats[tk * 2 + 1];
     const float* xp = x + (long long)n * x_img_stride + t;
     const float* dp = dy + (long long)n * dy_img_stride + t;
-    float a = 0.f, b = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float gd = gamma[c] * dp[(long long)c * T];
-        a += gd;
-        b += gd * ((xp[(long long)c * T] - mean) * rstd);
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int c = cg;
+    for (; c + 4 < C; c += 8) {
+        const float g0 = gamma[c] * dp[(long long)c * T], g1 = gamma[c + 4] * dp[(long long)(c + 4) * T];
+        const float h0 = (xp[(long long)c * T] - mean) * rstd, h1 = (xp[(long long)(c + 4) * T] - mean) * rstd;
+        a0 += g0; b0 += g0 * h0;
+        a1 += g1; b1 += g1 * h1;
     }
-    a /= (float)C;
-    b /= (float)C;
+    if (c < C) {
+        const float g0 = gamma[c] * dp[(long long)c * T];
+        a0 += g0; b0 += g0 * ((xp[(long long)c * T] - mean) * rstd);
+    }
+    r1[cg][tl] = a0 + a1;
+    r2[cg][tl] = b0 + b1;
+    __syncthreads();
+    const float a = ((r1[0][tl] + r1[1][tl]) + (r1[2][tl] + r1[3][tl])) / (float)C;
+    const float b = ((r2[0][tl] + r2[1][tl]) + (r2[2][tl] + r2[3][tl])) / (float)C;
+    if (!valid) return;
     float* op = dx + (long long)n * dx_img_stride + t;
     const float* ap = add ? add + (long long)n * add_img_stride + t : nullptr;
-    for (int c = 0; c < C; ++c) {
+    for (c = cg; c < C; c += 4) {
         const float xh = (xp[(long long)c * T] - mean) * rstd;
         float v = rstd * (gamma[c] * dp[(long long)c * T] - a - xh * b);
         if (ap) v += ap[(long long)c * T];
@@ -99,7 +129,7 @@ extern "C" int dp_layernorm_bwd(const float* x, long long x_img_stride, const fl
                                 long long dx_img_stride, const float* add, long long add_img_stride, float* pws, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, gamma, stats, dy, dy_img_stride, N, C, T, dx, dx_img_stride, add, add_img_stride);
     int e = DP_LAUNCH_CHECK();
     if (e) return e;
