@@ -28,6 +28,43 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(L.ConvGeom) == 14 * 4 + 2 * 8
 
 
+def test_kernel_dispatch_heuristics():
+    """Host-side dispatch rules of ops.py (pure arithmetic, no device): GroupNorm slicing, 96-row tiles for pruned
+    widths, split-K of small grids."""
+    ops = pkg('ops')
+    L = pkg('_lib')
+
+    class T:                                    # stand-in with the two attributes _gn_slices reads
+        def __init__(self, ptr=0):
+            self._p = ptr
+
+        def data_ptr(self):
+            return self._p
+    assert ops._gn_slices(256, 32, 1024, (T(),), (4,)) == 0            # CIFAR batch 256: plenty of groups
+    assert ops._gn_slices(4, 32, 65536, (T(), None), (4, 0)) == 16     # bedroom-256 batch 4: 16 slices of 4096 pixels
+    assert ops._gn_slices(6, 32, 4096, (T(),), (4,)) == 1              # LDM latents: one slice per channel plane
+    assert ops._gn_slices(4, 32, 65536, (T(8),), (4,)) == 0            # misaligned plane -> generic kernels
+    assert ops._gn_slices(2, 8, 256, (T(),), (4,)) == 0                # small planes stay on the per-group kernel
+
+    def conv_params(M, C=128, npix=4096, taps=9, stride=1, ups=0):
+        p = L.ConvGemmParams()
+        p.g = ops._geom(16, 16, 16, 16, 16 << ups, 16 << ups, 3, stride, 1, 1, 1, ups, C, 0, 0)
+        p.M, p.C, p.NPIX, p.ntaps, p.batches, p.a_kc, p.tile = M, C, npix, taps, 1, 0, 0
+        return p
+    for M, want in ((90, 3), (180, 3), (128, 0), (256, 0), (359, 0), (64, 0)):
+        p = conv_params(M)
+        p.tile = ops.pick_tile(M, p.NPIX)
+        before = p.tile
+        ops._prefer_tile96(p)
+        assert p.tile == (want if M > 64 else before), (M, p.tile)
+    p = conv_params(90, stride=2)               # strided conv: general kernel keeps its tile
+    p.tile = 1
+    ops._prefer_tile96(p)
+    assert p.tile == 1
+    assert ops._cg_name(conv_params(256)) == 'conv_gemm_fast_kernel<128, 128, false>'
+    assert ops._cg_name(conv_params(256, C=90)) == 'conv_gemm_fast_kernel<128, 128, true>'
+
+
 def test_no_cpu_fallback():
     """The product refuses to run its hot path off-device instead of silently falling back."""
     unet = pkg('unet')
