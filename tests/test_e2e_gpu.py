@@ -190,6 +190,44 @@ def test_cifar_c1_masks_bit_exact(report):
     assert sum(p.numel() for p in model.parameters()) == 19851157
 
 
+def test_full_size_determinism_and_shard_linearity(report):
+    """BASELINE.json configs[1] at its full size (CIFAR-10 UNet, batch 256), through size-independent properties:
+    (a) the sweep is run-to-run bit-identical (fixed-order reductions, also with the weight-gradient stream),
+    (b) gradients are linear in the batch shards: two 128-image shards, each scaled for the global batch exactly as the
+        data-parallel path scales them, sum to the full-batch gradients (the property the one all-reduce relies on),
+    (c) the prune masks from the summed shard gradients equal the full-batch masks, group by group."""
+    sweep, diffusion = pkg('sweep'), pkg('diffusion')
+    cfg, B, steps = gc.CIFAR_CFG, 256, 2
+    clean, noise = _inputs(B, 32, 11, 12)
+    clean, noise = clean.to(DEV), noise.to(DEV)
+    sched = diffusion.DDPMScheduler()
+
+    def run(lo, hi):
+        model = make_model(cfg, 0)
+        flat = sweep.flatten_grads(model)
+        step = sweep.HipSweepStep(model, sched, clean[lo:hi], noise[lo:hi], B * clean[0].numel(), 'mse', B)
+        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=steps, step_fn=step, flat_grads=flat)
+        torch.cuda.synchronize()
+        return model, flat, res['losses']
+
+    m_full, g_full, l_full = run(0, B)
+    m_again, g_again, l_again = run(0, B)
+    assert torch.equal(g_full, g_again) and l_full == l_again                 # (a)
+    del m_again, g_again
+    m1, g1, l1 = run(0, B // 2)
+    m2, g2, l2 = run(B // 2, B)
+    e_loss = max(abs((a + b) - c) / c for a, b, c in zip(l1, l2, l_full))
+    e_grad = relerr(g1 + g2, g_full)
+    g1.add_(g2)                                                               # what the all-reduce leaves on every rank
+    pr_full = sweep.prune_model(m_full, 0.3)
+    pr_sum = sweep.prune_model(m1, 0.3)
+    mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
+    report['e2e/full_size'] = dict(loss_rel=e_loss, shard_grad_rel=e_grad, groups=len(pr_full.records), mask_mismatches=mism)
+    assert e_loss < 1e-5 and e_grad < 2e-5                                    # (b): fp32 re-association only
+    assert len(pr_full.records) == len(pr_sum.records) == 50 and not mism     # (c)
+    assert sum(p.numel() for p in m_full.parameters()) == sum(p.numel() for p in m1.parameters())
+
+
 def test_autograd_bridge_and_finetune_step(report):
     """`loss.backward()` through the one-node autograd bridge equals the sweep engine; one finetune step equals the
     oracle's clip+Adam+EMA arithmetic."""
