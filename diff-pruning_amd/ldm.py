@@ -158,6 +158,13 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(nn.GroupNorm(32, model_channels), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._engine = None
 
+    def __getstate__(self):
+        """Whole-module pickles (`torch.save(model, 'unet_pruned.pth')`, ddpm_prune.py:135) carry parameters and shapes
+        only: the HIP engine (packed operands, streams) is rebuilt on first use after loading."""
+        state = dict(self.__dict__)
+        state['_engine'] = None
+        return state
+
     @property
     def device(self):
         return self.out[2].weight.device

@@ -164,8 +164,9 @@ class Dependency:
 class Group:
     """Iterates as (dep, idxs), root first (dependency.py:143-191)."""
 
-    def __init__(self, items):
+    def __init__(self, items, dg=None):
         self._items = items
+        self._DG = dg
 
     def __iter__(self):
         return iter(self._items)
@@ -176,9 +177,16 @@ class Group:
     def __getitem__(self, k):
         return self._items[k]
 
-    def prune(self):
-        for dep, idxs in self._items:
-            dep(idxs)
+    def prune(self, idxs=None, record_history=True):
+        """dependency.py:160-188: prune every member; the root goes into the graph's replayable pruning history as
+        [root module name, is_out_channel_pruning, root indices]."""
+        if idxs is not None:
+            raise NotImplementedError('re-indexing an enumerated group: ask the graph for get_pruning_group(module, fn, idxs)')
+        for dep, ix in self._items:
+            dep(ix)
+        if record_history and self._DG is not None and self._items:
+            root, ridx = self._items[0]
+            self._DG._pruning_history.append([root.target.name, root.kind != 'in', [int(i) for i in ridx]])
 
     def details(self):
         return ['%s:%s(%d)' % (dep.kind, dep.target.name, len(idxs)) for dep, idxs in self._items]
@@ -447,13 +455,28 @@ class DependencyGraph:
         self.graph = LdmGraph(cfg) if 'model_channels' in cfg else UNetGraph(cfg)
         self.name2module = dict(model.named_modules())
         self.module2name = {m: n for n, m in self.name2module.items()}
+        self._pruning_history = []
+
+    def pruning_history(self):
+        """dependency.py:278-279: [[root module name, is_out_channel_pruning, idxs], ...] in application order."""
+        return self._pruning_history
+
+    def load_pruning_history(self, pruning_history):
+        """dependency.py:281-293: replay a recorded history on this (un-pruned) model -- structure only, no gradients
+        needed; afterwards the parameter shapes match the pruned checkpoint."""
+        self._pruning_history = [[n, bool(o), [int(i) for i in ix]] for n, o, ix in pruning_history]
+        for name, is_out, idxs in self._pruning_history:
+            if not is_out:
+                raise NotImplementedError('in-channel roots do not occur in histories written by the prune scripts')
+            module = self.name2module[name]
+            self.get_pruning_group(module, _handler_for(module, 'out'), idxs).prune(record_history=False)
 
     def _chan(self):
         n2m = self.name2module
         return ChannelView(lambda name: n2m[name].weight.shape[0])
 
     def _group(self, members):
-        return Group([(Dependency(self.name2module[m.name], m.name, m.kind), list(m.idxs)) for m in members])
+        return Group([(Dependency(self.name2module[m.name], m.name, m.kind), list(m.idxs)) for m in members], self)
 
     def get_pruning_group(self, module, pruning_fn, idxs):
         name = self.module2name[module]
@@ -521,6 +544,12 @@ class MetaPruner:
             return self.prune_local()
         for group in self.prune_local():
             group.prune()
+
+    def pruning_history(self):
+        return self.DG.pruning_history()
+
+    def load_pruning_history(self, pruning_history):
+        self.DG.load_pruning_history(pruning_history)
 
     def estimate_importance(self, group, ch_groups=1):
         return self.importance(group, ch_groups=ch_groups)

@@ -24,7 +24,12 @@ class UNet2DOutput:
 
 class FrozenConfig(dict):
     """dict with attribute access (Diffusers' FrozenDict behaviour: `unet.config.sample_size`)."""
-    __getattr__ = dict.__getitem__
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None          # keeps copy / pickle protocol probes working
 
 
 # ---- parameter-holder modules, named as in Diffusers so that state_dict keys match ----------------
@@ -194,6 +199,13 @@ class UNet2DModel(nn.Module):
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], cfg['out_channels'], 3, padding=1)
         self._engine = None
+
+    def __getstate__(self):
+        """Whole-module pickles (`torch.save(model, 'unet_pruned.pth')`, ddpm_prune.py:135) carry parameters and shapes
+        only: the HIP engine (packed operands, streams) is rebuilt on first use after loading."""
+        state = dict(self.__dict__)
+        state['_engine'] = None
+        return state
 
     # ------------------------------------------------------------------------------------------
     @property

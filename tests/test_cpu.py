@@ -429,6 +429,59 @@ def test_sibling_criteria_flow_on_mocked_kernels(mocked, monkeypatch, crit):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+def test_pruned_checkpoint_roundtrips(mocked, monkeypatch, tmp_path):
+    """a pruned model chains into finetune / sampling three ways -- the replayable pruning history
+    (dependency.py:278-293 format) + safetensors, the whole-module pickle of ddpm_prune.py:135, and a shape-aware load of a
+    bare pruned state dict.  The recorded history equals the reference's pruned index lists."""
+    sweep, pruning, ckpt = pkg('sweep'), pkg('pruning'), pkg('checkpoint')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = gc.TINY_CFG
+    fx = load_json('tiny_prune.json')
+    model = _cpu_model(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=4)
+    pr = sweep.prune_model(model, 0.3)
+    hist = pr.pruning_history()
+    assert [h[0] for h in hist] == [r['root'] for r in fx['prune']] and all(h[1] for h in hist)
+    assert [sorted(h[2]) for h in hist] == [r['pruned'] for r in fx['prune']]
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+
+    # 1. safetensors + JSON with the history
+    meta = ckpt.save_pruned(model, str(tmp_path / 'pruned'), hist)
+    assert meta['num_parameters'] == fx['params_after']
+    m1 = ckpt.load_pruned(str(tmp_path / 'pruned'))
+    assert {k: list(v.shape) for k, v in m1.state_dict().items()} == fx['shapes_after']
+    assert all(torch.equal(v, want[k]) for k, v in m1.state_dict().items())
+    assert all(u.conv.in_channels == u.channels for u in m1.modules() if hasattr(u, 'channels') and hasattr(u, 'conv'))
+
+    # 2. whole-module pickle (the engine is not part of it)
+    model.engine()                                              # make sure an engine object exists before pickling
+    torch.save(model, str(tmp_path / 'unet_pruned.pth'))
+    m2 = torch.load(str(tmp_path / 'unet_pruned.pth'), weights_only=False)
+    assert m2._engine is None and all(torch.equal(v, want[k]) for k, v in m2.state_dict().items())
+    res = sweep.taylor_sweep(m2, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1)     # still runs
+    assert np.isfinite(res['losses'][0])
+
+    # 3. bare pruned state dict onto a fresh un-pruned module
+    m3 = ckpt.adopt_state_dict(_cpu_model(cfg, 7), want)
+    assert all(torch.equal(v, want[k]) for k, v in m3.state_dict().items())
+    assert m3.conv_norm_out.num_channels == want['conv_norm_out.weight'].shape[0]
+    # an inconsistent dict (one conv with a foreign width) is rejected
+    bad = dict(want)
+    k = 'mid_block.resnets.0.conv1.weight'
+    bad[k] = bad[k][:-1]
+    bad['mid_block.resnets.0.conv1.bias'] = bad['mid_block.resnets.0.conv1.bias'][:-1]
+    with pytest.raises((ValueError, RuntimeError)):
+        ckpt.adopt_state_dict(_cpu_model(cfg, 7), bad)
+
+    # replay on a fresh model through the pruner surface (metapruner.py:138)
+    m4 = _cpu_model(cfg, 5)
+    p4 = pruning.MagnitudePruner(m4, None, importance=pruning.TaylorImportance(), ch_sparsity=0.3, ignored_layers=[m4.conv_out])
+    p4.load_pruning_history(hist)
+    assert {k: list(v.shape) for k, v in m4.state_dict().items()} == fx['shapes_after']
+
+
 # ------------------------------------------------------------------------------------------------ LDM (row a17)
 def test_ldm_oracle_matches_reference_unet():
     """oracle/ldm_ref.py vs the reference's own UNetModel (fixtures from make_golden_ldm.py): bit-exact forward, loss and
@@ -629,3 +682,15 @@ def test_ldm_prune_flow_on_mocked_kernels(mocked, monkeypatch):
     assert [r[3] for r in pr.records] == [r['pruned'] for r in fx['prune']]
     assert {n: list(p.shape) for n, p in model.named_parameters()} == fx['shapes_after']
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
+    # the pruned LDM UNet survives the pickle-free checkpoint (history replay over the LDM coupling graph, GEGLU / head
+    # groups included) and the shape-aware load of its bare state dict
+    import tempfile
+    ckpt = pkg('checkpoint')
+    with tempfile.TemporaryDirectory() as d:
+        ckpt.save_pruned(model, d, pr.pruning_history())
+        back = ckpt.load_pruned(d)
+    sd = model.state_dict()
+    assert all(torch.equal(v, sd[k]) for k, v in back.state_dict().items()) and len(back.state_dict()) == len(sd)
+    fresh = ldm.UNetModel(**cfg)
+    ckpt.adopt_state_dict(fresh, sd)
+    assert {n: list(p.shape) for n, p in fresh.named_parameters()} == fx['shapes_after']
