@@ -111,7 +111,8 @@ def _extent_bytes(x):
     s0 = x.stride(0) if N > 1 else 0
     n = ((N - 1) * s0 + Cc * H * W) * 4
     if n >= _MAX_BYTES:
-        raise ValueError('tensor extent %d bytes >= 2 GiB: split the batch (32-bit buffer addressing)' % n)
+        raise ValueError('tensor extent %d bytes >= 2 GiB (32-bit buffer addressing): run the shard in micro-batches, '
+                         'e.g. taylor_sweep(..., micro_batch=16)' % n)
     return n
 
 

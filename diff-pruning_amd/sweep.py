@@ -30,8 +30,12 @@ def flatten_grads(model):
 
 
 class HipSweepStep:
-    """One timestep of the sweep on the local image shard (forward + loss + backward on the HIP kernels)."""
+    """One timestep of the sweep on the local image shard (forward + loss + backward on the HIP kernels).
+    `micro` (images): the shard is walked in micro-batches of that size within every timestep (gradients accumulate, the
+    per-image loss scaling is the global one, so the result is the same sum) -- for shards whose activations would
+    exceed the 2 GiB-per-tensor limit of the buffer descriptors (e.g. 256x256 images at batch >= 64 per GPU)."""
     _graph = None
+    micro = None
 
     def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
         if clean.device.type != 'cuda':
@@ -49,9 +53,19 @@ class HipSweepStep:
         self.acp = scheduler._acp_on(clean.device)
 
     def _step(self, t):
-        noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
+        if self.micro is None or self.B <= self.micro:
+            return self._micro_step(self.clean, self.noise, t)
+        total = None
+        for lo in range(0, self.B, self.micro):
+            hi = min(lo + self.micro, self.B)
+            l = self._micro_step(self.clean[lo:hi], self.noise[lo:hi], t[lo:hi])
+            total = l if total is None else ops.axpby(l, 1.0, total, 1.0)
+        return total
+
+    def _micro_step(self, clean, noise, t):
+        noisy = ops.add_noise(clean, noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
-        loss, dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
+        loss, dout = ops.mse_fwd_bwd(out, noise, self.gscale, self.lscale)
         self.eng.backward(dout)
         return loss
 
@@ -78,7 +92,7 @@ class HipSweepStep:
 
 
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
-                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False):
+                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False, micro_batch=None):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
 
     clean_images / noise: this rank's shard.  `group`: torch.distributed process group (None = default group if
@@ -98,6 +112,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         flat_grads = flatten_grads(model)
     if step_fn is None:
         step_fn = HipSweepStep(model, scheduler, clean_images, noise, B_global * per_img, loss_kind, B_global)
+        step_fn.micro = micro_batch
         if use_graph:
             step_fn.capture()
     losses = []

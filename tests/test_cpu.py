@@ -429,6 +429,24 @@ def test_sibling_criteria_flow_on_mocked_kernels(mocked, monkeypatch, crit):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+def test_micro_batched_sweep_equals_full_shard(mocked, monkeypatch):
+    """taylor_sweep(micro_batch=m): walking the shard in micro-batches inside every timestep gives the same losses and
+    accumulated gradients (global loss scaling, fp32 re-association only) and the same early-exit step."""
+    sweep = pkg('sweep')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = gc.TINY_CFG
+    clean = torch.from_numpy(gc.det_clean((3, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((3, 3, 16, 16), 2))
+    sched = pkg('diffusion').DDPMScheduler()
+    full, micro = _cpu_model(cfg, 5), _cpu_model(cfg, 5)
+    r_full = sweep.taylor_sweep(full, sched, clean, noise, num_steps=1000, thr=0.99)
+    r_micro = sweep.taylor_sweep(micro, sched, clean, noise, num_steps=1000, thr=0.99, micro_batch=2)   # chunks of 2 + 1
+    assert r_full['steps'] == r_micro['steps'] and np.allclose(r_full['losses'], r_micro['losses'], rtol=1e-6)
+    for (n, a), (_, b) in zip(full.named_parameters(), micro.named_parameters()):
+        if a.grad.abs().max() > 1e-7:
+            assert relerr(b.grad, a.grad) < 1e-5, n
+
+
 def test_pruned_checkpoint_roundtrips(mocked, monkeypatch, tmp_path):
     """a pruned model chains into finetune / sampling three ways -- the replayable pruning history
     (dependency.py:278-293 format) + safetensors, the whole-module pickle of ddpm_prune.py:135, and a shape-aware load of a
