@@ -113,3 +113,118 @@ def adopt_state_dict(model, state_dict):
             raise ValueError('inconsistent pruned shapes at %s (%s channels: %d, coupling graph covers %d)'
                              % (name, side, dim, len(got)))
     return model
+
+
+# --------------------------------------------------------------------------------------------------------
+# Original-DDPM ("ddpm_exp") checkpoints <-> Diffusers UNet2DModel keys
+# --------------------------------------------------------------------------------------------------------
+# The reference's second code path (ddpm_exp/prune.py, finetune_simple.py, runners/diffusion.py) works on the original
+# DDPM `Model` class (ddpm_exp/models/diffusion.py:191-341), whose checkpoints (`ckpt.pth`, the `pretrained/` download)
+# name the same tensors differently.  The key correspondence below restates the layout that class builds
+# (models/diffusion.py:218-305) against unet_2d.py:84-217; the reference's own converter for it is
+# tools/convert_ddpm_original_checkpoint_to_diffusers_cifar10.py:100-240.  Differences in content, not only in names:
+# attention projections are 1x1 Conv2d there ([C, C, 1, 1]) and Linear here ([C, C]); `up.{i}` is indexed by resolution
+# level (0 = full resolution), `up_blocks.{j}` by execution order (0 = lowest resolution).
+_RES_O2D = (('norm1', 'norm1'), ('conv1', 'conv1'), ('temb_proj', 'time_emb_proj'), ('norm2', 'norm2'), ('conv2', 'conv2'),
+            ('nin_shortcut', 'conv_shortcut'))
+_ATT_O2D = (('norm', 'group_norm'), ('q', 'to_q'), ('k', 'to_k'), ('v', 'to_v'), ('proj_out', 'to_out.0'))
+
+
+def ddpm_original_key_map(keys):
+    """{original key: diffusers key} for the parameter names of a ddpm_exp `Model` state dict."""
+    keys = list(keys)
+    levels = 1 + max(int(k.split('.')[1]) for k in keys if k.startswith('down.'))
+    fixed = {'temb.dense.0': 'time_embedding.linear_1', 'temb.dense.1': 'time_embedding.linear_2', 'conv_in': 'conv_in',
+             'norm_out': 'conv_norm_out', 'conv_out': 'conv_out', 'mid.block_1': 'mid_block.resnets.0',
+             'mid.block_2': 'mid_block.resnets.1', 'mid.attn_1': 'mid_block.attentions.0'}
+    out = {}
+    for k in keys:
+        stem, _, leaf = k.rpartition('.')                      # leaf = weight | bias
+        parts = stem.split('.')
+        new = None
+        if parts[0] in ('down', 'up'):
+            i = int(parts[1])
+            blk = ('down_blocks.%d' % i) if parts[0] == 'down' else ('up_blocks.%d' % (levels - 1 - i))
+            if parts[2] == 'block':
+                new = '%s.resnets.%s.%s' % (blk, parts[3], dict(_RES_O2D)[parts[4]])
+            elif parts[2] == 'attn':
+                new = '%s.attentions.%s.%s' % (blk, parts[3], dict(_ATT_O2D)[parts[4]])
+            elif parts[2] == 'downsample':
+                new = blk + '.downsamplers.0.conv'
+            elif parts[2] == 'upsample':
+                new = blk + '.upsamplers.0.conv'
+        else:
+            for old, rep in fixed.items():
+                if stem == old:
+                    new = rep
+                elif stem.startswith(old + '.'):
+                    sub = stem[len(old) + 1:]
+                    new = rep + '.' + (dict(_ATT_O2D)[sub] if 'attn' in old else dict(_RES_O2D)[sub])
+        if new is None:
+            raise KeyError('not a ddpm_exp Model parameter: %s' % k)
+        out[k] = new + '.' + leaf
+    return out
+
+
+def convert_ddpm_original(state_dict):
+    """Original-DDPM `Model` state dict -> state dict with this package's / Diffusers' UNet2DModel keys."""
+    kmap = ddpm_original_key_map(state_dict.keys())
+    out = {}
+    for k, v in state_dict.items():
+        nk = kmap[k]
+        if '.attentions.' in nk and not nk.rsplit('.', 2)[-2].startswith('group_norm') and v.dim() == 4:
+            v = v.reshape(v.shape[0], v.shape[1])              # 1x1 Conv2d -> Linear
+        out[nk] = v
+    return out
+
+
+def convert_to_ddpm_original(state_dict):
+    """Inverse of convert_ddpm_original (to hand a pruned / finetuned model back to the ddpm_exp scripts)."""
+    levels = 1 + max(int(k.split('.')[1]) for k in state_dict if k.startswith('down_blocks.'))
+    res_d2o = {b: a for a, b in _RES_O2D}
+    att_d2o = {b: a for a, b in _ATT_O2D}
+    fixed = {'time_embedding.linear_1': 'temb.dense.0', 'time_embedding.linear_2': 'temb.dense.1', 'conv_in': 'conv_in',
+             'conv_norm_out': 'norm_out', 'conv_out': 'conv_out'}
+    out = {}
+    for k, v in state_dict.items():
+        stem, _, leaf = k.rpartition('.')
+        p = stem.split('.')
+        if stem in fixed:
+            new = fixed[stem]
+        elif p[0] == 'mid_block':
+            new = ('mid.block_%d.%s' % (int(p[2]) + 1, res_d2o[p[3]])) if p[1] == 'resnets' else \
+                  ('mid.attn_1.' + att_d2o['.'.join(p[3:])])
+        elif p[0] in ('down_blocks', 'up_blocks'):
+            i = int(p[1])
+            blk = ('down.%d' % i) if p[0] == 'down_blocks' else ('up.%d' % (levels - 1 - i))
+            if p[2] == 'resnets':
+                new = '%s.block.%s.%s' % (blk, p[3], res_d2o[p[4]])
+            elif p[2] == 'attentions':
+                new = '%s.attn.%s.%s' % (blk, p[3], att_d2o['.'.join(p[4:])])
+            elif p[2] == 'downsamplers':
+                new = blk + '.downsample.conv'
+            elif p[2] == 'upsamplers':
+                new = blk + '.upsample.conv'
+            else:
+                raise KeyError(k)
+        else:
+            raise KeyError(k)
+        if ('.attn' in new) and not new.endswith('.norm') and v.dim() == 2:
+            v = v.reshape(v.shape[0], v.shape[1], 1, 1)        # Linear -> 1x1 Conv2d
+        out[new + '.' + leaf] = v
+    return out
+
+
+def unet2d_config_from_ddpm_original(ch, ch_mult, num_res_blocks, attn_resolutions, image_size, in_channels=3, out_ch=3):
+    """UNet2DModel kwargs equivalent to a ddpm_exp `Model` config (ddpm_exp/configs/*.yml: model.ch, ch_mult,
+    num_res_blocks, attn_resolutions; data.image_size)."""
+    res, down, up = image_size, [], []
+    for lvl in range(len(ch_mult)):
+        down.append('AttnDownBlock2D' if res in attn_resolutions else 'DownBlock2D')
+        up.insert(0, 'AttnUpBlock2D' if res in attn_resolutions else 'UpBlock2D')
+        if lvl != len(ch_mult) - 1:
+            res //= 2
+    return dict(sample_size=image_size, in_channels=in_channels, out_channels=out_ch, layers_per_block=num_res_blocks,
+                block_out_channels=tuple(ch * m for m in ch_mult), down_block_types=tuple(down), up_block_types=tuple(up),
+                norm_num_groups=32, norm_eps=1e-6, downsample_padding=0, flip_sin_to_cos=False, freq_shift=1,
+                attention_head_dim=None, act_fn='silu')

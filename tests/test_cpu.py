@@ -429,6 +429,31 @@ def test_sibling_criteria_flow_on_mocked_kernels(mocked, monkeypatch, crit):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+def test_ddpm_original_checkpoint_layout_matches_reference_twin():
+    """Original-DDPM (`ddpm_exp/models/diffusion.py` Model) checkpoints: the key / shape table equals the reference class's,
+    and the reference Model's forward on seeded weights equals the oracle UNet on the converted weights -- the independent
+    twin implementation cross-checks both the converter and the UNet restatement."""
+    from oracle import unet_ref as U
+    ckpt, unet = pkg('checkpoint'), pkg('unet')
+    fx = load_json('ddpm_original.json')
+    want = load_npz('ddpm_original.npz')['out']
+    c = fx['cfg']
+    cfg = ckpt.unet2d_config_from_ddpm_original(c['ch'], c['ch_mult'], c['num_res_blocks'], c['attn_resolutions'], c['image_size'])
+    # layout: our module's state dict, renamed to the original layout, has exactly the reference's keys and shapes
+    ours = ckpt.convert_to_ddpm_original(unet.UNet2DModel(**cfg).state_dict())
+    assert {k: list(v.shape) for k, v in ours.items()} == fx['shapes']
+    # numerics: weights generated from the ORIGINAL names, converted, run through the oracle
+    orig = {n: torch.from_numpy(gc.det_param(n, tuple(s), fx['seed'])) for n, s in fx['shapes'].items()}
+    conv = ckpt.convert_ddpm_original(orig)
+    assert {k: tuple(v.shape) for k, v in conv.items()} == {k: tuple(s) for k, s in U.param_shapes(cfg).items()}
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), fx['input_seed']))
+    with torch.no_grad():
+        y = U.unet_forward(conv, cfg, x, torch.tensor(fx['timesteps']))
+    assert float((y - torch.from_numpy(want)).abs().max()) < 2e-5
+    back = ckpt.convert_to_ddpm_original(conv)
+    assert all(torch.equal(back[k], orig[k]) for k in orig)
+
+
 def test_micro_batched_sweep_equals_full_shard(mocked, monkeypatch):
     """taylor_sweep(micro_batch=m): walking the shard in micro-batches inside every timestep gives the same losses and
     accumulated gradients (global loss scaling, fp32 re-association only) and the same early-exit step."""
