@@ -69,6 +69,25 @@ class HipSweepStep:
         self.eng.backward(dout)
         return loss
 
+    # ---- two-phase step for the ddpm_exp / LDM flavour of Diff-Pruning, whose threshold test sits BEFORE the backward
+    #      (ddpm_exp/prune.py:249-256): the breaking timestep contributes no gradient
+    def forward_loss(self, k):
+        if self.micro is not None and self.B > self.micro:
+            raise NotImplementedError('break-before-backward keeps one forward context: not combined with micro-batches')
+        t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+        noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
+        out = self.eng.forward(noisy, t, save=True)
+        loss, self._dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
+        return loss
+
+    def backward_pending(self):
+        self.eng.backward(self._dout)
+        self._dout = None
+
+    def discard_pending(self):
+        self.eng.ctx = None
+        self._dout = None
+
     def capture(self):
         """Record one timestep (~900 kernel launches) into a hipGraph; afterwards every step is: write t, replay.
         Removes the ~60 ms of Python/ctypes launch overhead per step -- the launch-bound regime at small batch."""
@@ -92,8 +111,13 @@ class HipSweepStep:
 
 
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
-                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False, micro_batch=None):
+                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False, micro_batch=None,
+                 accumulate_breaking_step=True):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
+
+    thr=None: plain Taylor.  thr=x: Diff-Pruning early exit.  accumulate_breaking_step=True is ddpm_prune.py:102-106
+    (backward, then the threshold test); False is the ddpm_exp flavour (ddpm_exp/prune.py:249-256: test, break, else
+    backward), to be combined with loss_kind='sum' (functions/losses.py:15).
 
     clean_images / noise: this rank's shard.  `group`: torch.distributed process group (None = default group if
     torch.distributed is initialised, single process otherwise).  `step_fn(k) -> local loss tensor` lets the
@@ -119,7 +143,24 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     pending = []
     loss_max = 0.0
     steps = 0
+    two_phase = thr is not None and not accumulate_breaking_step
+    if two_phase and use_graph:
+        raise ValueError('use_graph replays forward + backward as one unit: not available with accumulate_breaking_step=False')
     for k in range(num_steps):
+        if two_phase:
+            l = step_fn.forward_loss(k)
+            steps += 1
+            if use_dist:
+                dist.all_reduce(l, group=group)
+            lv = float(l)
+            losses.append(lv)
+            if lv > loss_max:
+                loss_max = lv
+            if lv < loss_max * thr:
+                step_fn.discard_pending()
+                break
+            step_fn.backward_pending()
+            continue
         l = step_fn(k)
         steps += 1
         if use_dist and (thr is not None):

@@ -87,11 +87,13 @@ def to_image(x):
     return (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
 
 
-def taylor_sweep(P, cfg, clean, noise, steps, thr=None, loss_kind='mse', on_step=None):
+def taylor_sweep(P, cfg, clean, noise, steps, thr=None, loss_kind='mse', on_step=None, accumulate_breaking_step=True):
     """ddpm_prune.py:94-106.  P: dict of leaf tensors with requires_grad; grads accumulate into .grad.
 
     thr=None -> plain Taylor (all `steps`); thr=x -> Diff-Pruning early exit; the breaking step IS
     accumulated (backward happens before the threshold test, ddpm_prune.py:102-106).
+    accumulate_breaking_step=False -> the ddpm_exp flavour (ddpm_exp/prune.py:249-256): threshold test first, the
+    breaking step is NOT accumulated (pinned by tests/golden/ddpm_original.json 'sweep').
     Returns the list of per-step losses (python floats)."""
     acp = alphas_cumprod()
     for p in P.values():
@@ -107,8 +109,16 @@ def taylor_sweep(P, cfg, clean, noise, steps, thr=None, loss_kind='mse', on_step
             loss = F.mse_loss(out, noise)
         else:                                   # ddpm_exp/functions/losses.py:15, ddpm_train.py:459
             loss = (noise - out).square().sum(dim=(1, 2, 3)).mean(dim=0)
-        loss.backward()
         lv = float(loss.detach())
+        if thr is not None and not accumulate_breaking_step:
+            losses.append(lv)
+            if lv > loss_max:
+                loss_max = lv
+            if lv < loss_max * thr:
+                break
+            loss.backward()
+            continue
+        loss.backward()
         losses.append(lv)
         if on_step is not None:
             on_step(k, lv)

@@ -38,8 +38,28 @@ def main():
     with torch.no_grad():
         y = model(x, t)
     np.savez(os.path.join(HERE, 'ddpm_original.npz'), out=y.numpy())
-    json.dump(dict(cfg=CFG, shapes=shapes, seed=21, input_seed=31, timesteps=[3, 500]),
+    # the ddpm_exp flavour of the Diff-Pruning sweep (ddpm_exp/prune.py:236-258 with functions/losses.py:9-15): threshold
+    # test BEFORE backward, loss = sum over C,H,W / mean over the batch, timesteps passed as float
+    from functions.losses import noise_estimation_loss
+    x0 = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 41))
+    e = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 42))
+    betas = torch.linspace(1e-4, 0.02, 1000)
+    model.zero_grad()
+    max_loss, losses, thr = 0, [], 0.99
+    for step_k in range(1000):
+        tt = torch.ones(2, dtype=torch.long) * step_k
+        loss = noise_estimation_loss(model, x0, tt, e, betas)
+        losses.append(float(loss))
+        if loss > max_loss:
+            max_loss = loss
+        if loss < max_loss * thr:
+            break
+        loss.backward()
+    gstats = {n: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())] for n, p in model.named_parameters()}
+    json.dump(dict(cfg=CFG, shapes=shapes, seed=21, input_seed=31, timesteps=[3, 500],
+                   sweep=dict(thr=thr, clean_seed=41, noise_seed=42, losses=losses, grad_stats=gstats)),
               open(os.path.join(HERE, 'ddpm_original.json'), 'w'))
+    print('twin sweep: %d losses (last step breaks before backward)' % len(losses))
     print('ddpm_original ok:', len(shapes), 'tensors, out', tuple(y.shape), float(y.abs().mean()))
 
 

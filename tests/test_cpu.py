@@ -454,6 +454,39 @@ def test_ddpm_original_checkpoint_layout_matches_reference_twin():
     assert all(torch.equal(back[k], orig[k]) for k in orig)
 
 
+def test_ddpm_exp_sweep_flavour_matches_reference_twin(mocked, monkeypatch):
+    """The ddpm_exp flavour of the Diff-Pruning sweep (ddpm_exp/prune.py:236-258: threshold test before backward, loss summed
+    over C,H,W): oracle == the reference twin's recorded run (losses, stop step, gradient statistics), product == oracle."""
+    from oracle import diffusion_ref as D
+    ckpt, sweep = pkg('checkpoint'), pkg('sweep')
+    fx = load_json('ddpm_original.json')
+    sw, c = fx['sweep'], fx['cfg']
+    cfg = ckpt.unet2d_config_from_ddpm_original(c['ch'], c['ch_mult'], c['num_res_blocks'], c['attn_resolutions'], c['image_size'])
+    orig = {n: torch.from_numpy(gc.det_param(n, tuple(s), fx['seed'])) for n, s in fx['shapes'].items()}
+    kmap = ckpt.ddpm_original_key_map(orig.keys())
+    P = {k: v.clone().requires_grad_(True) for k, v in ckpt.convert_ddpm_original(orig).items()}
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), sw['clean_seed']))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), sw['noise_seed']))
+    losses = D.taylor_sweep(P, cfg, clean, noise, 1000, thr=sw['thr'], loss_kind='sum', accumulate_breaking_step=False)
+    assert len(losses) == len(sw['losses']) and np.allclose(losses, sw['losses'], rtol=2e-5)
+    for on, (s, a) in sw['grad_stats'].items():
+        g = P[kmap[on]].grad.double()
+        # biases in front of a one-channel-per-group GroupNorm (32 channels, 32 groups) have exactly zero gradient in exact
+        # arithmetic: absolute floor (the summed loss is 768x the mean-squared one)
+        assert abs(float(g.abs().sum()) - a) <= 5e-5 * a + 1e-5 * g.numel(), on
+    # product control flow (host logic + mocked kernels)
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    model = pkg('unet').UNet2DModel(**cfg)
+    model.load_state_dict({k: v.detach() for k, v in P.items()})
+    res = sweep.taylor_sweep(model.eval(), pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1000, thr=sw['thr'],
+                             loss_kind='sum', accumulate_breaking_step=False)
+    assert res['steps'] == len(losses) and np.allclose(res['losses'], losses, rtol=1e-5)
+    gmax = max(float(t.grad.abs().max()) for t in P.values())
+    for n, p in model.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-4 * gmax:          # skip the exactly-zero-in-theory bias gradients (noise)
+            assert relerr(p.grad, P[n].grad) < 5e-5, n
+
+
 def test_micro_batched_sweep_equals_full_shard(mocked, monkeypatch):
     """taylor_sweep(micro_batch=m): walking the shard in micro-batches inside every timestep gives the same losses and
     accumulated gradients (global loss scaling, fp32 re-association only) and the same early-exit step."""

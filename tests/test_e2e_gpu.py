@@ -130,6 +130,33 @@ def test_sibling_criteria_masks_bit_exact(report, crit):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+def test_ddpm_exp_sweep_flavour_break_before_backward(report):
+    """ddpm_exp/prune.py:236-258 on the HIP engine: loss summed over C,H,W, threshold test before the backward (the breaking
+    step contributes no gradient), original-DDPM checkpoint layout -- against the reference twin's recorded run."""
+    ckpt, sweep, unet = pkg('checkpoint'), pkg('sweep'), pkg('unet')
+    fx = load_json('ddpm_original.json')
+    sw, c = fx['sweep'], fx['cfg']
+    cfg = ckpt.unet2d_config_from_ddpm_original(c['ch'], c['ch_mult'], c['num_res_blocks'], c['attn_resolutions'], c['image_size'])
+    orig = {n: torch.from_numpy(gc.det_param(n, tuple(s), fx['seed'])) for n, s in fx['shapes'].items()}
+    kmap = ckpt.ddpm_original_key_map(orig.keys())
+    model = unet.UNet2DModel(**cfg)
+    model.load_state_dict(ckpt.convert_ddpm_original(orig))
+    model = model.to(DEV).eval()
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), sw['clean_seed'])).to(DEV)
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), sw['noise_seed'])).to(DEV)
+    res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1000, thr=sw['thr'],
+                             loss_kind='sum', accumulate_breaking_step=False)
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], sw['losses']))
+    P = dict(model.named_parameters())
+    bad = []
+    for on, (s, a) in sw['grad_stats'].items():
+        g = P[kmap[on]].grad.double()
+        if abs(float(g.abs().sum()) - a) > 5e-5 * a + 1e-5 * g.numel():
+            bad.append(on)
+    report['e2e/ddpm_exp_sweep'] = dict(steps=res['steps'], ref_steps=len(sw['losses']), loss_rel=e_loss, bad=bad)
+    assert res['steps'] == len(sw['losses']) and e_loss < 2e-5 and not bad, bad[:5]
+
+
 def test_diff_pruning_early_exit_step(report):
     cfg = gc.TINY_CFG
     fx = load_json('tiny_prune.json')['early_exit']
