@@ -2,8 +2,10 @@
 
 Parity: the UNet forward/backward is PINNED against the reference's own `UNetModel` (importable with a 3-line
 omegaconf stub; fixtures tests/golden/ldm_unet.npz from tests/golden/make_golden_ldm.py).
-`LatentDiffusion` / `DDIMSampler` are NOT importable here (pytorch_lightning, omegaconf, taming absent), so the loss,
-the q_sample tables and the CFG DDIM sampler below are restated from the source lines and are **parity unpinned**.
+The noise schedule and the CFG DDIM sampler are PINNED against the reference's own `DDIMSampler` + `make_beta_schedule`
+(both import cleanly) driven over the reference UNetModel: tests/golden/ldm_sampler.npz (make_golden_ldm.py sampler).
+`LatentDiffusion` itself is NOT importable here (pytorch_lightning absent), so the ~10 lines of get_loss_at_t / p_losses /
+q_sample and the driver loop of prune_ldm.py are restated from the source lines and remain **parity unpinned**.
 
 Reference lines followed (relative to /root/reference/ldm_exp):
   ldm/modules/diffusionmodules/openaimodel.py:710-742      UNetModel.forward
@@ -235,7 +237,7 @@ def ldm_param_shapes(cfg):
 
 
 # ------------------------------------------------------------------------------------------------------
-# LatentDiffusion pieces (parity unpinned: restated from source, the classes are not importable here)
+# LatentDiffusion pieces (schedule + sampler pinned by ldm_sampler.npz; q_sample / loss-at-t restated from source, unpinned)
 # ------------------------------------------------------------------------------------------------------
 def ldm_alphas_cumprod(n_timestep=1000, linear_start=0.0015, linear_end=0.0195):
     """util.py:21-25 ('linear') + ddpm.py register_schedule: fp64 tables, cast to fp32."""

@@ -168,3 +168,54 @@ def ldm_prune():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'prune':
     ldm_prune()
+
+
+def ldm_sampler():
+    """Pins the CFG DDIM sampler of the LDM importance pass (ldm_exp/prune_ldm.py:111-118 -> DDIMSampler.sample,
+    ldm/models/diffusion/ddim.py:57-203) and the latent-diffusion noise schedule (ldm/modules/diffusionmodules/util.py
+    make_beta_schedule 'linear' with the cin256-v2 linear_start / linear_end): the reference's own DDIMSampler driven over the
+    reference's own UNetModel (tiny config, seeded weights), 20 steps, guidance 3.0, eta 0, fixed x_T.
+    LatentDiffusion itself needs pytorch_lightning (absent); the sampler only reads a handful of attributes of it, which
+    the stand-in below provides from the reference's own schedule function."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    cfg = gc.LDM_TINY_CFG
+    unet = UNetModel(**cfg).eval()
+    gc.det_init_(unet, 9)
+    betas = make_beta_schedule('linear', 1000, linear_start=0.0015, linear_end=0.0195, cosine_s=8e-3)
+    alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    class Host:                                   # what DDIMSampler reads from LatentDiffusion
+        num_timesteps = 1000
+        device = torch.device('cpu')
+        parameterization = 'eps'
+
+        def __init__(self):
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(alphas_cumprod, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, alphas_cumprod[:-1]), dtype=torch.float32)
+
+        def apply_model(self, x, t, c):           # ddpm.py:840-860 with conditioning_key 'crossattn': unet(x, t, context=c)
+            return unet(x, t, context=c)
+
+    class CpuSampler(DDIMSampler):
+        def register_buffer(self, name, attr):    # the reference moves every buffer to 'cuda' here; no arithmetic
+            setattr(self, name, attr)
+
+    B, H = 2, cfg['image_size']
+    x_T = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 51))
+    cond = torch.from_numpy(gc.det_noise((B, 1, cfg['context_dim']), 52))
+    uncond = torch.from_numpy(gc.det_noise((B, 1, cfg['context_dim']), 53))
+    sampler = CpuSampler(Host())
+    with torch.no_grad():
+        samples, inter = sampler.sample(S=20, conditioning=cond, batch_size=B, shape=[cfg['in_channels'], H, H], verbose=False,
+                                        unconditional_guidance_scale=3.0, unconditional_conditioning=uncond, eta=0.0, x_T=x_T,
+                                        log_every_t=5)
+    np.savez(os.path.join(HERE, 'ldm_sampler.npz'), samples=samples.numpy(), ddim_timesteps=np.asarray(sampler.ddim_timesteps),
+             ddim_alphas=np.asarray(sampler.ddim_alphas, dtype=np.float64), alphas_cumprod=alphas_cumprod.astype(np.float64),
+             x_inter=torch.stack(inter['x_inter']).numpy())
+    print('ldm sampler ok:', tuple(samples.shape), 'steps', list(sampler.ddim_timesteps)[:4], '...', float(samples.abs().mean()))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'sampler':
+    ldm_sampler()

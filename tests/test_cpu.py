@@ -691,6 +691,28 @@ def test_ldm_importance_sweep_control_flow_matches_oracle(mocked, monkeypatch):
             assert res['accumulated'] == 0 and float(res['flat_grads'].abs().max()) == 0.0
 
 
+def test_ldm_sampler_matches_reference_ddim_sampler():
+    """The CFG DDIM sampler of the LDM importance pass and its noise schedule against the reference's own DDIMSampler
+    (ldm/models/diffusion/ddim.py:57-203) run over the reference UNetModel: schedule tables exact to fp64 rounding, 20-step
+    guided sample within fp32 accumulation."""
+    from oracle import ldm_ref as R
+    g = load_npz('ldm_sampler.npz')
+    cfg = gc.LDM_TINY_CFG
+    acp = R.ldm_alphas_cumprod()
+    assert np.allclose(np.asarray(acp, dtype=np.float64), g['alphas_cumprod'], rtol=1e-12, atol=0)
+    steps, a, a_prev, sig = R.ddim_schedule(acp, 20)
+    assert [int(s) for s in steps] == [int(s) for s in g['ddim_timesteps']]
+    assert np.allclose(np.asarray(a, dtype=np.float64), g['ddim_alphas'], rtol=1e-6)
+    P = {n: torch.from_numpy(gc.det_param(n, s, 9)) for n, s in R.ldm_param_shapes(cfg).items()}
+    H = cfg['image_size']
+    x_T = torch.from_numpy(gc.det_noise((2, cfg['in_channels'], H, H), 51))
+    cond = torch.from_numpy(gc.det_noise((2, 1, cfg['context_dim']), 52))
+    uncond = torch.from_numpy(gc.det_noise((2, 1, cfg['context_dim']), 53))
+    with torch.no_grad():
+        x = R.ddim_sample_cfg(P, cfg, acp, x_T, cond, uncond, S=20, scale=3.0)
+    assert relerr(x, torch.from_numpy(g['samples'])) < 2e-4
+
+
 def test_ldm_group_enumeration_matches_reference():
     from oracle import ldm_ref as L
     G = pkg('graph')
