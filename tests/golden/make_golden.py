@@ -271,6 +271,24 @@ def do_tiny():
     print('tiny ok: groups', len(table), 'pruned groups', len(rec), 'params', nparams, 'early steps', len(losses2))
 
 
+def do_tiny_bedroom():
+    """Bedroom/church-256 topology (6 levels, attention in the 5th down / 2nd up block) at tiny widths: forward output, loss and
+    per-parameter gradient statistics of one sweep step from the reference UNet2DModel."""
+    cfg = dict(gc.BEDROOM_CFG, block_out_channels=[16, 16, 32, 32, 64, 64], sample_size=32, norm_num_groups=8)
+    model = build_ref_unet(cfg, 3)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((1, 3, 32, 32), 5))
+    noise = torch.from_numpy(gc.det_noise((1, 3, 32, 32), 6))
+    t = torch.tensor([250])
+    with torch.no_grad():
+        y = model(sched.add_noise(clean, noise, t), t).sample.numpy()
+    losses = sweep(model, sched, clean, noise, 2)
+    np.savez(os.path.join(HERE, 'tiny_bedroom.npz'), fwd_out=y, losses=np.array(losses))
+    json.dump(dict(cfg={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()}, grad_stats=grad_stats(model)),
+              open(os.path.join(HERE, 'tiny_bedroom.json'), 'w'))
+    print('tiny bedroom ok', y.shape, losses)
+
+
 def do_criteria():
     """The sibling criteria selectable in ddpm_exp/prune.py:193-208 on the tiny UNet after a 4-step sweep:
     per-group score vectors and pruned index lists of the whole sequential prune, one run per criterion."""
@@ -339,6 +357,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom']
     for w in what:
         globals()['do_' + w]()

@@ -126,6 +126,26 @@ def test_oracle_unet_forward_and_sweep_grads():
         assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
 
 
+def test_oracle_bedroom_topology_matches_reference():
+    """6-level bedroom/church-256 topology at tiny widths: oracle forward, sweep losses and gradient statistics against the
+    reference UNet2DModel (tests/golden/tiny_bedroom.*)."""
+    from oracle import diffusion_ref as D, unet_ref as U
+    fx, g = load_json('tiny_bedroom.json'), load_npz('tiny_bedroom.npz')
+    cfg = fx['cfg']
+    P = oracle_params(cfg, 3)
+    clean = torch.from_numpy(gc.det_clean((1, 3, 32, 32), 5))
+    noise = torch.from_numpy(gc.det_noise((1, 3, 32, 32), 6))
+    t = torch.tensor([250])
+    with torch.no_grad():
+        y = U.unet_forward(P, cfg, D.add_noise(D.alphas_cumprod(), clean, noise, t), t)
+    assert float((y - torch.from_numpy(g['fwd_out'])).abs().max()) < 1e-5
+    losses = D.taylor_sweep(P, cfg, clean, noise, 2)
+    assert np.allclose(losses, g['losses'], rtol=1e-5)
+    for n, (s, a, q) in fx['grad_stats'].items():
+        gr = P[n].grad.double()
+        assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
+
+
 def test_oracle_prune_masks_match_reference_tiny():
     """Scores, masks and post-prune shapes of the full ratio-0.3 prune of the tiny UNet."""
     from oracle import diffusion_ref as D, unet_ref as U
