@@ -141,6 +141,7 @@ def adam_ema_step(params, grads, m, v, ema, step, lr=2e-4, b1=0.9, b2=0.999, eps
                   max_norm=1.0):
     """ddpm_train.py:462-469: clip_grad_norm_(1.0) -> Adam (torch.optim.Adam defaults of :331-337, wd 0) ->
     EMAModel.step with constant decay (training_utils.py:201,215-216).  Lists of tensors, updated in place.
+    Pinned by tests/golden/optim.json (three steps of the reference's own clip + torch Adam + vendored EMAModel).
     Returns the pre-clip global gradient norm."""
     total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)

@@ -289,6 +289,32 @@ def do_tiny_bedroom():
     print('tiny bedroom ok', y.shape, losses)
 
 
+def do_optim():
+    """ddpm_train.py:453-469 update rule on small seeded tensors, 3 consecutive steps: clip_grad_norm_(1.0) -> torch.optim.Adam
+    with the script's argparse defaults (ddpm_train.py:137-159: betas (0.9, 0.999), weight_decay 0, eps 1e-8) and the lr of
+    scripts/finetune_ddpm_cifar10.sh (2e-4) -> vendored EMAModel.step (ema_max_decay 0.9999 from the same script)."""
+    from diffusers.training_utils import EMAModel
+    shapes = [(4, 3, 3, 3), (4,), (5, 4)]
+    params = [torch.nn.Parameter(torch.from_numpy(gc.det_param('p%d.weight' % i, s, 61))) for i, s in enumerate(shapes)]
+    ema = EMAModel(params, decay=0.9999, use_ema_warmup=False, inv_gamma=1.0, power=0.75)
+    hp = dict(lr=2e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8)
+    opt = torch.optim.Adam(params, **hp)
+    rec = []
+    for step in range(3):
+        opt.zero_grad()
+        for i, p_ in enumerate(params):
+            p_.grad = torch.from_numpy(gc.det_param('g%d_%d.weight' % (i, step), shapes[i], 62)) * (3.0 if step == 0 else 0.05)
+        norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        ema.step(params)
+        rec.append(dict(norm=float(norm), params=[gc.f32_to_b64(p_.detach().numpy()) for p_ in params],
+                        ema=[gc.f32_to_b64(e.detach().numpy()) for e in ema.shadow_params]))
+    json.dump(dict(shapes=[list(s) for s in shapes], hp=dict(lr=hp['lr'], betas=list(hp['betas']), weight_decay=hp['weight_decay'],
+                                                            eps=hp['eps']), ema_decay=0.9999, steps=rec),
+              open(os.path.join(HERE, 'optim.json'), 'w'))
+    print('optim ok', [r['norm'] for r in rec])
+
+
 def do_criteria():
     """The sibling criteria selectable in ddpm_exp/prune.py:193-208 on the tiny UNet after a 4-step sweep:
     per-group score vectors and pruned index lists of the whole sequential prune, one run per criterion."""
@@ -357,6 +383,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim']
     for w in what:
         globals()['do_' + w]()

@@ -126,6 +126,28 @@ def test_oracle_unet_forward_and_sweep_grads():
         assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
 
 
+def test_oracle_optimizer_step_matches_reference_pieces():
+    """clip_grad_norm_(1.0) -> torch.optim.Adam (ddpm_train.py:331-337 hyper-parameters) -> vendored EMAModel.step
+    (training_utils.py:181-218), three consecutive steps on seeded tensors (first step clips, the others do not)."""
+    from oracle import diffusion_ref as D
+    fx = load_json('optim.json')
+    shapes = [tuple(s) for s in fx['shapes']]
+    params = [torch.from_numpy(gc.det_param('p%d.weight' % i, s, 61)).clone() for i, s in enumerate(shapes)]
+    ema = [p.clone() for p in params]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    hp = fx['hp']
+    for step, rec in enumerate(fx['steps']):
+        grads = [torch.from_numpy(gc.det_param('g%d_%d.weight' % (i, step), shapes[i], 62)) * (3.0 if step == 0 else 0.05)
+                 for i in range(len(shapes))]
+        norm = D.adam_ema_step(params, grads, m, v, ema, step + 1, lr=hp['lr'], b1=hp['betas'][0], b2=hp['betas'][1],
+                               eps=hp['eps'], ema_decay=fx['ema_decay'], max_norm=1.0)
+        assert abs(norm - rec['norm']) <= 1e-6 * rec['norm']
+        for p, e, rp, re_ in zip(params, ema, rec['params'], rec['ema']):
+            assert relerr(p, torch.from_numpy(gc.b64_to_f32(rp)).view_as(p)) < 2e-6
+            assert relerr(e, torch.from_numpy(gc.b64_to_f32(re_)).view_as(e)) < 2e-6
+
+
 def test_oracle_bedroom_topology_matches_reference():
     """6-level bedroom/church-256 topology at tiny widths: oracle forward, sweep losses and gradient statistics against the
     reference UNet2DModel (tests/golden/tiny_bedroom.*)."""
