@@ -610,6 +610,7 @@ class MetaPruner:
 
 MagnitudePruner = MetaPruner
 pruner = SimpleNamespace(MetaPruner=MetaPruner, MagnitudePruner=MagnitudePruner)
+utils = None        # filled below (count_ops_and_params is defined after the pruner classes)
 
 
 def fix_static_attributes(model):
@@ -619,5 +620,56 @@ def fix_static_attributes(model):
             m.channels = m.conv.in_channels
 
 
+def count_ops_and_params(model, example_inputs=None):
+    """`tp.utils.count_ops_and_params(model, example_inputs)` (ddpm_prune.py:89,118, ddpm_sample.py:51) for UNet2DModel:
+    returns (MACs-style count per image, parameter count) with the vendored counter's conventions
+    (utils/op_counter.py:53-101,248-298): Conv2d = k*k*Cin*Cout*positions + Cout*positions (bias), Linear =
+    numel(input)*out + out (bias, once), GroupNorm = 2*numel(input); activations, interpolation and the attention
+    matmuls are not counted.  The reference obtains the shapes with forward hooks; here they follow from the block
+    structure (this model has no PyTorch forward to hook).  `example_inputs` only supplies the spatial size."""
+    cfg = getattr(model, 'config', None)
+    if cfg is None or 'block_out_channels' not in cfg:
+        raise NotImplementedError('count_ops_and_params is implemented for UNet2DModel')
+    H = W = cfg['sample_size'] if isinstance(cfg['sample_size'], int) else None
+    if H is None:
+        H, W = cfg['sample_size']
+    if example_inputs is not None:
+        x = example_inputs['sample'] if isinstance(example_inputs, dict) else example_inputs[0]
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+    levels = len(cfg['block_out_channels'])
+
+    def hw(level):
+        return (H >> level) * (W >> level)
+
+    def positions(name, module):
+        p = name.split('.')
+        if p[0] == 'down_blocks':
+            lvl = int(p[1])
+            return hw(lvl + 1) if p[2] == 'downsamplers' else hw(lvl)
+        if p[0] == 'up_blocks':
+            lvl = levels - 1 - int(p[1])
+            return hw(lvl - 1) if p[2] == 'upsamplers' else hw(lvl)
+        if p[0] == 'mid_block':
+            return hw(levels - 1)
+        return H * W                                            # conv_in, conv_norm_out, conv_out
+
+    total = 0
+    for name, m in model.named_modules():
+        if isinstance(m, nn.Conv2d):
+            pos = positions(name, m)
+            total += m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels * pos
+            if m.bias is not None:
+                total += m.out_channels * pos
+        elif isinstance(m, nn.Linear):
+            tokens = positions(name, m) if '.attentions.' in name else 1      # q/k/v/out see [1, T, C]; the rest [1, C]
+            total += tokens * m.in_features * m.out_features + (m.out_features if m.bias is not None else 0)
+        elif isinstance(m, nn.GroupNorm):
+            total += 2 * m.num_channels * positions(name, m)
+    return float(total), count_params(model)
+
+
 def count_params(model):
     return sum(p.numel() for p in model.parameters())
+
+
+utils = SimpleNamespace(count_ops_and_params=count_ops_and_params, count_params=count_params)

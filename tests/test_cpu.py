@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(L.ConvGeom) == 14 * 4 + 2 * 8
 
 
+def test_count_ops_and_params_matches_reference_c1():
+    """tp.utils.count_ops_and_params (ddpm_prune.py:89,118): the un-pruned CIFAR UNet and the UNet pruned with the reference's
+    C1 masks (replayed as a pruning history) give exactly the reference's MAC and parameter counts."""
+    pruning, unet = pkg('pruning'), pkg('unet')
+    fx = load_json('cifar_c1.json')
+    model = unet.UNet2DModel(**gc.CIFAR_CFG)
+    ex = {'sample': torch.randn(1, 3, 32, 32), 'timestep': torch.ones((1,)).long()}
+    macs, params = pruning.utils.count_ops_and_params(model, ex)
+    assert (macs, params) == (fx['base_macs'], fx['base_params'])
+    pruning.DependencyGraph(model).load_pruning_history([[r['root'], True, r['pruned']] for r in fx['prune']])
+    pruning.fix_static_attributes(model)
+    macs, params = pruning.utils.count_ops_and_params(model, ex)
+    assert (macs, params) == (fx['macs_after'], fx['params_after'])
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == fx['shapes_after']
+
+
 def test_kernel_dispatch_heuristics():
     """Host-side dispatch rules of ops.py (pure arithmetic, no device): GroupNorm slicing, 96-row tiles for pruned
     widths, split-K of small grids."""
