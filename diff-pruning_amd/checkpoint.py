@@ -228,3 +228,98 @@ def unet2d_config_from_ddpm_original(ch, ch_mult, num_res_blocks, attn_resolutio
                 block_out_channels=tuple(ch * m for m in ch_mult), down_block_types=tuple(down), up_block_types=tuple(up),
                 norm_num_groups=32, norm_eps=1e-6, downsample_padding=0, flip_sin_to_cos=False, freq_shift=1,
                 attention_head_dim=None, act_fn='silu')
+
+
+# --------------------------------------------------------------------------------------------------------
+# Diffusers pipeline directories (ddpm_prune.py:50 DDPMPipeline.from_pretrained, :131 pipeline.save_pretrained;
+# ddpm_train.py:297-306,494-498; ddpm_sample.py:54-62)
+#   <dir>/model_index.json                         {"_class_name": ..., "scheduler": ["diffusers", cls], "unet": [...]}
+#   <dir>/unet/config.json                         constructor kwargs (+ "_class_name", "_diffusers_version")
+#   <dir>/unet/diffusion_pytorch_model.bin|.safetensors
+#   <dir>/scheduler/scheduler_config.json
+# Layout pinned by tests/golden/pretrained_micro/ (written by the vendored diffusers 0.17.0.dev0).
+# --------------------------------------------------------------------------------------------------------
+DIFFUSERS_VERSION = '0.17.0.dev0'
+_UNET_WEIGHTS = ('diffusion_pytorch_model.safetensors', 'diffusion_pytorch_model.bin')
+
+
+def _read_json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def _write_json(path, obj):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        json.dump(obj, f, indent=2, sort_keys=True)
+        f.write('\n')
+
+
+def load_unet(directory, subfolder=None):
+    """UNet2DModel.from_pretrained: `directory` (or its `subfolder`) holds config.json + the weight file."""
+    from .unet import UNet2DModel
+    d = os.path.join(directory, subfolder) if subfolder else directory
+    if not os.path.exists(os.path.join(d, 'config.json')) and os.path.exists(os.path.join(d, 'unet', 'config.json')):
+        d = os.path.join(d, 'unet')
+    cfg = {k: v for k, v in _read_json(os.path.join(d, 'config.json')).items() if not k.startswith('_')}
+    model = UNet2DModel(**cfg)
+    for name in _UNET_WEIGHTS:
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            if name.endswith('.safetensors'):
+                from safetensors.torch import load_file
+                sd = load_file(p)
+            else:
+                sd = torch.load(p, map_location='cpu', weights_only=True)
+            model.load_state_dict(sd, strict=True)
+            return model.eval()
+    raise FileNotFoundError('no %s in %s' % (' / '.join(_UNET_WEIGHTS), d))
+
+
+def save_unet(model, directory, safe_serialization=False):
+    """UNet2DModel.save_pretrained layout (the vendored diffusers writes the .bin pickle of the state dict by default)."""
+    os.makedirs(directory, exist_ok=True)
+    cfg = dict(_config_dict(model), _class_name='UNet2DModel', _diffusers_version=DIFFUSERS_VERSION)
+    _write_json(os.path.join(directory, 'config.json'), cfg)
+    sd = {k: v.detach().to('cpu').contiguous() for k, v in model.state_dict().items()}
+    if safe_serialization:
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(directory, _UNET_WEIGHTS[0]))
+    else:
+        torch.save(sd, os.path.join(directory, _UNET_WEIGHTS[1]))
+
+
+def load_scheduler(cls, directory, subfolder=None):
+    d = os.path.join(directory, subfolder) if subfolder else directory
+    if not os.path.exists(os.path.join(d, 'scheduler_config.json')) and os.path.exists(os.path.join(d, 'scheduler')):
+        d = os.path.join(d, 'scheduler')
+    cfg = {k: v for k, v in _read_json(os.path.join(d, 'scheduler_config.json')).items() if not k.startswith('_')}
+    if cfg.get('thresholding') or cfg.get('trained_betas') is not None:
+        raise NotImplementedError('thresholding / trained_betas schedulers are not on the hot path')
+    import inspect
+    accepted = set(inspect.signature(cls.__init__).parameters) - {'self'}
+    return cls(**{k: v for k, v in cfg.items() if k in accepted})
+
+
+def save_scheduler(scheduler, directory):
+    cfg = {k: v for k, v in vars(scheduler.config).items()}
+    cfg.update(_class_name=type(scheduler).__name__, _diffusers_version=DIFFUSERS_VERSION)
+    _write_json(os.path.join(directory, 'scheduler_config.json'), cfg)
+
+
+def load_pipeline(cls, directory):
+    from . import diffusion
+    index = _read_json(os.path.join(directory, 'model_index.json'))
+    sched_name = index.get('scheduler', [None, 'DDPMScheduler'])[1]
+    sched_cls = getattr(diffusion, sched_name, None)
+    if sched_cls is None:
+        raise NotImplementedError('scheduler class %s' % sched_name)
+    return cls(unet=load_unet(directory, 'unet'), scheduler=load_scheduler(sched_cls, directory, 'scheduler'))
+
+
+def save_pipeline(pipeline, directory, safe_serialization=False):
+    _write_json(os.path.join(directory, 'model_index.json'),
+                dict(_class_name=type(pipeline).__name__, _diffusers_version=DIFFUSERS_VERSION,
+                     scheduler=['diffusers', type(pipeline.scheduler).__name__], unet=['diffusers', 'UNet2DModel']))
+    save_unet(pipeline.unet, os.path.join(directory, 'unet'), safe_serialization)
+    save_scheduler(pipeline.scheduler, os.path.join(directory, 'scheduler'))

@@ -42,6 +42,15 @@ def _betas(num_train_timesteps, beta_start, beta_end, beta_schedule):
 
 
 class _SchedulerBase:
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, **kwargs):
+        from . import checkpoint
+        return checkpoint.load_scheduler(cls, pretrained_model_name_or_path, subfolder)
+
+    def save_pretrained(self, save_directory):
+        from . import checkpoint
+        checkpoint.save_scheduler(self, save_directory)
+
     def _init_tables(self, num_train_timesteps, beta_start, beta_end, beta_schedule):
         self.betas = _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
         self.alphas = 1.0 - self.betas
@@ -161,6 +170,20 @@ class ImagePipelineOutput:
 class _PipelineBase:
     def __init__(self, unet, scheduler):
         self.unet, self.scheduler = unet, scheduler
+        self._progress_bar_config = {}
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **kwargs):
+        """A local Diffusers pipeline directory (model_index.json, unet/, scheduler/); there is no hub access."""
+        from . import checkpoint
+        return checkpoint.load_pipeline(cls, pretrained_model_name_or_path)
+
+    def save_pretrained(self, save_directory, safe_serialization=False):
+        from . import checkpoint
+        checkpoint.save_pipeline(self, save_directory, safe_serialization)
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
 
     @property
     def device(self):
@@ -171,7 +194,11 @@ class _PipelineBase:
         return self
 
     def progress_bar(self, it):
-        return it
+        cfg = getattr(self, '_progress_bar_config', {})
+        if cfg.get('disable', True):               # quiet unless asked for (pipeline_utils.py progress_bar + tqdm)
+            return it
+        from tqdm import tqdm
+        return tqdm(it, **cfg)
 
     @staticmethod
     def numpy_to_pil(images):

@@ -220,6 +220,16 @@ class UNet2DModel(nn.Module):
     def from_config(cls, config):
         return cls(**{k: v for k, v in dict(config).items() if not k.startswith('_')})
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, **kwargs):
+        """config.json + diffusion_pytorch_model.{safetensors,bin} in a local directory (modeling_utils.py layout)."""
+        from . import checkpoint
+        return checkpoint.load_unet(pretrained_model_name_or_path, subfolder)
+
+    def save_pretrained(self, save_directory, safe_serialization=False):
+        from . import checkpoint
+        checkpoint.save_unet(self, save_directory, safe_serialization)
+
     def engine(self):
         """The HIP execution engine bound to the *current* parameter tensors (re-bound after pruning)."""
         if self.conv_in.weight.device.type != 'cuda':

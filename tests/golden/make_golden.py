@@ -315,6 +315,26 @@ def do_optim():
     print('optim ok', [r['norm'] for r in rec])
 
 
+def do_pretrained():
+    """A Diffusers pipeline directory as the reference writes it (ddpm_prune.py:50,131: DDPMPipeline.from_pretrained /
+    save_pretrained): micro UNet (9 k parameters) with seeded weights -> tests/golden/pretrained_micro/."""
+    import shutil
+    from diffusers import DDPMPipeline
+    cfg = dict(gc.TINY_CFG, block_out_channels=[8, 8], down_block_types=['DownBlock2D', 'AttnDownBlock2D'],
+               up_block_types=['AttnUpBlock2D', 'UpBlock2D'], norm_num_groups=4, sample_size=8, layers_per_block=1)
+    model = build_ref_unet(cfg, 71)
+    out = os.path.join(HERE, 'pretrained_micro')
+    shutil.rmtree(out, ignore_errors=True)
+    DDPMPipeline(unet=model, scheduler=DDPMScheduler(num_train_timesteps=1000)).save_pretrained(out)
+    x = torch.from_numpy(gc.det_noise((1, 3, 8, 8), 72))
+    with torch.no_grad():
+        y = model(x, torch.tensor([10])).sample
+    np.savez(os.path.join(out, 'expected.npz'), fwd_out=y.numpy())
+    for root, _, files in os.walk(out):
+        for f in files:
+            print(os.path.relpath(os.path.join(root, f), out), os.path.getsize(os.path.join(root, f)))
+
+
 def do_criteria():
     """The sibling criteria selectable in ddpm_exp/prune.py:193-208 on the tiny UNet after a 4-step sweep:
     per-group score vectors and pruned index lists of the whole sequential prune, one run per criterion."""
@@ -383,6 +403,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained']
     for w in what:
         globals()['do_' + w]()

@@ -9,6 +9,8 @@ import pytest
 import torch
 
 import golden_common as gc
+import os as _os
+GOLD_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
 from helpers import GOLD, load_json, load_npz, oracle_params, pkg, relerr, oracle_prune_replay
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +28,45 @@ def test_library_exports_every_declared_symbol():
     assert lib.dp_version() >= 100
     # struct sizes agree with the C header layout (all-int/pointer/long long members, natural alignment)
     assert ctypes.sizeof(L.ConvGeom) == 14 * 4 + 2 * 8
+
+
+def test_diffusers_pipeline_directory_io(tmp_path):
+    """DDPMPipeline.from_pretrained / save_pretrained (ddpm_prune.py:50,131) on a directory written by the vendored diffusers
+    (tests/golden/pretrained_micro): same config, same weights, oracle forward equals the reference's recorded output; our
+    own save_pretrained round-trips and writes the same file layout and JSON keys."""
+    import os
+    from oracle import unet_ref as U
+    diffusion, unet = pkg('diffusion'), pkg('unet')
+    src = os.path.join(GOLD_DIR, 'pretrained_micro')
+    pipe = diffusion.DDPMPipeline.from_pretrained(src)
+    assert isinstance(pipe.unet, unet.UNet2DModel) and isinstance(pipe.scheduler, diffusion.DDPMScheduler)
+    assert pipe.scheduler.config.num_train_timesteps == 1000 and pipe.unet.config.sample_size == 8
+    sd = pipe.unet.state_dict()
+    for n, p in sd.items():
+        assert torch.equal(p, torch.from_numpy(gc.det_param(n, tuple(p.shape), 71))), n
+    cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in dict(pipe.unet.config).items()}
+    x = torch.from_numpy(gc.det_noise((1, 3, 8, 8), 72))
+    with torch.no_grad():
+        y = U.unet_forward({k: v.clone() for k, v in sd.items()}, cfg, x, torch.tensor([10]))
+    want = np.load(os.path.join(src, 'expected.npz'))['fwd_out']
+    assert float((y - torch.from_numpy(want)).abs().max()) < 1e-5
+    # write it back: same files, same JSON key sets and values, weights identical
+    pipe.set_progress_bar_config(disable=True)
+    out = str(tmp_path / 'saved')
+    pipe.save_pretrained(out)
+    import json
+    for rel in ('model_index.json', 'unet/config.json'):
+        assert json.load(open(os.path.join(out, rel))) == json.load(open(os.path.join(src, rel))), rel
+    ours, ref = json.load(open(os.path.join(out, 'scheduler/scheduler_config.json'))), json.load(open(os.path.join(src, 'scheduler/scheduler_config.json')))
+    assert all(ref[k] == v for k, v in ours.items())                   # every key we write exists with the same value
+    back = diffusion.DDPMPipeline.from_pretrained(out)
+    assert all(torch.equal(v, sd[k]) for k, v in back.unet.state_dict().items())
+    assert os.path.exists(os.path.join(out, 'unet', 'diffusion_pytorch_model.bin'))
+    pipe.save_pretrained(str(tmp_path / 'safe'), safe_serialization=True)
+    back = unet.UNet2DModel.from_pretrained(str(tmp_path / 'safe'), subfolder='unet')
+    assert all(torch.equal(v, sd[k]) for k, v in back.state_dict().items())
+    sched = diffusion.DDIMScheduler.from_pretrained(src, subfolder='scheduler')      # ddpm_prune.py:139-141
+    assert sched.config.num_train_timesteps == 1000
 
 
 def test_count_ops_and_params_matches_reference_c1():
