@@ -18,6 +18,11 @@ def antithetic_timesteps(bsz, num_train_timesteps, generator=None):
     return torch.cat([t, num_train_timesteps - t - 1], dim=0)[:bsz]
 
 
+def _require_hip_device(dev):
+    if dev.type != 'cuda':
+        raise RuntimeError('finetune runs on the MI355X HIP kernels only')
+
+
 class FinetuneEngine:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, ema_decay=0.9999, max_grad_norm=1.0,
                  use_ema=True, group=None, dropout=0.0):
@@ -28,8 +33,7 @@ class FinetuneEngine:
         self.ema_decay, self.max_grad_norm, self.group = ema_decay, max_grad_norm, group
         params = list(model.parameters())
         dev = params[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('finetune runs on the MI355X HIP kernels only')
+        _require_hip_device(dev)
         total = sum(p.numel() for p in params)
         self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -54,6 +58,29 @@ class FinetuneEngine:
             out[n] = self.ema[off:off + p.numel()].view_as(p)
             off += p.numel()
         return out
+
+    # ---- EMAModel.store / copy_to / restore (training_utils.py:220-262) as used around checkpoints and evaluation
+    #      (ddpm_train.py:387-401,489-514): swap the EMA weights into the live model and back
+    def _weights_changed(self):
+        eng = getattr(self.model, '_engine', None)
+        if eng is not None:
+            eng.packs.clear()                              # packed operands are stale
+
+    def ema_store(self):
+        self._stash = self.flat_p.clone()
+
+    def ema_copy_to(self):
+        if self.ema is None:
+            raise RuntimeError('FinetuneEngine was built with use_ema=False')
+        self.flat_p.copy_(self.ema)
+        self._weights_changed()
+
+    def ema_restore(self):
+        if getattr(self, '_stash', None) is None:
+            raise RuntimeError('This ExponentialMovingAverage has no `store()`ed weights to `restore()`')
+        self.flat_p.copy_(self._stash)
+        self._stash = None
+        self._weights_changed()
 
     def step(self, clean, noise, timesteps, global_batch=None):
         """Returns the (local share of the) loss as a [1] device tensor; no host synchronisation."""

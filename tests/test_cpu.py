@@ -586,6 +586,50 @@ def test_ddpm_exp_sweep_flavour_matches_reference_twin(mocked, monkeypatch):
             assert relerr(p.grad, P[n].grad) < 5e-5, n
 
 
+def test_finetune_engine_control_flow_and_ema_swaps(mocked, monkeypatch):
+    """FinetuneEngine (ddpm_train.py:453-469) on mocked kernels: two steps equal the oracle's loss / clip / Adam / EMA on the
+    same data; EMAModel.store / copy_to / restore semantics (training_utils.py:220-262) around a checkpoint."""
+    from oracle import diffusion_ref as D
+    train = pkg('train')
+    monkeypatch.setattr(train, '_require_hip_device', lambda dev: None)
+    cfg = gc.TINY_CFG
+    model = _cpu_model(cfg, 5)
+    sched = pkg('diffusion').DDPMScheduler()
+    monkeypatch.setattr(type(sched), '_acp_on', lambda self, dev: self.alphas_cumprod, raising=False)
+    ft = train.FinetuneEngine(model, sched, lr=2e-4)
+    names = [n for n, _ in model.named_parameters()]
+    P = oracle_params(cfg, 5)
+    plist = [P[n] for n in names]
+    m = [torch.zeros_like(p) for p in plist]
+    v = [torch.zeros_like(p) for p in plist]
+    ema = [p.detach().clone() for p in plist]
+    gen = torch.Generator().manual_seed(3)
+    for step in range(2):
+        clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 10 + step))
+        noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 20 + step))
+        t = train.antithetic_timesteps(2, 1000, gen)
+        loss = ft.step(clean, noise, t)
+        for p in plist:
+            p.grad = None
+        lo = D.finetune_loss(P, cfg, clean, noise, t)
+        lo.backward()
+        with torch.no_grad():
+            D.adam_ema_step([p.data for p in plist], [p.grad for p in plist], m, v, ema, step + 1, lr=2e-4)
+        assert abs(float(loss) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    live = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for n, p in zip(names, plist):
+        assert relerr(live[n], p.detach()) < 2e-4, n                  # Adam amplifies rounding on near-zero gradients
+    es = ft.ema_state()
+    for n, e in zip(names, ema):
+        assert relerr(es[n], e) < 1e-5, n
+    ft.ema_store(); ft.ema_copy_to()
+    assert all(torch.equal(p.detach(), es[n]) for n, p in model.named_parameters())       # the module now holds the EMA weights
+    ft.ema_restore()
+    assert all(torch.equal(p.detach(), live[n]) for n, p in model.named_parameters())
+    with pytest.raises(RuntimeError):
+        ft.ema_restore()
+
+
 def test_micro_batched_sweep_equals_full_shard(mocked, monkeypatch):
     """taylor_sweep(micro_batch=m): walking the shard in micro-batches inside every timestep gives the same losses and
     accumulated gradients (global loss scaling, fp32 re-association only) and the same early-exit step."""
