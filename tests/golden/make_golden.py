@@ -376,6 +376,30 @@ def do_groups():
     json.dump(out, open(os.path.join(HERE, 'groups.json'), 'w'))
 
 
+def do_groups_more():
+    """Further UNet2DModel topologies for the group enumeration (the graph is generic over block types, depths and widths):
+    all-attention blocks, 3 levels with layers_per_block 1 / 3, the Diffusers default head dim (attention_head_dim 8),
+    non-uniform widths."""
+    base = dict(gc.TINY_CFG)
+    variants = {
+        'all_attn_3lvl_l1': dict(base, block_out_channels=[16, 32, 32], layers_per_block=1, norm_num_groups=8, sample_size=16,
+                                 down_block_types=['AttnDownBlock2D'] * 3, up_block_types=['AttnUpBlock2D'] * 3),
+        'no_attn_2lvl_l3': dict(base, block_out_channels=[16, 48], layers_per_block=3, norm_num_groups=8, sample_size=16,
+                                down_block_types=['DownBlock2D'] * 2, up_block_types=['UpBlock2D'] * 2),
+        'heads8_4lvl': dict(base, block_out_channels=[16, 32, 48, 64], layers_per_block=2, norm_num_groups=8, sample_size=16,
+                            attention_head_dim=8,
+                            down_block_types=['DownBlock2D', 'AttnDownBlock2D', 'AttnDownBlock2D', 'DownBlock2D'],
+                            up_block_types=['UpBlock2D', 'AttnUpBlock2D', 'AttnUpBlock2D', 'UpBlock2D']),
+    }
+    out = {}
+    for name, cfg in variants.items():
+        model = build_ref_unet(cfg, 0)
+        out[name] = dict(cfg={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()},
+                         groups=group_table(model, cfg['sample_size']))
+        print(name, 'groups', len(out[name]['groups']))
+    json.dump(out, open(os.path.join(HERE, 'groups_more.json'), 'w'))
+
+
 def do_c1():
     cfg = gc.CIFAR_CFG
     model = build_ref_unet(cfg, 0)
@@ -403,6 +427,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more']
     for w in what:
         globals()['do_' + w]()

@@ -330,6 +330,15 @@ def test_group_enumeration_matches_reference_cifar():
     _check_groups(gc.CIFAR_CFG, load_json('groups.json')['cifar'])
 
 
+@pytest.mark.parametrize('variant', ['all_attn_3lvl_l1', 'no_attn_2lvl_l3', 'heads8_4lvl'])
+def test_group_enumeration_matches_reference_other_topologies(variant):
+    """The coupling graph is generic over UNet2DModel configs: all-attention blocks, other depths / layers_per_block,
+    multi-head attention (attention_head_dim 8), non-uniform widths -- group order and member index sets equal to the
+    vendored DependencyGraph's."""
+    fx = load_json('groups_more.json')[variant]
+    _check_groups(fx['cfg'], fx['groups'])
+
+
 def test_group_enumeration_matches_reference_bedroom_topology():
     cfg = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
     _check_groups(cfg, load_json('groups.json')['bedroom_topology'])
