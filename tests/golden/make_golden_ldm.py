@@ -56,14 +56,22 @@ if __name__ == '__main__' and len(sys.argv) == 1:
     print('ok', len(stats))
 
 
-def ldm_groups():
+LDM_VARIANTS = {      # other members of the configuration family (same block kinds, other depths / widths / attention levels)
+    'small_2lvl': dict(gc.LDM_TINY_CFG, image_size=8, model_channels=32, channel_mult=[1, 2], attention_resolutions=[1, 2],
+                       num_res_blocks=1),
+    'deep_3lvl': dict(gc.LDM_TINY_CFG, image_size=16, model_channels=32, channel_mult=[1, 1, 3], attention_resolutions=[4],
+                      num_res_blocks=3),
+}
+
+
+def ldm_groups(which=None, out_name='ldm_groups.json'):
     """Group table of the LDM UNet under the reference's vendored torch_pruning (prune_ldm.py:70-100 setup)."""
     sys.path.insert(0, '/root/reference/ddpm_exp')
     os.makedirs('/tmp/golden_scratch', exist_ok=True)
     os.chdir('/tmp/golden_scratch')
     import torch_pruning as tp
     out = {}
-    for tag, cfg in (('tiny', gc.LDM_TINY_CFG),):
+    for tag, cfg in (which or (('tiny', gc.LDM_TINY_CFG),)):
         m = UNetModel(**cfg).eval()
         gc.det_init_(m, 9)
         H = cfg['image_size']
@@ -95,11 +103,13 @@ def ldm_groups():
             table.append(dict(ch_groups=int(pr.get_channel_groups(g)), members=mem))
         out[tag] = table
         print(tag, 'groups', len(table))
-    json.dump(out, open(os.path.join(HERE, 'ldm_groups.json'), 'w'))
+    json.dump(out, open(os.path.join(HERE, out_name), 'w'))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'groups':
     ldm_groups()
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'groups_more':
+    ldm_groups(tuple(LDM_VARIANTS.items()), 'ldm_groups_more.json')
 
 
 def ldm_prune():

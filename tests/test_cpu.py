@@ -878,6 +878,25 @@ def test_ldm_group_enumeration_matches_reference():
         assert {(m[0], m[1]): gc.expand(m[2]) for m in ref['members']} == {(m.name, m.kind): m.idxs for m in mem}, root
 
 
+@pytest.mark.parametrize('variant', ['small_2lvl', 'deep_3lvl'])
+def test_ldm_group_enumeration_other_configs(variant):
+    """LdmGraph over other members of the LDM UNet family (depths, widths, attention levels, res-block counts)."""
+    from oracle import ldm_ref as L
+    G = pkg('graph')
+    cfgs = {'small_2lvl': dict(gc.LDM_TINY_CFG, image_size=8, model_channels=32, channel_mult=[1, 2],
+                               attention_resolutions=[1, 2], num_res_blocks=1),
+            'deep_3lvl': dict(gc.LDM_TINY_CFG, image_size=16, model_channels=32, channel_mult=[1, 1, 3],
+                              attention_resolutions=[4], num_res_blocks=3)}
+    cfg = cfgs[variant]
+    table = load_json('ldm_groups_more.json')[variant]
+    shapes = L.ldm_param_shapes(cfg)
+    groups = list(G.all_groups(G.LdmGraph(cfg), lambda: G.ChannelView(shapes), ('out', 'out.0', 'out.1', 'out.2')))
+    assert len(groups) == len(table)
+    for ref, (root, mem) in zip(table, groups):
+        assert ref['members'][0][0] == root
+        assert {(m[0], m[1]): gc.expand(m[2]) for m in ref['members']} == {(m.name, m.kind): m.idxs for m in mem}, root
+
+
 def _ldm_grads_oracle():
     from oracle import ldm_ref as L
     cfg = gc.LDM_TINY_CFG
