@@ -97,8 +97,8 @@ def _attn(cfg, channels, rescale=1.0):
     hd = cfg['attention_head_dim']
     heads = channels // hd if hd is not None else 1
     dim_head = hd if hd is not None else channels
-    if heads != 1:
-        raise NotImplementedError('multi-head attention (attention_head_dim=%r) is outside the DDPM hot path' % hd)
+    # heads > 1 (e.g. CompVis/ldm-celebahq-256, attention_head_dim 32): the module can be built, loaded, pruned (head-grouped
+    # channel selection, ldm_prune.py:73-79) and saved; running it raises in engine() -- the HIP attention path is single-head
     return Attention(channels, heads, dim_head, cfg['norm_num_groups'], cfg['norm_eps'], rescale)
 
 
@@ -199,6 +199,7 @@ class UNet2DModel(nn.Module):
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], cfg['out_channels'], 3, padding=1)
         self._engine = None
+        self._multi_head = any(getattr(m, 'heads', 1) != 1 for m in self.modules())
 
     def __getstate__(self):
         """Whole-module pickles (`torch.save(model, 'unet_pruned.pth')`, ddpm_prune.py:135) carry parameters and shapes
@@ -232,6 +233,9 @@ class UNet2DModel(nn.Module):
 
     def engine(self):
         """The HIP execution engine bound to the *current* parameter tensors (re-bound after pruning)."""
+        if self._multi_head:
+            raise NotImplementedError('multi-head attention (attention_head_dim=%r) is not implemented in the HIP engine'
+                                      % self.config['attention_head_dim'])
         if self.conv_in.weight.device.type != 'cuda':
             raise RuntimeError('UNet2DModel runs on the MI355X HIP kernels only: move the model to a cuda device '
                                '(there is no CPU / PyTorch fallback)')

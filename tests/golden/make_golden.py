@@ -397,6 +397,26 @@ def do_groups_more():
         out[name] = dict(cfg={k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()},
                          groups=group_table(model, cfg['sample_size']))
         print(name, 'groups', len(out[name]['groups']))
+    # ldm_prune.py:62-90 on the multi-head variant: MagnitudeImportance + channel_groups = attention heads (q/k/v selected
+    # per head), ratio 0.3 -- the pruned index list of every group
+    cfg = variants['heads8_4lvl']
+    model = build_ref_unet(cfg, 4)
+    channel_groups = {}
+    for m in model.modules():
+        if isinstance(m, Attention):
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    ex = {'sample': torch.randn(1, 3, 16, 16), 'timestep': torch.ones((1,)).long()}
+    pruner = tp.pruner.MagnitudePruner(model, ex, importance=tp.importance.MagnitudeImportance(), iterative_steps=1,
+                                       channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.conv_out])
+    names = name_of(model)
+    rec = []
+    for g in pruner.step(interactive=True):
+        rec.append(dict(root=names[g[0][0].target.module], ch_groups=int(pruner.get_channel_groups(g)),
+                        pruned=compress(sorted(int(i) for i in g[0][1]))))
+        g.prune()
+    out['heads8_4lvl']['magnitude_prune'] = dict(seed=4, records=rec, params_after=int(sum(p.numel() for p in model.parameters())),
+                                                 shapes_after={n: list(p.shape) for n, p in model.named_parameters()})
+    print('heads8 magnitude prune groups', len(rec), 'head-grouped', sum(1 for r in rec if r['ch_groups'] > 1 and r['ch_groups'] != 8))
     json.dump(out, open(os.path.join(HERE, 'groups_more.json'), 'w'))
 
 

@@ -339,6 +339,41 @@ def test_group_enumeration_matches_reference_other_topologies(variant):
     _check_groups(fx['cfg'], fx['groups'])
 
 
+def test_multi_head_unet_magnitude_prune_with_head_groups(mocked):
+    """ldm_prune.py:62-90 shape of use: a multi-head UNet2DModel (attention_head_dim 8) is built, pruned with
+    MagnitudeImportance and channel_groups = attention heads (per-head channel selection), and reproduces the reference's
+    pruned index lists, shapes and parameter count; running it is refused (the HIP attention path is single-head)."""
+    pruning, unet = pkg('pruning'), pkg('unet')
+    fx = load_json('groups_more.json')['heads8_4lvl']
+    mp = fx['magnitude_prune']
+    model = unet.UNet2DModel(**fx['cfg'])
+    gc.det_init_(model, mp['seed'])
+    channel_groups = {}
+    for m in model.modules():
+        if isinstance(m, unet.Attention):
+            assert m.heads > 1
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    pr = pruning.MagnitudePruner(model, None, importance=pruning.MagnitudeImportance(), iterative_steps=1,
+                                 channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.conv_out])
+    for g in pr.step(interactive=True):
+        g.prune()
+    assert [r[0] for r in pr.records] == [r['root'] for r in mp['records']]
+    want = [[i for a, b in r['pruned'] for i in range(a, b)] for r in mp['records']]
+    assert [r[3] for r in pr.records] == want
+    # (16-channel layers under 8 GroupNorm groups lose 5 // 8 = 0 channels per sub-group: empty lists on both sides; the
+    #  fixture's ch_groups of such an empty group was read from a root-only group and is not meaningful)
+    assert all(r[1] == ref['ch_groups'] for r, ref, w in zip(pr.records, mp['records'], want) if w)
+    assert any(ref['ch_groups'] not in (1, 8) for ref, w in zip(mp['records'], want) if w)      # head-grouped q/k/v present
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == mp['shapes_after']
+    assert sum(p.numel() for p in model.parameters()) == mp['params_after']
+
+
+def test_multi_head_unet_refuses_to_run():
+    m = pkg('unet').UNet2DModel(**load_json('groups_more.json')['heads8_4lvl']['cfg'])
+    with pytest.raises(NotImplementedError):
+        m.engine()
+
+
 def test_group_enumeration_matches_reference_bedroom_topology():
     cfg = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
     _check_groups(cfg, load_json('groups.json')['bedroom_topology'])
