@@ -233,7 +233,7 @@ class UNet2DModel(nn.Module):
 
     def engine(self):
         """The HIP execution engine bound to the *current* parameter tensors (re-bound after pruning)."""
-        if self._multi_head:
+        if getattr(self, '_multi_head', False):
             raise NotImplementedError('multi-head attention (attention_head_dim=%r) is not implemented in the HIP engine'
                                       % self.config['attention_head_dim'])
         if self.conv_in.weight.device.type != 'cuda':
