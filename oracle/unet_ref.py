@@ -62,11 +62,13 @@ def resnet_block(P, pre, x, temb, groups, eps, out_scale):
     return (x + h) / out_scale
 
 
-def attention_block(P, pre, x, groups, eps, scale, rescale):
-    """attention_processor.py:415-470, heads == 1, residual_connection=True.
+def attention_block(P, pre, x, groups, eps, scale, rescale, heads=1):
+    """attention_processor.py:415-470 (AttnProcessor; head_to_batch_dim / batch_to_head_dim :283-305), residual_connection=True.
 
-    `scale` is the module attribute fixed at construction (dim_head ** -0.5 with dim_head = the
-    *un-pruned* channel count, attention_processor.py:85-86); inner width comes from to_q."""
+    `scale` and `heads` are module attributes fixed at construction (dim_head ** -0.5 with dim_head = attention_head_dim
+    or the *un-pruned* channel count, heads = channels // attention_head_dim; attention_processor.py:85-86,
+    unet_2d_blocks.py:722-723); the inner width comes from to_q, so after pruning a head has inner // heads channels.
+    heads > 1 is pinned by tests/golden/tiny_heads.npz."""
     B, C, H, W = x.shape
     res = x
     h = x.view(B, C, H * W).transpose(1, 2)
@@ -75,10 +77,17 @@ def attention_block(P, pre, x, groups, eps, scale, rescale):
     q = _lin(P, pre + '.to_q', h)
     k = _lin(P, pre + '.to_k', h)
     v = _lin(P, pre + '.to_v', h)
-    s = torch.baddbmm(torch.empty(B, q.shape[1], k.shape[1], dtype=q.dtype, device=q.device), q,
+    T = q.shape[1]
+    if heads > 1:
+        def to_batch(t):
+            return t.reshape(B, T, heads, t.shape[-1] // heads).permute(0, 2, 1, 3).reshape(B * heads, T, t.shape[-1] // heads)
+        q, k, v = to_batch(q), to_batch(k), to_batch(v)
+    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device), q,
                       k.transpose(-1, -2), beta=0, alpha=scale)
     p = s.float().softmax(dim=-1).to(q.dtype)
     h = torch.bmm(p, v)
+    if heads > 1:
+        h = h.reshape(B, heads, T, h.shape[-1]).permute(0, 2, 1, 3).reshape(B, T, heads * h.shape[-1])
     h = _lin(P, pre + '.to_out.0', h)
     h = h.transpose(-1, -2).reshape(B, C, H, W)
     return (h + res) / rescale
@@ -101,6 +110,11 @@ def attn_scale_for(cfg, channels):
     hd = cfg.get('attention_head_dim')
     dim_head = hd if hd is not None else channels
     return float(dim_head) ** -0.5
+
+
+def attn_heads_for(cfg, channels):
+    hd = cfg.get('attention_head_dim')
+    return channels // hd if hd is not None else 1
 
 
 def unet_forward(P, cfg, sample, timesteps):
@@ -127,7 +141,7 @@ def unet_forward(P, cfg, sample, timesteps):
             x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0)
             if bt == 'AttnDownBlock2D':
                 x = attention_block(P, '%s.attentions.%d' % (pre, j), x, groups, eps,
-                                    attn_scale_for(cfg, boc[i]), 1.0)
+                                    attn_scale_for(cfg, boc[i]), 1.0, attn_heads_for(cfg, boc[i]))
             skips.append(x)
         if i != nb - 1:
             x = downsample(P, pre + '.downsamplers.0', x, cfg['downsample_padding'])
@@ -136,7 +150,8 @@ def unet_forward(P, cfg, sample, timesteps):
     msf = float(cfg.get('mid_block_scale_factor', 1))
     x = resnet_block(P, 'mid_block.resnets.0', x, emb, groups, eps, msf)
     if cfg.get('add_attention', True):
-        x = attention_block(P, 'mid_block.attentions.0', x, groups, eps, attn_scale_for(cfg, boc[-1]), msf)
+        x = attention_block(P, 'mid_block.attentions.0', x, groups, eps, attn_scale_for(cfg, boc[-1]), msf,
+                            attn_heads_for(cfg, boc[-1]))
     x = resnet_block(P, 'mid_block.resnets.1', x, emb, groups, eps, msf)
 
     rev = list(reversed(boc))
@@ -147,7 +162,7 @@ def unet_forward(P, cfg, sample, timesteps):
             x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0)
             if bt == 'AttnUpBlock2D':
                 x = attention_block(P, '%s.attentions.%d' % (pre, j), x, groups, eps,
-                                    attn_scale_for(cfg, rev[i]), 1.0)
+                                    attn_scale_for(cfg, rev[i]), 1.0, attn_heads_for(cfg, rev[i]))
         if i != nb - 1:
             x = upsample(P, pre + '.upsamplers.0', x)
 

@@ -420,6 +420,22 @@ def do_groups_more():
     json.dump(out, open(os.path.join(HERE, 'groups_more.json'), 'w'))
 
 
+def do_tiny_heads():
+    """Multi-head attention (attention_head_dim 8) on the 'heads8_4lvl' topology: forward, two sweep steps, gradient stats."""
+    cfg = json.load(open(os.path.join(HERE, 'groups_more.json')))['heads8_4lvl']['cfg']
+    model = build_ref_unet(cfg, 4)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 81))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 82))
+    t = torch.tensor([5, 700])
+    with torch.no_grad():
+        y = model(sched.add_noise(clean, noise, t), t).sample.numpy()
+    losses = sweep(model, sched, clean, noise, 2)
+    np.savez(os.path.join(HERE, 'tiny_heads.npz'), fwd_out=y, losses=np.array(losses))
+    json.dump(dict(grad_stats=grad_stats(model)), open(os.path.join(HERE, 'tiny_heads.json'), 'w'))
+    print('tiny heads ok', y.shape, losses)
+
+
 def do_c1():
     cfg = gc.CIFAR_CFG
     model = build_ref_unet(cfg, 0)
@@ -447,6 +463,6 @@ def do_c1():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads']
     for w in what:
         globals()['do_' + w]()

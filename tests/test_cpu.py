@@ -368,6 +368,26 @@ def test_multi_head_unet_magnitude_prune_with_head_groups(mocked):
     assert sum(p.numel() for p in model.parameters()) == mp['params_after']
 
 
+def test_oracle_multi_head_attention_matches_reference():
+    """Oracle UNet with attention_head_dim 8 (4 / 6 / 8 heads) against the reference UNet2DModel: forward, sweep losses and
+    gradient statistics (the restatement next round's multi-head engine path will be checked against)."""
+    from oracle import diffusion_ref as D, unet_ref as U
+    cfg = load_json('groups_more.json')['heads8_4lvl']['cfg']
+    fx, g = load_json('tiny_heads.json'), load_npz('tiny_heads.npz')
+    P = oracle_params(cfg, 4)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 81))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 82))
+    t = torch.tensor([5, 700])
+    with torch.no_grad():
+        y = U.unet_forward(P, cfg, D.add_noise(D.alphas_cumprod(), clean, noise, t), t)
+    assert float((y - torch.from_numpy(g['fwd_out'])).abs().max()) < 1e-5
+    losses = D.taylor_sweep(P, cfg, clean, noise, 2)
+    assert np.allclose(losses, g['losses'], rtol=1e-5)
+    for n, (s, a, q) in fx['grad_stats'].items():
+        gr = P[n].grad.double()
+        assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
+
+
 def test_multi_head_unet_refuses_to_run():
     m = pkg('unet').UNet2DModel(**load_json('groups_more.json')['heads8_4lvl']['cfg'])
     with pytest.raises(NotImplementedError):
