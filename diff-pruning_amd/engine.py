@@ -216,7 +216,12 @@ class UNetEngine:
         return dx
 
     # ---- Attention (attention_processor.py:415-470, heads == 1) ---------------------------------
-    def attn_fwd(self, pre, x, scale, rescale, save):
+    def attn_heads(self, channels):
+        """Heads of an attention block over `channels` (un-pruned width; fixed at construction, unet_2d_blocks.py:722-723)."""
+        hd = self.cfg.get('attention_head_dim')
+        return channels // hd if hd is not None else 1
+
+    def attn_fwd(self, pre, x, scale, rescale, save, heads=1):
         P, cfg = self.P, self.cfg
         G, eps = cfg['norm_num_groups'], cfg['norm_eps']
         N, C, H, W = x.shape
@@ -226,16 +231,19 @@ class UNetEngine:
         k = self._conv(pre + '.to_k', n, None, _SPEC1)
         v = self._conv(pre + '.to_v', n, None, _SPEC1)
         inner = q.shape[1]
-        s = ops.bmm_tn(q.view(N, inner, T), k.view(N, inner, T), alpha=scale)
+        # heads: channel-major tokens make head_to_batch_dim (attention_processor.py:283-305) a view: head h owns the
+        # contiguous channel rows [h*d, (h+1)*d) of every image -> batch index n*heads + h
+        Z, d = N * heads, inner // heads
+        s = ops.bmm_tn(q.view(Z, d, T), k.view(Z, d, T), alpha=scale)
         p = ops.softmax_fwd(s, out=s)
-        o = ops.bmm_nt(v.view(N, inner, T), p)
+        o = ops.bmm_nt(v.view(Z, d, T), p)
         out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
         if save is not None:
-            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale)
+            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads)
         return out
 
     def attn_bwd(self, pre, dout, extra=None):
-        x, st, n, q, k, v, p, o, scale, rescale = self.ctx.pop(pre)
+        x, st, n, q, k, v, p, o, scale, rescale, heads = self.ctx.pop(pre)
         P, cfg = self.P, self.cfg
         G = cfg['norm_num_groups']
         N, C, H, W = x.shape
@@ -246,12 +254,13 @@ class UNetEngine:
         if rescale != 1.0:
             d = ops.axpby(dout.contiguous(), 1.0 / rescale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
         do = self._conv_bwd(pre + '.to_out.0', d, o.view(N, inner, H, W), None, _SPEC1, hw)
-        do3 = do.view(N, inner, T)
+        Z, dh = N * heads, inner // heads
+        do3 = do.view(Z, dh, T)
         dv = ops.bmm_nn(do3, p)
-        dp = ops.bmm_tn(do3, v.view(N, inner, T))
+        dp = ops.bmm_tn(do3, v.view(Z, dh, T))
         ds = ops.softmax_bwd(p, dp, scale, out=dp)
-        dq = ops.bmm_nt(k.view(N, inner, T), ds)
-        dk = ops.bmm_nn(q.view(N, inner, T), ds)
+        dq = ops.bmm_nt(k.view(Z, dh, T), ds)
+        dk = ops.bmm_nn(q.view(Z, dh, T), ds)
         dn = torch.empty_like(n)
         first = True
         for dproj, name in ((dq, '.to_q'), (dk, '.to_k'), (dv, '.to_v')):
@@ -285,7 +294,7 @@ class UNetEngine:
             for j in range(Lr):
                 x = self.resnet_fwd('%s.resnets.%d' % (pre, j), x, None, semb, 1.0, ctx)
                 if bt == 'AttnDownBlock2D':
-                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(boc[i]), 1.0, ctx)
+                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(boc[i]), 1.0, ctx, self.attn_heads(boc[i]))
                 skips.append(x)
             if i != nb - 1:
                 spec = ops.ConvSpec(3, 2, cfg['downsample_padding'], 0)
@@ -297,7 +306,7 @@ class UNetEngine:
         msf = float(cfg.get('mid_block_scale_factor', 1))
         x = self.resnet_fwd('mid_block.resnets.0', x, None, semb, msf, ctx)
         if cfg.get('add_attention', True):
-            x = self.attn_fwd('mid_block.attentions.0', x, self.attn_scale(boc[-1]), msf, ctx)
+            x = self.attn_fwd('mid_block.attentions.0', x, self.attn_scale(boc[-1]), msf, ctx, self.attn_heads(boc[-1]))
         x = self.resnet_fwd('mid_block.resnets.1', x, None, semb, msf, ctx)
         rev = list(reversed(boc))
         n_skips = len(skips)
@@ -307,7 +316,7 @@ class UNetEngine:
                 skip = skips.pop()
                 x = self.resnet_fwd('%s.resnets.%d' % (pre, j), x, skip, semb, 1.0, ctx)
                 if bt == 'AttnUpBlock2D':
-                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(rev[i]), 1.0, ctx)
+                    x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(rev[i]), 1.0, ctx, self.attn_heads(rev[i]))
             if i != nb - 1:
                 xin = x
                 x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC_UP)

@@ -388,6 +388,26 @@ def test_oracle_multi_head_attention_matches_reference():
         assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
 
 
+def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkeypatch):
+    """The engine's attention forward / backward with heads > 1 (head h = contiguous channel rows of every image -> batch
+    index n*heads + h of the same batched products) against the pinned multi-head oracle, on mocked kernels.  (On the GPU
+    UNet2DModel.engine() still refuses multi-head models until this path has run there.)"""
+    from oracle import diffusion_ref as D
+    sweep = pkg('sweep')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    cfg = load_json('groups_more.json')['heads8_4lvl']['cfg']
+    model = _cpu_model(cfg, 4)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 81))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 82))
+    res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=2)
+    P = oracle_params(cfg, 4)
+    losses = D.taylor_sweep(P, cfg, clean, noise, 2)
+    assert np.allclose(res['losses'], losses, rtol=1e-5)
+    for n, p in model.named_parameters():
+        if P[n].grad.abs().max() > 1e-7:
+            assert relerr(p.grad, P[n].grad) < 5e-5, n
+
+
 def test_multi_head_unet_refuses_to_run():
     m = pkg('unet').UNet2DModel(**load_json('groups_more.json')['heads8_4lvl']['cfg'])
     with pytest.raises(NotImplementedError):
