@@ -40,6 +40,8 @@ def patch():
         self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
         self.acp = scheduler.alphas_cumprod
     sweep.HipSweepStep.__init__ = step_init
+    train._require_hip_device = lambda dev: None
+    pkg('diffusion').DDPMScheduler._acp_on = lambda self, dev: self.alphas_cumprod
 
 
 def main():
@@ -63,7 +65,23 @@ def main():
     grads = {n: p.grad.clone() for n, p in model.named_parameters()}
     pr = pkg('sweep').prune_model(model, 0.3)
     masks = [r[3] for r in pr.records]
-    torch.save(dict(losses=res['losses'], steps=res['steps'], grads=grads, masks=masks,
+    # finetune (config C4): two optimizer steps on the pruned model, gradient all-reduce over the ranks every step
+    for p in model.parameters():
+        p.grad = None
+    ft = pkg('train').FinetuneEngine(model, sched, lr=2e-4)
+    gen = torch.Generator().manual_seed(11)
+    ft_losses = []
+    for step in range(2):
+        fc = torch.from_numpy(gc.det_clean((B, 3, 16, 16), 30 + step))
+        fn = torch.from_numpy(gc.det_noise((B, 3, 16, 16), 40 + step))
+        t = pkg('train').antithetic_timesteps(B, 1000, gen)
+        l = ft.step(fc[sl], fn[sl], t[sl])
+        if world > 1:
+            dist.all_reduce(l)
+        ft_losses.append(float(l))
+    ft_params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    torch.save(dict(losses=res['losses'], steps=res['steps'], grads=grads, masks=masks, ft_losses=ft_losses,
+                    ft_params=ft_params, ft_norm=float(ft.last_grad_norm),
                     global_batch=res['global_batch']), os.path.join(outdir, 'r%d_w%d.pt' % (rank, world)))
     if world > 1:
         dist.barrier()

@@ -1,4 +1,4 @@
-"""world_size-2 (gloo, CPU) test of the data-parallel sweep: batch shards + scalar-loss all-reduce for the early exit +
+"""world_size-2 (gloo, CPU) test of the data-parallel sweep and of the data-parallel finetune step: batch shards + scalar-loss all-reduce for the early exit +
 one gradient all-reduce give the same stop step, the same gradients and the same prune masks as a single process."""
 import os
 import socket
@@ -43,3 +43,10 @@ def test_two_rank_sweep_equals_single_process(tmp_path):
         if scale > 1e-7:
             assert float((r0['grads'][n] - g).abs().max()) <= 2e-5 * scale, n
     assert r0['masks'] == r1['masks'] == one['masks']                       # identical prune masks
+    # finetune steps (C4): same loss, same pre-clip gradient norm, same parameters after two Adam + EMA steps
+    for a, b, c in zip(one['ft_losses'], r0['ft_losses'], r1['ft_losses']):
+        assert abs(a - b) <= 1e-5 * abs(a) and b == c
+    assert abs(one['ft_norm'] - r0['ft_norm']) <= 1e-4 * one['ft_norm'] and r0['ft_norm'] == r1['ft_norm']
+    for n, p in one['ft_params'].items():
+        assert torch.equal(r0['ft_params'][n], r1['ft_params'][n])
+        assert float((r0['ft_params'][n] - p).abs().max()) <= 2e-4 * float(p.abs().max()) + 1e-7, n
