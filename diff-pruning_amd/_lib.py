@@ -46,7 +46,13 @@ class NtGemmParams(C.Structure):
                 ('o_tap_stride', LL), ('o_col_stride', C.c_int), ('_pad2', C.c_int), ('col_bias', C.c_void_p)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [('thr24', C.c_uint), ('scale', C.c_float), ('seed', C.c_ulonglong), ('site', C.c_uint), ('step', C.c_uint),
+                ('n_off', LL)]
+
+
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL
+_dr = C.POINTER(Dropout)
 
 # name -> argtypes (restype is always int); this table is also what the CPU test-suite checks against
 # include/dp_hip.h (every declared symbol must resolve).
@@ -56,12 +62,13 @@ SIGNATURES = {
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
     'dp_splitk_reduce_taps': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp],
     'dp_pack_weight': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
-    'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _vp],
+    'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _dr, _vp],
     'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
-                              _vp, _ll, _vp, _vp],
-    'dp_groupnorm_silu_fwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp, _vp],
+                              _vp, _ll, _vp, _dr, _vp],
+    'dp_groupnorm_silu_fwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp, _dr,
+                                    _vp],
     'dp_groupnorm_silu_bwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
-                                    _vp, _ll, _vp, _i, _vp, _vp],
+                                    _vp, _ll, _vp, _i, _vp, _dr, _vp],
     'dp_colsum_accum': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     'dp_rowsum_nc': [_vp, _ll, _i, _i, _i, _vp, _vp],
     'dp_silu_fwd': [_vp, _vp, _ll, _vp],
@@ -80,7 +87,10 @@ SIGNATURES = {
     'dp_sumsq_partials': [_vp, _ll, _vp, _i, _vp],
     'dp_clip_coef': [_vp, _i, _f, _vp, _vp, _vp],
     'dp_adam_ema': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
-    'dp_ddim_step': [_vp, _vp, _vp, _f, _f, _f, _i, _vp, _ll, _vp],
+    'dp_ddim_step': [_vp, _vp, _vp, _f, _f, _f, _i, _f, _vp, _ll, _vp],
+    'dp_ddpm_step': [_vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _ll, _vp],
+    'dp_dropout_apply': [_vp, _ll, _vp, _ll, _i, _ll, _dr, _vp],
+    'dp_dropout_mask': [_vp, _ll, _ll, _dr, _vp],
     'dp_layernorm_fwd': [_vp, _ll, _vp, _vp, _i, _i, _i, _f, _vp, _ll, _vp, _vp],
     'dp_layernorm_bwd': [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _vp],
     'dp_geglu_fwd': [_vp, _i, _ll, _vp, _vp],

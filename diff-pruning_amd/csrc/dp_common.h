@@ -59,4 +59,59 @@ __device__ __forceinline__ float dp_silu_grad(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dropout masks: counter-based Philox4x32-10 (Salmon et al., SC'11; the Random123 constants), so the backward pass
+// REGENERATES the mask of the forward pass from (seed, site, step, element index) instead of storing it, and a CPU
+// restatement (oracle/philox_ref.py) reproduces every mask bit-for-bit.
+//   counter = (idx4 lo, idx4 hi, site, step), key = (seed lo, seed hi); element idx takes output word idx & 3;
+//   keep iff (word >> 8) >= thr24  (thr24 = ceil(p * 2^24));  kept values are scaled by 1 / (1 - p).
+// idx is the LOGICAL element index ((n_global * C + c) * HW + hw), independent of strides and of the rank's shard.
+// ------------------------------------------------------------------------------------------------
+struct DpDrop {
+    unsigned thr24;            // 0 = dropout disabled
+    float scale;               // 1 / (1 - p)
+    unsigned seed_lo, seed_hi, site, step;
+    long long n_off;           // global index of this shard's first image
+};
+
+__device__ __forceinline__ uint4 dp_philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// multipliers (0 or scale) of the 4 elements idx .. idx+3, idx % 4 == 0
+__device__ __forceinline__ float4 dp_drop4(const DpDrop& d, long long idx) {
+    const unsigned long long q = (unsigned long long)idx >> 2;
+    const uint4 r = dp_philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.site, d.step), d.seed_lo, d.seed_hi);
+    return make_float4((r.x >> 8) >= d.thr24 ? d.scale : 0.f, (r.y >> 8) >= d.thr24 ? d.scale : 0.f,
+                       (r.z >> 8) >= d.thr24 ? d.scale : 0.f, (r.w >> 8) >= d.thr24 ? d.scale : 0.f);
+}
+
+__device__ __forceinline__ float dp_drop1(const DpDrop& d, long long idx) {
+    const float4 m = dp_drop4(d, idx & ~3ll);
+    const int j = (int)(idx & 3);
+    return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
+}
+
+static inline DpDrop dp_drop_host(const dp_dropout* d) {
+    DpDrop r{};
+    if (d && d->thr24) {
+        r.thr24 = d->thr24;
+        r.scale = d->scale;
+        r.seed_lo = (unsigned)(d->seed & 0xffffffffull);
+        r.seed_hi = (unsigned)(d->seed >> 32);
+        r.site = d->site;
+        r.step = d->step;
+        r.n_off = d->n_off;
+    }
+    return r;
+}
+
 #define DP_LAUNCH_CHECK() ((int)hipGetLastError())

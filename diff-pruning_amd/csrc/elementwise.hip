@@ -259,18 +259,18 @@ extern "C" int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, in
 // ---------------------------------------------------------------------------------------------
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ vn,
                                  float sqrt_a_t, float sqrt_b_t, float sqrt_a_prev, float dir_coef, float stdv, int clip,
-                                 float* __restrict__ out, long long n) {
+                                 float clip_range, float* __restrict__ out, long long n) {
     GS_LOOP(i, n) {
         const float e = eps[i];
         float x0 = (x[i] - sqrt_b_t * e) / sqrt_a_t;
-        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (clip) x0 = fminf(fmaxf(x0, -clip_range), clip_range);
         float v = sqrt_a_prev * x0 + dir_coef * e;
         if (vn) v += stdv * vn[i];
         out[i] = v;
     }
 }
 extern "C" int dp_ddim_step(const float* x, const float* eps, const float* vnoise, float a_t, float a_prev, float stdv,
-                            int clip, float* out, long long n, void* stream) {
+                            int clip, float clip_range, float* out, long long n, void* stream) {
     if (n <= 0) return 0;
     // coefficient arithmetic in fp32, in the reference's operation order (0-d fp32 tensors there)
     const float b_t = 1.0f - a_t;
@@ -279,7 +279,62 @@ extern "C" int dp_ddim_step(const float* x, const float* eps, const float* vnois
     const float sqrt_a_prev = powf(a_prev, 0.5f);
     const float dir_coef = powf(1.0f - a_prev - stdv * stdv, 0.5f);
     hipLaunchKernelGGL(ddim_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
-                       sqrt_b_t, sqrt_a_prev, dir_coef, stdv, clip, out, n);
+                       sqrt_b_t, sqrt_a_prev, dir_coef, stdv, clip, clip_range, out, n);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDPM ancestral update (scheduling_ddpm.py:360-401): coefficients arrive from the host (0-d fp32 arithmetic there)
+// ---------------------------------------------------------------------------------------------
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ vn,
+                                 float sqrt_a_t, float sqrt_b_t, float c_x0, float c_xt, float sigma, int clip,
+                                 float clip_range, float* __restrict__ out, long long n) {
+    GS_LOOP(i, n) {
+        const float xi = x[i];
+        float x0 = (xi - sqrt_b_t * eps[i]) / sqrt_a_t;
+        if (clip) x0 = fminf(fmaxf(x0, -clip_range), clip_range);
+        float v = c_x0 * x0 + c_xt * xi;
+        if (vn) v += sigma * vn[i];
+        out[i] = v;
+    }
+}
+extern "C" int dp_ddpm_step(const float* x, const float* eps, const float* vnoise, float sqrt_a_t, float sqrt_b_t, float c_x0,
+                            float c_xt, float sigma, int clip, float clip_range, float* out, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
+                       sqrt_b_t, c_x0, c_xt, sigma, clip, clip_range, out, n);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dropout, standalone forms (Attention.to_out[1]; mask export for the parity tests).  Philox masks: dp_common.h.
+// ---------------------------------------------------------------------------------------------
+__global__ void dropout_apply_kernel(const float* __restrict__ x, long long xs, float* __restrict__ y, long long ys, int N,
+                                     long long per_img, DpDrop drop) {
+    const long long total = (long long)N * per_img;
+    GS_LOOP(i, total) {
+        const long long n = i / per_img;
+        const long long r = i - n * per_img;
+        y[n * ys + r] = x[n * xs + r] * dp_drop1(drop, (drop.n_off + n) * per_img + r);
+    }
+}
+extern "C" int dp_dropout_apply(const float* x, long long x_img_stride, float* y, long long y_img_stride, int N,
+                                long long per_img, const dp_dropout* drop, void* stream) {
+    if ((long long)N * per_img <= 0) return 0;
+    if (!drop || !drop->thr24) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_img_stride, y, y_img_stride, N, per_img, dp_drop_host(drop));
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ m, long long idx0, long long n, DpDrop drop) {
+    GS_LOOP(i, n) m[i] = dp_drop1(drop, idx0 + i);
+}
+extern "C" int dp_dropout_mask(float* m, long long idx0, long long n, const dp_dropout* drop, void* stream) {
+    if (n <= 0) return 0;
+    if (!drop || !drop->thr24) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, m, idx0, n,
+                       dp_drop_host(drop));
     return DP_LAUNCH_CHECK();
 }
 

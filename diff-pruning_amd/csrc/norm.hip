@@ -20,12 +20,13 @@ __device__ __forceinline__ const float* gn_chan_ptr(const GnSrc& s, int n, int c
 
 __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int C, int HW, int G, float eps, int silu, float* __restrict__ y,
-                                                     long long y_img_stride, float* __restrict__ stats) {
+                                                     long long y_img_stride, float* __restrict__ stats, DpDrop drop) {
     __shared__ float red[4];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
     const int cpg = C / G;
     const int cnt = cpg * HW;
+    const long long didx0 = ((drop.n_off + n) * C + (long long)g * cpg) * HW;      // logical index of the group's first element
     const int tid = threadIdx.x;
     const bool cached = cnt <= 256 * GN_CACHE;
     const int c_base = g * cpg;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __r
                 const int c = c_base + e / HW;
                 float v = (xr[i] - mean) * rstd * gamma[c] + beta[c];
                 if (silu) v = dp_silu(v);
+                if (drop.thr24) v *= dp_drop1(drop, didx0 + e);
                 yb[e] = v;
             }
         }
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __r
             const int c = c_base + cl;
             float v = (gn_chan_ptr(src, n, c, HW)[e - cl * HW] - mean) * rstd * gamma[c] + beta[c];
             if (silu) v = dp_silu(v);
+            if (drop.thr24) v *= dp_drop1(drop, didx0 + e);
             yb[e] = v;
         }
     }
@@ -99,12 +102,13 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __r
 __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C, int HW, int G, float eps,
                                                           int silu, float* __restrict__ y, long long y_img_stride,
-                                                          float* __restrict__ stats) {
+                                                          float* __restrict__ stats, DpDrop drop) {
     __shared__ float red[4];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
     const int cpg = C / G;
     const int cnt4 = cpg * HW / 4;
+    const long long didx0 = ((drop.n_off + n) * C + (long long)g * cpg) * HW;
     const int HW4 = HW / 4;
     const int tid = threadIdx.x;
     const bool cached = cnt4 <= 256 * (GN_CACHE / 4);
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
         stats[(long long)blockIdx.x * 2 + 1] = rstd;
     }
     float4* yb = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c_base * HW);
-    auto apply = [&](float4 v, int c) {
+    auto apply = [&](float4 v, int c, int e4) {
         const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
         float4 o;
         o.x = (v.x - mean) * rstd * gamma[c] + beta[c];
@@ -166,18 +170,19 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
         o.w = (v.w - mean) * rstd * gamma[c] + beta[c];
         (void)ga; (void)be;
         if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * e4); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
         return o;
     };
     if (cached) {
 #pragma unroll
         for (int i = 0; i < GN_CACHE / 4; ++i) {
             const int e = tid + 256 * i;
-            if (e < cnt4) yb[e] = apply(xr[i], c_base + e / HW4);
+            if (e < cnt4) yb[e] = apply(xr[i], c_base + e / HW4, e);
         }
     } else {
         for (int e = tid; e < cnt4; e += 256) {
             const int cl = e / HW4;
-            yb[e] = apply(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4], c_base + cl);
+            yb[e] = apply(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4], c_base + cl, e);
         }
     }
 }
@@ -185,18 +190,19 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
 extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                      long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
                                      int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
-                                     void* stream) {
+                                     const dp_dropout* drop, void* stream) {
     if (N <= 0 || C <= 0) return 0;
     if (C % G) return (int)hipErrorInvalidValue;
+    const DpDrop dd = dp_drop_host(drop);
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
     const bool vec4 = (HW % 4 == 0) && (x1_img_stride % 4 == 0) && (x2_img_stride % 4 == 0) && (y_img_stride % 4 == 0) &&
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0);
     if (vec4)
         hipLaunchKernelGGL(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
-                           silu, y, y_img_stride, stats);
+                           silu, y, y_img_stride, stats, dd);
     else
         hipLaunchKernelGGL(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu,
-                           y, y_img_stride, stats);
+                           y, y_img_stride, stats, dd);
     return DP_LAUNCH_CHECK();
 }
 
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
                                                      float* __restrict__ dx, long long dx_img_stride,
                                                      const float* __restrict__ add1, long long add1_s,
                                                      const float* __restrict__ add2, long long add2_s,
-                                                     float* __restrict__ pws) {
+                                                     float* __restrict__ pws, DpDrop drop) {
     __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
@@ -225,6 +231,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
     const float mean = stats[(long long)blockIdx.x * 2 + 0];
     const float rstd = stats[(long long)blockIdx.x * 2 + 1];
     const float* dzb = dz + (long long)n * dz_img_stride;
+    const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
 
     // pass 1: per-channel sums, one wavefront per channel
     for (int cl = wave; cl < cpg; cl += 4) {
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
         for (int i = lane; i < HW; i += 64) {
             const float xh = (xp[i] - mean) * rstd;
             float d = dp[i];
+            if (drop.thr24) d *= dp_drop1(drop, didx0 + (long long)cl * HW + i);
             if (silu) d *= dp_silu_grad(xh * ga + be);
             a1 += d;
             a2 += d * xh;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
         const float xh = (gn_chan_ptr(src, n, c, HW)[e - cl * HW] - mean) * rstd;
         const float ga = gamma[c];
         float d = dzb[(long long)c_base * HW + e];
+        if (drop.thr24) d *= dp_drop1(drop, didx0 + e);
         if (silu) d *= dp_silu_grad(xh * ga + beta[c]);
         float v = rstd * (ga * d - a - xh * b);
         if (a1b) v += a1b[e];
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
                                                           int HW, int G, int silu, float* __restrict__ dx,
                                                           long long dx_img_stride, const float* __restrict__ add1,
                                                           long long add1_s, const float* __restrict__ add2, long long add2_s,
-                                                          float* __restrict__ pws) {
+                                                          float* __restrict__ pws, DpDrop drop) {
     __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
@@ -298,8 +307,10 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
     const float mean = stats[(long long)blockIdx.x * 2 + 0];
     const float rstd = stats[(long long)blockIdx.x * 2 + 1];
     const float* dzb = dz + (long long)n * dz_img_stride;
-    auto dyv = [&](float4 xv, float4 dv, float ga, float be, float4& xh) {
+    const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
+    auto dyv = [&](float4 xv, float4 dv, float ga, float be, float4& xh, long long e4) {      // e4: float4 index in the group chunk
         xh.x = (xv.x - mean) * rstd; xh.y = (xv.y - mean) * rstd; xh.z = (xv.z - mean) * rstd; xh.w = (xv.w - mean) * rstd;
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4 * e4); dv.x *= m.x; dv.y *= m.y; dv.z *= m.z; dv.w *= m.w; }
         if (silu) {
             dv.x *= dp_silu_grad(xh.x * ga + be); dv.y *= dp_silu_grad(xh.y * ga + be);
             dv.z *= dp_silu_grad(xh.z * ga + be); dv.w *= dp_silu_grad(xh.w * ga + be);
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
         float a1 = 0.f, a2 = 0.f;
         for (int i = lane; i < HW4; i += 64) {
             float4 xh;
-            const float4 d = dyv(xp[i], dp[i], ga, be, xh);
+            const float4 d = dyv(xp[i], dp[i], ga, be, xh, (long long)cl * HW4 + i);
             a1 += (d.x + d.y) + (d.z + d.w);
             a2 += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
         }
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
         const int c = c_base + cl;
         const float ga = gamma[c];
         float4 xh;
-        const float4 d = dyv(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4], dzc[e], ga, beta[c], xh);
+        const float4 d = dyv(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4], dzc[e], ga, beta[c], xh, e);
         float4 v;
         v.x = rstd * (ga * d.x - a - xh.x * b);
         v.y = rstd * (ga * d.y - a - xh.y * b);
@@ -363,9 +374,11 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
                                      long long x2_img_stride, const float* gamma, const float* beta, const float* stats,
                                      const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
                                      float* dx, long long dx_img_stride, const float* add1, long long add1_img_stride,
-                                     const float* add2, long long add2_img_stride, float* pws, void* stream) {
+                                     const float* add2, long long add2_img_stride, float* pws, const dp_dropout* drop,
+                                     void* stream) {
     if (N <= 0 || C <= 0) return 0;
     if (C % G || C / G > GN_MAXCPG) return (int)hipErrorInvalidValue;
+    const DpDrop dd = dp_drop_host(drop);
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
     const bool vec4 = (HW % 4 == 0) && ((x1_img_stride | x2_img_stride | dz_img_stride | dx_img_stride | add1_img_stride |
                                          add2_img_stride) % 4 == 0) &&
@@ -373,11 +386,11 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     if (vec4)
         hipLaunchKernelGGL(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                           pws);
+                           pws, dd);
     else
         hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                           pws);
+                           pws, dd);
     return DP_LAUNCH_CHECK();
 }
 
@@ -433,9 +446,10 @@ __global__ void gn_split_combine_fwd_kernel(const float* __restrict__ part, int 
 __global__ __launch_bounds__(256) void gn_split_apply_fwd_kernel(GnSrc src, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int C, int HW, int G, int S,
                                                                  int silu, const float* __restrict__ stats,
-                                                                 float* __restrict__ y, long long y_img_stride) {
+                                                                 float* __restrict__ y, long long y_img_stride, DpDrop drop) {
     const int nc = blockIdx.x, sl = blockIdx.y;
     const int n = nc / C, c = nc - n * C;
+    const long long didx0 = ((drop.n_off + n) * C + c) * (long long)HW + (long long)sl * (HW / S);
     const int g = c / (C / G);
     const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
     const float ga = gamma[c], be = beta[c];
@@ -448,6 +462,7 @@ __global__ __launch_bounds__(256) void gn_split_apply_fwd_kernel(GnSrc src, cons
         o.x = (v.x - mean) * rstd * ga + be; o.y = (v.y - mean) * rstd * ga + be;
         o.z = (v.z - mean) * rstd * ga + be; o.w = (v.w - mean) * rstd * ga + be;
         if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
         yp[i] = o;
     }
 }
@@ -455,8 +470,9 @@ __global__ __launch_bounds__(256) void gn_split_apply_fwd_kernel(GnSrc src, cons
 extern "C" int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                            long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
                                            int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
-                                           int slices, float* ws, void* stream) {
+                                           int slices, float* ws, const dp_dropout* drop, void* stream) {
     if (N <= 0 || C <= 0) return 0;
+    const DpDrop dd = dp_drop_host(drop);
     if (C % G || slices <= 0 || HW % (4 * slices) || !ws) return (int)hipErrorInvalidValue;
     if (((x1_img_stride | x2_img_stride | y_img_stride) % 4) || (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16))
         return (int)hipErrorInvalidValue;
@@ -466,17 +482,19 @@ extern "C" int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int
     hipLaunchKernelGGL(gn_split_combine_fwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, N * G, C / G, slices, HW, eps,
                        stats);
     hipLaunchKernelGGL(gn_split_apply_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, C, HW, G, slices, silu,
-                       stats, y, y_img_stride);
+                       stats, y, y_img_stride, dd);
     return DP_LAUNCH_CHECK();
 }
 
 __global__ __launch_bounds__(256) void gn_split_part_bwd_kernel(GnSrc src, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ stats,
                                                                 const float* __restrict__ dz, long long dz_img_stride, int C,
-                                                                int HW, int G, int S, int silu, float* __restrict__ part) {
+                                                                int HW, int G, int S, int silu, float* __restrict__ part,
+                                                                DpDrop drop) {
     __shared__ float red[4];
     const int nc = blockIdx.x, sl = blockIdx.y;
     const int n = nc / C, c = nc - n * C;
+    const long long didx0 = ((drop.n_off + n) * C + c) * (long long)HW + (long long)sl * (HW / S);
     const int g = c / (C / G);
     const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
     const float ga = gamma[c], be = beta[c];
@@ -488,6 +506,7 @@ __global__ __launch_bounds__(256) void gn_split_part_bwd_kernel(GnSrc src, const
         const float4 xv = xp[i];
         float4 d = dp[i];
         const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
         if (silu) {
             d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
             d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
@@ -532,9 +551,11 @@ __global__ __launch_bounds__(256) void gn_split_apply_bwd_kernel(GnSrc src, cons
                                                                  long long dz_img_stride, int C, int HW, int G, int S, int silu,
                                                                  float* __restrict__ dx, long long dx_img_stride,
                                                                  const float* __restrict__ add1, long long add1_s,
-                                                                 const float* __restrict__ add2, long long add2_s) {
+                                                                 const float* __restrict__ add2, long long add2_s,
+                                                                 DpDrop drop) {
     const int nc = blockIdx.x, sl = blockIdx.y;
     const int n = nc / C, c = nc - n * C;
+    const long long didx0 = ((drop.n_off + n) * C + c) * (long long)HW + (long long)sl * (HW / S);
     const int g = c / (C / G);
     const float mean = stats[((long long)n * G + g) * 2 + 0], rstd = stats[((long long)n * G + g) * 2 + 1];
     const float a = ab[((long long)n * G + g) * 2 + 0], b = ab[((long long)n * G + g) * 2 + 1];
@@ -550,6 +571,7 @@ __global__ __launch_bounds__(256) void gn_split_apply_bwd_kernel(GnSrc src, cons
         const float4 xv = xp[i];
         float4 d = dp[i];
         const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
         if (silu) {
             d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
             d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
@@ -568,8 +590,9 @@ extern "C" int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int
                                            const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
                                            float* dx, long long dx_img_stride, const float* add1, long long add1_img_stride,
                                            const float* add2, long long add2_img_stride, float* pws, int slices, float* ws,
-                                           void* stream) {
+                                           const dp_dropout* drop, void* stream) {
     if (N <= 0 || C <= 0) return 0;
+    const DpDrop dd = dp_drop_host(drop);
     if (C % G || slices <= 0 || HW % (4 * slices) || !ws) return (int)hipErrorInvalidValue;
     if (((x1_img_stride | x2_img_stride | dz_img_stride | dx_img_stride | add1_img_stride | add2_img_stride) % 4) ||
         (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)add1 | (uintptr_t)add2) % 16))
@@ -578,11 +601,11 @@ extern "C" int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int
     hipStream_t st = (hipStream_t)stream;
     float* ab = ws + (long long)N * C * slices * 2;               // ws: [N*C*slices*2] partials, then [N*G*2] group terms
     hipLaunchKernelGGL(gn_split_part_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, dz, dz_img_stride,
-                       C, HW, G, slices, silu, ws);
+                       C, HW, G, slices, silu, ws, dd);
     hipLaunchKernelGGL(gn_split_combine_bwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, gamma, N * G, G, C, slices, HW,
                        pws, ab);
     hipLaunchKernelGGL(gn_split_apply_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, ab, dz,
-                       dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride);
+                       dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, dd);
     return DP_LAUNCH_CHECK();
 }
 

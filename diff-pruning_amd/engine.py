@@ -23,7 +23,7 @@ _SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
 RES_DIFFUSERS = dict(norm1='.norm1', conv1='.conv1', temb='.time_emb_proj', norm2='.norm2', conv2='.conv2',
-                     shortcut='.conv_shortcut')
+                     shortcut='.conv_shortcut', dropout='.dropout')
 RES_LDM = dict(norm1='.in_layers.0', conv1='.in_layers.2', temb='.emb_layers.1', norm2='.out_layers.0',
                conv2='.out_layers.3', shortcut='.skip_connection')
 
@@ -50,10 +50,16 @@ def _low_priority_stream(device):
 
 
 class _Packs:
-    """Cache of packed (m-contiguous) weight operands, keyed by the identity + version of the source tensor."""
+    """Cache of packed (m-contiguous) weight operands, keyed by the identity + version of the source tensor.
+
+    Neither key detects an in-place write through `.data` (`param.data.copy_()` -- how the vendored EMAModel.copy_to /
+    restore swap weights, training_utils.py:231,286 -- leaves `_version` untouched), so the cache is only trusted while
+    it is *pinned*: `model.engine()` drops it on every re-bind unless a caller that knows the weights are frozen (the
+    sweep, a sampling loop) holds `model.pin_weights()`."""
 
     def __init__(self):
         self._c = {}
+        self.pin_depth = 0
 
     def get(self, name, w, mode):
         key = (name, mode)
@@ -68,6 +74,29 @@ class _Packs:
     def clear(self):
         self._c.clear()
 
+    def rebind(self):
+        """Called by `model.engine()`: weights may have been rewritten in place since the last call."""
+        if self.pin_depth == 0:
+            self._c.clear()
+
+
+class _PinnedWeights:
+    """`with model.pin_weights():` -- the parameters are not written inside the block, packed operands are kept
+    across `model(...)` calls (one pack per layer instead of one per forward)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        eng = self.model.engine()                 # re-bind (and re-pack lazily) once, against the current weights
+        eng.packs.pin_depth += 1
+        self.eng = eng
+        return self.model
+
+    def __exit__(self, *exc):
+        self.eng.packs.pin_depth -= 1
+        return False
+
 
 class UNetEngine:
     def __init__(self, cfg):
@@ -80,12 +109,26 @@ class UNetEngine:
         # fills the CUs while the main stream is in the HBM-bound GroupNorm / reduction kernels and in the launch
         # ramp / tail of its contraction kernels.  Same kernels, same accumulation order -> same bits.
         self.overlap_wgrad = not os.environ.get('DP_NO_OVERLAP')
-        self._side = None
+        self._side, self._side_dev = None, None
+        # Dropout (training mode only; utils.set_dropout, ddpm_train.py:380-382): {module name: p} of the nn.Dropout
+        # holders with p > 0, or None.  Masks are Philox functions of (seed, crc32(module name), step, element index):
+        # the backward regenerates them, nothing is stored (csrc/dp_common.h).
+        self.dropout = None
+        self.drop_seed, self.drop_step, self.drop_n_off = 0, 0, 0
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
         self.P = params
         self.G = grads
+
+    def set_dropout(self, table, seed=0, step=0, n_off=0):
+        self.dropout = table if table else None
+        self.drop_seed, self.drop_step, self.drop_n_off = seed, step, n_off
+
+    def _drop(self, site):
+        if not self.dropout:
+            return None
+        return ops.dropout_desc(self.dropout.get(site, 0.0), self.drop_seed, site, self.drop_step, self.drop_n_off)
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
@@ -123,8 +166,8 @@ class UNetEngine:
         `tensors` are read by the side-stream work: the allocator must not recycle them before that work is done."""
         if not self.overlap_wgrad or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
             return None
-        if self._side is None:
-            self._side = _low_priority_stream(tensors[0].device)
+        if self._side is None or self._side_dev != tensors[0].device:        # the model may have moved to another GPU
+            self._side, self._side_dev = _low_priority_stream(tensors[0].device), tensors[0].device
         self._side.wait_stream(torch.cuda.current_stream())
         for t in tensors:
             if t is not None:
@@ -174,7 +217,10 @@ class UNetEngine:
         n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], G, eps, True)
         tproj = self._linear(pre + nm['temb'], semb)
         h = self._conv(pre + nm['conv1'], n1, None, _SPEC3, tadd=tproj)
-        n2, st2 = ops.groupnorm_fwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], G, eps, True)
+        # resnet.py:622-630: norm2 -> SiLU -> dropout -> conv2; the dropout is fused into the GroupNorm kernel's store
+        drop = self._drop(pre + nm['dropout']) if 'dropout' in nm else None
+        n2, st2 = ops.groupnorm_fwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], G, eps, True,
+                                    drop=drop)
         has_sc = (pre + nm['shortcut'] + '.weight') in P
         if has_sc:
             res = self._conv(pre + nm['shortcut'], xa, xb, _SPEC1)
@@ -185,12 +231,12 @@ class UNetEngine:
                 res = xa
         out = self._conv(pre + nm['conv2'], n2, None, _SPEC3, res=res, post_scale=1.0 / out_scale)
         if save is not None:
-            save[pre] = (xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G)
+            save[pre] = (xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G, drop)
         return out
 
     def resnet_bwd(self, pre, dout, semb, d_semb, extra=None):
         """Returns d(input) over the (virtually concatenated) input channels."""
-        xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G = self.ctx.pop(pre)
+        xa, xb, st1, n1, h, st2, n2, has_sc, out_scale, nm, G, drop = self.ctx.pop(pre)
         P = self.P
         hw = tuple(h.shape[2:])
         d = dout
@@ -198,7 +244,8 @@ class UNetEngine:
             d = ops.axpby(dout.contiguous(), 1.0 / out_scale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
         rows_d = ops.rowsum_nc(d)
         dn2 = self._conv_bwd(pre + nm['conv2'], d, n2, None, _SPEC3, hw, rows=rows_d)
-        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], st2, dn2, G, True)
+        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], st2, dn2, G, True,
+                                     drop=drop)
         self._gn_param_grads(pre + nm['norm2'], pws2)
         del dn2
         # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
@@ -237,13 +284,22 @@ class UNetEngine:
         s = ops.bmm_tn(q.view(Z, d, T), k.view(Z, d, T), alpha=scale)
         p = ops.softmax_fwd(s, out=s)
         o = ops.bmm_nt(v.view(Z, d, T), p)
-        out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
+        drop = self._drop(pre + '.to_out.1')
+        if drop is None:
+            out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
+        else:
+            # attention_processor.py:455-466: to_out[0] -> to_out[1] (dropout) -> + residual -> / rescale_output_factor
+            out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1)
+            ops.dropout_apply(out, drop, out=out)
+            ops.copy_strided(x, out, accumulate=True)
+            if rescale != 1.0:
+                ops.axpby(out, 1.0 / rescale, out, 0.0)
         if save is not None:
-            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads)
+            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads, drop)
         return out
 
     def attn_bwd(self, pre, dout, extra=None):
-        x, st, n, q, k, v, p, o, scale, rescale, heads = self.ctx.pop(pre)
+        x, st, n, q, k, v, p, o, scale, rescale, heads, drop = self.ctx.pop(pre)
         P, cfg = self.P, self.cfg
         G = cfg['norm_num_groups']
         N, C, H, W = x.shape
@@ -253,7 +309,8 @@ class UNetEngine:
         d = dout
         if rescale != 1.0:
             d = ops.axpby(dout.contiguous(), 1.0 / rescale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
-        do = self._conv_bwd(pre + '.to_out.0', d, o.view(N, inner, H, W), None, _SPEC1, hw)
+        dproj = d if drop is None else ops.dropout_apply(d.contiguous(), drop)
+        do = self._conv_bwd(pre + '.to_out.0', dproj, o.view(N, inner, H, W), None, _SPEC1, hw)
         Z, dh = N * heads, inner // heads
         do3 = do.view(Z, dh, T)
         dv = ops.bmm_nn(do3, p)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import UNetEngine, RES_LDM, _SPEC1, _SPEC3, _SPEC_UP
+from .engine import UNetEngine, RES_LDM, _SPEC1, _SPEC3, _SPEC_UP, _PinnedWeights
 
 _SPEC_DOWN = ops.ConvSpec(3, 2, 1, 0)
 
@@ -174,8 +174,13 @@ class UNetModel(nn.Module):
             raise RuntimeError('UNetModel runs on the MI355X HIP kernels only (no CPU / PyTorch fallback)')
         if self._engine is None:
             self._engine = LdmEngine(self.config)
+        self._engine.packs.rebind()           # in-place weight writes are invisible to the pack cache
         self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
         return self._engine
+
+    def pin_weights(self):
+        """Context manager: the weights are frozen inside the block (sampling loop, importance pass)."""
+        return _PinnedWeights(self)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         if y is not None:

@@ -70,11 +70,12 @@ def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0
     x = x_T.contiguous()
     B = x.shape[0]
     ctx2 = torch.cat([uncond, cond]).contiguous()
-    for i in reversed(range(len(steps))):
-        t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
-        e = model(torch.cat([x, x]), t, context=ctx2)
-        e_t = ops.cfg_combine(e[:B], e[B:], scale)
-        x = ops.ddim_step(x, e_t, float(a[i]), float(a_prev[i]), float(sig[i]), None, clip=False)
+    with model.pin_weights():                    # 2 * S forwards over frozen weights: pack the operands once
+        for i in reversed(range(len(steps))):
+            t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
+            e = model(torch.cat([x, x]), t, context=ctx2)
+            e_t = ops.cfg_combine(e[:B], e[B:], scale)
+            x = ops.ddim_step(x, e_t, float(a[i]), float(a_prev[i]), float(sig[i]), None, clip=False)
     return x
 
 
@@ -119,24 +120,25 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
     class_rng = class_rng or random.Random(0)
     uc = embedder(torch.tensor(n_samples * [uncond_class]))
     losses, max_loss, accumulated = [], -1.0, 0
-    for t in range(num_steps):
-        if draws is not None:
-            xc, x_T, noise = draws(t)
-        else:
-            xc = torch.tensor(class_rng.sample(range(1000), n_samples))
-            x_T = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
-            noise = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
-        c = embedder(xc)
-        samples = ddim_sample_cfg(model, schedule, x_T.to(dev), c, uc, S=ddim_steps, scale=scale)
-        tt = torch.full((n_samples,), t, dtype=torch.long, device=dev)
-        loss = step.loss(samples, tt, c, noise.to(dev))
-        lv = float(loss)                         # host sync, as `if loss > max_loss` in the reference
-        losses.append(lv)
-        if lv > max_loss:
-            max_loss = lv
-        if thr is not None and lv / max_loss < thr:
-            step.discard()
-            break
-        step.backward()
-        accumulated += 1
+    with model.pin_weights():                    # the importance pass never writes weights: pack the operands once
+        for t in range(num_steps):
+            if draws is not None:
+                xc, x_T, noise = draws(t)
+            else:
+                xc = torch.tensor(class_rng.sample(range(1000), n_samples))
+                x_T = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
+                noise = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
+            c = embedder(xc)
+            samples = ddim_sample_cfg(model, schedule, x_T.to(dev), c, uc, S=ddim_steps, scale=scale)
+            tt = torch.full((n_samples,), t, dtype=torch.long, device=dev)
+            loss = step.loss(samples, tt, c, noise.to(dev))
+            lv = float(loss)                         # host sync, as `if loss > max_loss` in the reference
+            losses.append(lv)
+            if lv > max_loss:
+                max_loss = lv
+            if thr is not None and lv / max_loss < thr:
+                step.discard()
+                break
+            step.backward()
+            accumulated += 1
     return dict(losses=losses, steps=len(losses), accumulated=accumulated, flat_grads=flat)

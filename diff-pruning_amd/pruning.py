@@ -232,12 +232,18 @@ class TaylorImportance(Importance):
                            contribute sum((w*g)^2) over the other dims, GroupNorm members |w*g|, members whose length
                            differs from the root's are dropped, plain sum over members, no normalisation ('sum_sq').
     multivariable=True / False -> the pip torch_pruning criterion named by ddpm_prune.py:60,66: |sum w*g| / sum |w*g|
-                           per member, mean over members, mean-normalised (positive rescalings of the plain sum;
-                           that package is absent from the reference tree: PARITY UNPINNED for these two modes)."""
+                           per member, mean over members, mean-normalised (that package is absent from the reference
+                           tree and unpinned in requirements.txt:7: PARITY UNPINNED for these two modes).
+    groupnorm_term      -> whether GroupNorm members add |w*g|.  The vendored criterion has that branch
+                           (importance.py:412-418) -> default True for multivariable=None.  The pip criterion of that
+                           era only had a BatchNorm branch (prune_batchnorm_out_channels), GroupNorm members matched no
+                           branch and added nothing -> default False for the multivariable modes (recalled, unpinned).
+    `sweep.prune_model` defaults to the vendored ('sum_sq') criterion: the only one pinned by reference outputs."""
 
-    def __init__(self, group_reduction='mean', normalizer='mean', multivariable=None):
+    def __init__(self, group_reduction='mean', normalizer='mean', multivariable=None, groupnorm_term=None):
         self.group_reduction, self.normalizer, self.multivariable = group_reduction, normalizer, multivariable
         self.mode = 'sum_sq' if multivariable is None else ('abs_sum' if multivariable else 'sum_abs')
+        self.groupnorm_term = (multivariable is None) if groupnorm_term is None else bool(groupnorm_term)
         self._scratch = None
 
     def _member_score(self, layer, kind, idxs, out_len):
@@ -271,7 +277,7 @@ class TaylorImportance(Importance):
             if kind is None or kind == 'ln':          # LayerNorm members carry no term (importance.py:383-418)
                 continue
             layer = dep.target.module
-            if kind == 'gn' and not layer.affine:
+            if kind == 'gn' and (not layer.affine or not self.groupnorm_term):
                 continue
             terms.append((layer, kind, idxs))
         if not terms:

@@ -49,7 +49,9 @@ class HipSweepStep:
             gb = global_batch if global_batch is not None else self.B
             self.gscale, self.lscale = 2.0 / gb, 1.0 / gb
         self.eng = model.engine()
-        self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+        self._P = {n: p.detach() for n, p in model.named_parameters()}
+        self._G = {n: p.grad for n, p in model.named_parameters()}
+        self.eng.bind(self._P, self._G)
         self.acp = scheduler._acp_on(clean.device)
 
     def _step(self, t):
@@ -63,6 +65,9 @@ class HipSweepStep:
         return total
 
     def _micro_step(self, clean, noise, t):
+        # any model(...) / model.engine() call between two sweep steps (a no-grad evaluation, the autograd bridge) re-binds
+        # the engine without -- or with temporary -- gradient buffers: bind ours again
+        self.eng.bind(self._P, self._G)
         noisy = ops.add_noise(clean, noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
         loss, dout = ops.mse_fwd_bwd(out, noise, self.gscale, self.lscale)
@@ -75,6 +80,7 @@ class HipSweepStep:
         if self.micro is not None and self.B > self.micro:
             raise NotImplementedError('break-before-backward keeps one forward context: not combined with micro-batches')
         t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+        self.eng.bind(self._P, self._G)
         noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
         loss, self._dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)

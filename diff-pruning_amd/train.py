@@ -4,9 +4,15 @@ One step = add_noise -> UNet forward -> eps-loss (sum over C,H,W, mean over the 
 -> gradient all-reduce (one flat buffer; RCCL over xGMI) -> global-norm clip (1.0) -> Adam -> EMA (constant decay).
 Parameters, gradients, Adam moments and the EMA copy live in flat fp32 buffers so that the optimizer is ONE
 HBM-bound kernel launch (csrc/optim.hip) and the all-reduce is ONE collective.
-Dropout: the reference finetunes with dropout 0.1 (scripts/finetune_ddpm_cifar10.sh); this engine implements
-p = 0 only and raises otherwise (RNG-stream parity of dropout masks is not reproducible across backends anyway).
+Dropout: the reference finetunes with dropout 0.1 (scripts/finetune_ddpm_cifar10.sh:16 -> utils.set_dropout, utils.py:26-29,
+ddpm_train.py:380-382: EVERY nn.Dropout of the model, i.e. ResnetBlock2D.dropout and Attention.to_out[1]).  The masks are
+Philox functions of (seed, layer, optimizer step, global element index): fused into the GroupNorm+SiLU kernels, regenerated
+in the backward pass, independent of how the batch is sharded over ranks (csrc/dp_common.h).
+LR schedule: diffusers/optimization.py:282 `get_scheduler` (LambdaLR multipliers), stepped once per optimizer step
+(ddpm_train.py:340-346,464).
 """
+import math
+
 import torch
 
 from . import ops
@@ -18,6 +24,103 @@ def antithetic_timesteps(bsz, num_train_timesteps, generator=None):
     return torch.cat([t, num_train_timesteps - t - 1], dim=0)[:bsz]
 
 
+class LambdaLR:
+    """torch.optim.lr_scheduler.LambdaLR semantics for ONE parameter group (host scalar arithmetic): the lr in force is
+    base_lr * f(last_epoch); construction evaluates f(0), every step() advances last_epoch by one."""
+
+    def __init__(self, base_lr, lr_lambda, last_epoch=-1):
+        self.base_lr, self.lr_lambda = float(base_lr), lr_lambda
+        self.last_epoch = last_epoch
+        self.step()
+
+    def step(self):
+        self.last_epoch += 1
+        self._last_lr = [self.base_lr * self.lr_lambda(self.last_epoch)]
+
+    def get_last_lr(self):
+        return self._last_lr
+
+    def state_dict(self):
+        return dict(base_lr=self.base_lr, last_epoch=self.last_epoch)
+
+    def load_state_dict(self, sd):
+        self.base_lr, self.last_epoch = sd['base_lr'], sd['last_epoch'] - 1
+        self.step()
+
+
+SCHEDULER_TYPES = ('linear', 'cosine', 'cosine_with_restarts', 'polynomial', 'constant', 'constant_with_warmup',
+                   'piecewise_constant')
+
+
+def get_scheduler(name, base_lr, step_rules=None, num_warmup_steps=None, num_training_steps=None, num_cycles=1, power=1.0,
+                  last_epoch=-1, lr_end=1e-7):
+    """diffusers/optimization.py:282-354 with the optimizer replaced by its learning rate (one parameter group)."""
+    if name not in SCHEDULER_TYPES:
+        raise ValueError('%r is not a valid SchedulerType' % (name,))
+    if name == 'constant':                                        # optimization.py:40-53
+        return LambdaLR(base_lr, lambda _: 1, last_epoch)
+    if name == 'piecewise_constant':                              # optimization.py:81-120
+        rules, rule_list = {}, step_rules.split(',')
+        for rule in rule_list[:-1]:
+            value, steps = rule.split(':')
+            rules[int(steps)] = float(value)
+        last = float(rule_list[-1])
+
+        def piecewise(step):
+            for s in sorted(rules):
+                if step < s:
+                    return rules[s]
+            return last
+        return LambdaLR(base_lr, piecewise, last_epoch)
+    if num_warmup_steps is None:
+        raise ValueError('%s requires `num_warmup_steps`, please provide that argument.' % name)
+    W = num_warmup_steps
+    if name == 'constant_with_warmup':                            # optimization.py:56-78
+        return LambdaLR(base_lr, lambda k: float(k) / float(max(1.0, W)) if k < W else 1.0, last_epoch)
+    if num_training_steps is None:
+        raise ValueError('%s requires `num_training_steps`, please provide that argument.' % name)
+    T = num_training_steps
+    if name == 'linear':                                          # optimization.py:123-149
+        def f(k):
+            if k < W:
+                return float(k) / float(max(1, W))
+            return max(0.0, float(T - k) / float(max(1, T - W)))
+    elif name == 'cosine':                                        # optimization.py:152-183 (num_cycles = 0.5)
+        def f(k):
+            if k < W:
+                return float(k) / float(max(1, W))
+            progress = float(k - W) / float(max(1, T - W))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(0.5) * 2.0 * progress)))
+    elif name == 'cosine_with_restarts':                          # optimization.py:186-218
+        def f(k):
+            if k < W:
+                return float(k) / float(max(1, W))
+            progress = float(k - W) / float(max(1, T - W))
+            if progress >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(num_cycles) * progress) % 1.0))))
+    else:                                                         # polynomial, optimization.py:221-268
+        lr_init = base_lr
+        if not (lr_init > lr_end):
+            raise ValueError('lr_end (%s) must be be smaller than initial lr (%s)' % (lr_end, lr_init))
+
+        def f(k):
+            if k < W:
+                return float(k) / float(max(1, W))
+            if k > T:
+                return lr_end / lr_init
+            pct_remaining = 1 - (k - W) / (T - W)
+            return ((lr_init - lr_end) * pct_remaining ** power + lr_end) / lr_init
+    return LambdaLR(base_lr, f, last_epoch)
+
+
+def set_dropout(model, p):
+    """utils.py:26-29."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = p
+
+
 def _require_hip_device(dev):
     if dev.type != 'cuda':
         raise RuntimeError('finetune runs on the MI355X HIP kernels only')
@@ -25,10 +128,14 @@ def _require_hip_device(dev):
 
 class FinetuneEngine:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, ema_decay=0.9999, max_grad_norm=1.0,
-                 use_ema=True, group=None, dropout=0.0):
-        if dropout != 0.0:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP engine')
+                 use_ema=True, group=None, dropout=None, lr_scheduler=None, dropout_seed=0):
+        """dropout: None keeps whatever `set_dropout(model, p)` has set on the nn.Dropout holders; a float sets it.
+        lr_scheduler: a `LambdaLR` from `get_scheduler` (its base_lr is the learning rate) or None (constant `lr`)."""
+        if dropout is not None:
+            set_dropout(model, float(dropout))
         self.model, self.scheduler = model, scheduler
+        self.lr_scheduler = lr_scheduler
+        self.dropout_seed = dropout_seed
         self.lr, self.betas, self.eps = lr, betas, eps
         self.ema_decay, self.max_grad_norm, self.group = ema_decay, max_grad_norm, group
         params = list(model.parameters())
@@ -82,20 +189,29 @@ class FinetuneEngine:
         self._stash = None
         self._weights_changed()
 
-    def step(self, clean, noise, timesteps, global_batch=None):
-        """Returns the (local share of the) loss as a [1] device tensor; no host synchronisation."""
+    def step(self, clean, noise, timesteps, global_batch=None, image_offset=None):
+        """Returns the (local share of the) loss as a [1] device tensor; no host synchronisation.
+        image_offset: global index of this rank's first image (default rank * B): the dropout masks are functions of the
+        GLOBAL element index, so a sharded step draws the masks of the un-sharded one."""
         import torch.distributed as dist
         use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         B = clean.shape[0]
         gb = global_batch if global_batch is not None else (B * dist.get_world_size(self.group) if use_dist else B)
+        if image_offset is None:
+            image_offset = dist.get_rank(self.group) * B if use_dist else 0
         model = self.model
+        model.train()                                     # ddpm_train.py:430
+        dev = self.flat_p.device
+        clean = clean.to(dev, torch.float32).contiguous()
+        noise = noise.to(dev, torch.float32).contiguous()
         eng = model.engine()
         eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
-        t = timesteps.to(device=clean.device, dtype=torch.long)
-        noisy = ops.add_noise(clean.contiguous(), noise.contiguous(), self.acp, t)
+        eng.set_dropout(getattr(model, 'dropout_table', dict)(), self.dropout_seed, self.step_count + 1, image_offset)
+        t = timesteps.to(device=dev, dtype=torch.long).contiguous()
+        noisy = ops.add_noise(clean, noise, self.acp, t)
         self.flat_g.zero_()                               # optimizer.zero_grad()
         out = eng.forward(noisy, t, save=True)
-        loss, dout = ops.mse_fwd_bwd(out, noise.contiguous(), 2.0 / gb, 1.0 / gb)
+        loss, dout = ops.mse_fwd_bwd(out, noise, 2.0 / gb, 1.0 / gb)
         eng.backward(dout)
         if use_dist:
             dist.all_reduce(self.flat_g, group=self.group)      # sum of per-shard gradients of the global-mean loss
@@ -103,7 +219,11 @@ class FinetuneEngine:
         nc = ops.clip_coef(partial, self.max_grad_norm)
         self.last_grad_norm = nc[0:1]
         self.step_count += 1
-        ops.adam_ema(self.flat_p, self.flat_g, self.m, self.v, self.ema, nc[1:2], self.lr, self.betas[0], self.betas[1],
+        lr = self.lr_scheduler.get_last_lr()[0] if self.lr_scheduler is not None else self.lr
+        self.last_lr = lr
+        ops.adam_ema(self.flat_p, self.flat_g, self.m, self.v, self.ema, nc[1:2], lr, self.betas[0], self.betas[1],
                      self.eps, self.step_count, self.ema_decay)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()                       # ddpm_train.py:464
         eng.packs.clear()                                  # weights changed: packed operands are stale
         return loss

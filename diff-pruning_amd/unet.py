@@ -14,7 +14,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from .engine import UNetEngine
+from .engine import UNetEngine, _PinnedWeights
 
 
 @dataclass
@@ -97,8 +97,9 @@ def _attn(cfg, channels, rescale=1.0):
     hd = cfg['attention_head_dim']
     heads = channels // hd if hd is not None else 1
     dim_head = hd if hd is not None else channels
-    # heads > 1 (e.g. CompVis/ldm-celebahq-256, attention_head_dim 32): the module can be built, loaded, pruned (head-grouped
-    # channel selection, ldm_prune.py:73-79) and saved; running it raises in engine() -- the HIP attention path is single-head
+    # heads > 1 (e.g. CompVis/ldm-celebahq-256, attention_head_dim 32): head h owns the contiguous channel rows
+    # [h*d, (h+1)*d) of every image, so head_to_batch_dim (attention_processor.py:283-305) is a view of the channel-major
+    # tokens and the batched products run with batch index n*heads + h; pruning selects head-grouped channels (ldm_prune.py:73-79)
     return Attention(channels, heads, dim_head, cfg['norm_num_groups'], cfg['norm_eps'], rescale)
 
 
@@ -200,6 +201,9 @@ class UNet2DModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], cfg['out_channels'], 3, padding=1)
         self._engine = None
         self._multi_head = any(getattr(m, 'heads', 1) != 1 for m in self.modules())
+        # dropout masks are Philox functions of (dropout_seed, layer, step, element): see engine.UNetEngine.set_dropout
+        self.dropout_seed = 0
+        self._dropout_step = 0
 
     def __getstate__(self):
         """Whole-module pickles (`torch.save(model, 'unet_pruned.pth')`, ddpm_prune.py:135) carry parameters and shapes
@@ -233,17 +237,25 @@ class UNet2DModel(nn.Module):
 
     def engine(self):
         """The HIP execution engine bound to the *current* parameter tensors (re-bound after pruning)."""
-        if getattr(self, '_multi_head', False):
-            raise NotImplementedError('multi-head attention (attention_head_dim=%r) is not implemented in the HIP engine'
-                                      % self.config['attention_head_dim'])
         if self.conv_in.weight.device.type != 'cuda':
             raise RuntimeError('UNet2DModel runs on the MI355X HIP kernels only: move the model to a cuda device '
                                '(there is no CPU / PyTorch fallback)')
         if self._engine is None:
             self._engine = UNetEngine(self.config)
         params = {n: p.detach() for n, p in self.named_parameters()}
+        self._engine.packs.rebind()           # in-place weight writes (EMAModel.copy_to / restore) are invisible to the cache
         self._engine.bind(params, None)
+        self._engine.set_dropout(self.dropout_table() if self.training else None, getattr(self, 'dropout_seed', 0),
+                                 getattr(self, '_dropout_step', 0))
         return self._engine
+
+    def dropout_table(self):
+        """{module name: p} of the nn.Dropout holders with p > 0 (what utils.set_dropout, utils.py:26-29, has set)."""
+        return {n: float(m.p) for n, m in self.named_modules() if isinstance(m, nn.Dropout) and m.p > 0}
+
+    def pin_weights(self):
+        """Context manager: the weights are frozen inside the block (sweep, sampling loop) -> keep the packed operands."""
+        return _PinnedWeights(self)
 
     def _timesteps(self, sample, timestep):
         t = timestep
@@ -258,6 +270,8 @@ class UNet2DModel(nn.Module):
         if class_labels is not None:
             raise ValueError('class conditioning is not part of this model')
         t = self._timesteps(sample, timestep)
+        if self.training:
+            self._dropout_step = getattr(self, '_dropout_step', 0) + 1       # a fresh mask per training-mode forward
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
             names = [n for n, _ in self.named_parameters()]

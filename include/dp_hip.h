@@ -90,15 +90,33 @@ int dp_splitk_reduce_taps(const float* ws, long long stride, int splits, float* 
  * dst must hold taps*K*ld floats; padding columns are written as zeros. */
 int dp_pack_weight(const float* W, int Co, int Ci, int taps, int mode, float* dst, int ld, void* stream);
 
-/* GroupNorm (+ optional SiLU) forward over a (virtually concatenated) NCHW tensor.
+/* Dropout of the finetune step (nn.Dropout in ResnetBlock2D, resnet.py:628, and Attention.to_out[1],
+ * attention_processor.py:457; probability set by utils.set_dropout, utils.py:26-29, ddpm_train.py:380-382).
+ * The mask is a pure function of (seed, site, step, logical element index) through Philox4x32-10 -- see csrc/dp_common.h --
+ * so the backward kernels regenerate it instead of reading a stored mask.  thr24 = ceil(p * 2^24) (0 disables),
+ * scale = 1/(1-p), site = a stable id of the layer, step = optimizer step, n_off = global index of the shard's first
+ * image (masks do not depend on how the batch is sharded over ranks). */
+typedef struct dp_dropout {
+    unsigned thr24; float scale; unsigned long long seed; unsigned site; unsigned step; long long n_off;
+} dp_dropout;
+
+/* Standalone forms: y[i] = x[i] * m(i) (in place allowed; forward and backward are the same map), and the bare mask
+ * multipliers m(i) in {0, scale} for logical elements [idx0, idx0 + n) (parity tests export masks through it).
+ * x is [N][per_img] with image stride x_img_stride (logical index = (n_off + n) * per_img + r). */
+int dp_dropout_apply(const float* x, long long x_img_stride, float* y, long long y_img_stride, int N, long long per_img,
+                     const dp_dropout* drop, void* stream);
+int dp_dropout_mask(float* m, long long idx0, long long n, const dp_dropout* drop, void* stream);
+
+/* GroupNorm (+ optional SiLU) (+ optional dropout of the result, drop may be NULL) forward over a (virtually
+ * concatenated) NCHW tensor.
  * Replaces F.group_norm + F.silu: resnet.py:596-598,622-628, unet_2d.py:302-303, attention_processor.py:433.
  * Channel c < c_split is read from x1 (image stride x1_img_stride), else from x2.  y is contiguous
  * [N][C][HW] with image stride y_img_stride.  stats[(n*G+g)*2 + {0,1}] = {mean, rstd}. */
 int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
                           const float* gamma, const float* beta, int N, int C, int HW, int G, float eps, int silu,
-                          float* y, long long y_img_stride, float* stats, void* stream);
+                          float* y, long long y_img_stride, float* stats, const dp_dropout* drop, void* stream);
 
-/* Backward of the above.  dz = gradient w.r.t. the (SiLU'd) output, image stride dz_img_stride.
+/* Backward of the above (drop: the same descriptor as in the forward; dz is masked on the fly).  dz = gradient w.r.t. the (SiLU'd) output, image stride dz_img_stride.
  * dx (image stride dx_img_stride) = gn_backward(dz) (+ add1) (+ add2); add tensors carry their own image
  * strides.  pws[(n*C + c)*2 + {0,1}] = per-image sums {sum dy, sum dy*xhat} (reduce over n with
  * dp_colsum_accum to obtain dbeta / dgamma).  Replaces NativeGroupNormBackward + SiluBackward. */
@@ -107,7 +125,7 @@ int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long lo
                           int N, int C, int HW, int G, int silu,
                           float* dx, long long dx_img_stride,
                           const float* add1, long long add1_img_stride, const float* add2, long long add2_img_stride,
-                          float* pws, void* stream);
+                          float* pws, const dp_dropout* drop, void* stream);
 
 /* The same two operations for FEW, LARGE groups (e.g. 256x256 images at batch 4: N*G = 128 groups of 1 MB): the work unit
  * is one of `slices` equal slices of one channel plane, partial statistics go through ws and are combined in a fixed
@@ -115,12 +133,14 @@ int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long lo
  * ws: forward >= N*C*slices*2 floats, backward >= N*C*slices*2 + N*G*2 floats. */
 int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
                                 const float* gamma, const float* beta, int N, int C, int HW, int G, float eps, int silu,
-                                float* y, long long y_img_stride, float* stats, int slices, float* ws, void* stream);
+                                float* y, long long y_img_stride, float* stats, int slices, float* ws,
+                                const dp_dropout* drop, void* stream);
 int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int c_split, long long x1_img_stride, long long x2_img_stride,
                                 const float* gamma, const float* beta, const float* stats, const float* dz,
                                 long long dz_img_stride, int N, int C, int HW, int G, int silu, float* dx,
                                 long long dx_img_stride, const float* add1, long long add1_img_stride, const float* add2,
-                                long long add2_img_stride, float* pws, int slices, float* ws, void* stream);
+                                long long add2_img_stride, float* pws, int slices, float* ws, const dp_dropout* drop,
+                                void* stream);
 
 /* out[c*ostride] (+)= sum_n ws[(n*C + c)*wstride + woff]   (deterministic, n ascending) */
 int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate, void* stream);
@@ -179,9 +199,15 @@ int dp_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long l
                 float lr, float b1, float b2, float eps, float bc1, float bc2, float ema_decay, void* stream);
 
 /* DDIM update (scheduling_ddim.py:324-370, eta = 0 or with supplied noise):
- *   x0 = clamp((x - sqrt(1-a_t) eps)/sqrt(a_t));  prev = sqrt(a_prev) x0 + sqrt(1-a_prev-std^2) eps (+ std*noise) */
+ *   x0 = clamp((x - sqrt(1-a_t) eps)/sqrt(a_t), +-clip_range);  prev = sqrt(a_prev) x0 + sqrt(1-a_prev-std^2) eps (+ std*noise) */
 int dp_ddim_step(const float* x, const float* eps, const float* vnoise, float a_t, float a_prev, float std, int clip,
-                 float* out, long long n, void* stream);
+                 float clip_range, float* out, long long n, void* stream);
+
+/* DDPM ancestral update (scheduling_ddpm.py:312-406, epsilon prediction):
+ *   x0 = clamp((x - sqrt_b_t eps)/sqrt_a_t, +-clip_range);  prev = c_x0 * x0 + c_xt * x (+ sigma * noise)
+ * The 0-d coefficient arithmetic stays on the host in the reference's own fp32 operation order. */
+int dp_ddpm_step(const float* x, const float* eps, const float* vnoise, float sqrt_a_t, float sqrt_b_t, float c_x0,
+                 float c_xt, float sigma, int clip, float clip_range, float* out, long long n, void* stream);
 
 /* ---- LDM (CompVis) transformer-block glue on channel-major tokens x[n][c][t]  (ldm_exp/ldm/modules/attention.py) ---- */
 /* LayerNorm over the C channels of every token (attention.py:200-212 norm1/2/3); stats[(n*T+t)*2+{0,1}] = {mean, rstd}. */

@@ -67,6 +67,41 @@ def ddim_step(acp, model_output, t, sample, num_inference_steps, num_train_times
     return prev
 
 
+def ddpm_timesteps(num_inference_steps, num_train_timesteps=1000):
+    """scheduling_ddpm.py:231-236 (equal spacing, integer step ratio)."""
+    ratio = num_train_timesteps // num_inference_steps
+    return torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+
+def ddpm_step(acp, model_output, t, sample, num_inference_steps=None, num_train_timesteps=1000, variance_noise=None,
+              clip_sample=True, clip_sample_range=1.0, variance_type='fixed_small'):
+    """scheduling_ddpm.py:312-406 (epsilon prediction; variance types fixed_small / fixed_large, _get_variance :238-280)."""
+    t = int(t)
+    n_inf = num_inference_steps if num_inference_steps else num_train_timesteps
+    prev_t = t - num_train_timesteps // n_inf
+    one = torch.tensor(1.0)
+    a_t = acp[t]
+    a_prev = acp[prev_t] if prev_t >= 0 else one
+    b_t = 1 - a_t
+    b_prev = 1 - a_prev
+    cur_a = a_t / a_prev
+    cur_b = 1 - cur_a
+    x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+    if clip_sample:
+        x0 = x0.clamp(-clip_sample_range, clip_sample_range)
+    c_x0 = (a_prev ** 0.5 * cur_b) / b_t
+    c_xt = cur_a ** 0.5 * b_prev / b_t
+    prev = c_x0 * x0 + c_xt * sample
+    if t > 0:
+        var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_b, min=1e-20)
+        if variance_type == 'fixed_large':
+            var = cur_b
+        elif variance_type != 'fixed_small':
+            raise NotImplementedError(variance_type)
+        prev = prev + (var ** 0.5) * variance_noise
+    return prev
+
+
 @torch.no_grad()
 def ddim_sample(P, cfg, x_T, num_inference_steps, skip_type='uniform', eta=0.0, first_n=None):
     acp = alphas_cumprod()
@@ -130,10 +165,10 @@ def taylor_sweep(P, cfg, clean, noise, steps, thr=None, loss_kind='mse', on_step
     return losses
 
 
-def finetune_loss(P, cfg, clean, noise, t):
-    """ddpm_train.py:453-459."""
+def finetune_loss(P, cfg, clean, noise, t, drop=None):
+    """ddpm_train.py:453-459.  drop: philox_ref.DropSpec when the model trains with dropout (ddpm_train.py:380-382)."""
     acp = alphas_cumprod()
-    out = unet_forward(P, cfg, add_noise(acp, clean, noise, t), t)
+    out = unet_forward(P, cfg, add_noise(acp, clean, noise, t), t, drop)
     return (noise - out).square().sum(dim=(1, 2, 3)).mean(dim=0)
 
 

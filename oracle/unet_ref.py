@@ -49,20 +49,23 @@ def _lin(P, pre, x):
     return F.linear(x, P[pre + '.weight'], P.get(pre + '.bias'))
 
 
-def resnet_block(P, pre, x, temb, groups, eps, out_scale):
-    """resnet.py:589-639 with time_embedding_norm == 'default', no up/down, dropout in eval mode."""
+def resnet_block(P, pre, x, temb, groups, eps, out_scale, drop=None):
+    """resnet.py:589-639 with time_embedding_norm == 'default', no up/down.  drop: philox_ref.DropSpec (training mode with
+    nn.Dropout p > 0, resnet.py:628) or None (eval mode / p = 0)."""
     h = F.silu(_gn(P, pre + '.norm1', x, groups, eps))
     h = _conv(P, pre + '.conv1', h)
     t = _lin(P, pre + '.time_emb_proj', F.silu(temb))[:, :, None, None]
     h = h + t
     h = F.silu(_gn(P, pre + '.norm2', h, groups, eps))
+    if drop is not None:
+        h = drop.apply(pre + '.dropout', h)
     h = _conv(P, pre + '.conv2', h)
     if (pre + '.conv_shortcut.weight') in P:
         x = _conv(P, pre + '.conv_shortcut', x, padding=0)
     return (x + h) / out_scale
 
 
-def attention_block(P, pre, x, groups, eps, scale, rescale, heads=1):
+def attention_block(P, pre, x, groups, eps, scale, rescale, heads=1, drop=None):
     """attention_processor.py:415-470 (AttnProcessor; head_to_batch_dim / batch_to_head_dim :283-305), residual_connection=True.
 
     `scale` and `heads` are module attributes fixed at construction (dim_head ** -0.5 with dim_head = attention_head_dim
@@ -90,6 +93,8 @@ def attention_block(P, pre, x, groups, eps, scale, rescale, heads=1):
         h = h.reshape(B, heads, T, h.shape[-1]).permute(0, 2, 1, 3).reshape(B, T, heads * h.shape[-1])
     h = _lin(P, pre + '.to_out.0', h)
     h = h.transpose(-1, -2).reshape(B, C, H, W)
+    if drop is not None:          # to_out[1] (attention_processor.py:457); elementwise, so it commutes with the reshape
+        h = drop.apply(pre + '.to_out.1', h)
     return (h + res) / rescale
 
 
@@ -117,8 +122,8 @@ def attn_heads_for(cfg, channels):
     return channels // hd if hd is not None else 1
 
 
-def unet_forward(P, cfg, sample, timesteps):
-    """unet_2d.py:219-316.  P: flat parameter dict, cfg: Diffusers UNet2DModel config dict."""
+def unet_forward(P, cfg, sample, timesteps, drop=None):
+    """unet_2d.py:219-316.  P: flat parameter dict, cfg: Diffusers UNet2DModel config dict.  drop: see resnet_block."""
     boc = list(cfg['block_out_channels'])
     groups, eps = cfg['norm_num_groups'], cfg['norm_eps']
     L = cfg['layers_per_block']
@@ -138,31 +143,31 @@ def unet_forward(P, cfg, sample, timesteps):
     for i, bt in enumerate(cfg['down_block_types']):
         pre = 'down_blocks.%d' % i
         for j in range(L):
-            x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0)
+            x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0, drop)
             if bt == 'AttnDownBlock2D':
                 x = attention_block(P, '%s.attentions.%d' % (pre, j), x, groups, eps,
-                                    attn_scale_for(cfg, boc[i]), 1.0, attn_heads_for(cfg, boc[i]))
+                                    attn_scale_for(cfg, boc[i]), 1.0, attn_heads_for(cfg, boc[i]), drop)
             skips.append(x)
         if i != nb - 1:
             x = downsample(P, pre + '.downsamplers.0', x, cfg['downsample_padding'])
             skips.append(x)
 
     msf = float(cfg.get('mid_block_scale_factor', 1))
-    x = resnet_block(P, 'mid_block.resnets.0', x, emb, groups, eps, msf)
+    x = resnet_block(P, 'mid_block.resnets.0', x, emb, groups, eps, msf, drop)
     if cfg.get('add_attention', True):
         x = attention_block(P, 'mid_block.attentions.0', x, groups, eps, attn_scale_for(cfg, boc[-1]), msf,
-                            attn_heads_for(cfg, boc[-1]))
-    x = resnet_block(P, 'mid_block.resnets.1', x, emb, groups, eps, msf)
+                            attn_heads_for(cfg, boc[-1]), drop)
+    x = resnet_block(P, 'mid_block.resnets.1', x, emb, groups, eps, msf, drop)
 
     rev = list(reversed(boc))
     for i, bt in enumerate(cfg['up_block_types']):
         pre = 'up_blocks.%d' % i
         for j in range(L + 1):
             x = torch.cat([x, skips.pop()], dim=1)
-            x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0)
+            x = resnet_block(P, '%s.resnets.%d' % (pre, j), x, emb, groups, eps, 1.0, drop)
             if bt == 'AttnUpBlock2D':
                 x = attention_block(P, '%s.attentions.%d' % (pre, j), x, groups, eps,
-                                    attn_scale_for(cfg, rev[i]), 1.0, attn_heads_for(cfg, rev[i]))
+                                    attn_scale_for(cfg, rev[i]), 1.0, attn_heads_for(cfg, rev[i]), drop)
         if i != nb - 1:
             x = upsample(P, pre + '.upsamplers.0', x)
 

@@ -28,7 +28,10 @@ def patch():
     def cpu_engine(self):
         if self._engine is None:
             self._engine = engine.UNetEngine(self.config)
+        self._engine.packs.rebind()
         self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        self._engine.set_dropout(self.dropout_table() if self.training else None, getattr(self, 'dropout_seed', 0),
+                                 getattr(self, '_dropout_step', 0))
         return self._engine
     unet.UNet2DModel.engine = cpu_engine
 
@@ -37,7 +40,9 @@ def patch():
         self.clean, self.noise, self.B = clean.contiguous().float(), noise.contiguous().float(), clean.shape[0]
         self.gscale, self.lscale = 2.0 / global_numel, 1.0 / global_numel
         self.eng = model.engine()
-        self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+        self._P = {n: p.detach() for n, p in model.named_parameters()}
+        self._G = {n: p.grad for n, p in model.named_parameters()}
+        self.eng.bind(self._P, self._G)
         self.acp = scheduler.alphas_cumprod
     sweep.HipSweepStep.__init__ = step_init
     train._require_hip_device = lambda dev: None
@@ -65,10 +70,14 @@ def main():
     grads = {n: p.grad.clone() for n, p in model.named_parameters()}
     pr = pkg('sweep').prune_model(model, 0.3)
     masks = [r[3] for r in pr.records]
-    # finetune (config C4): two optimizer steps on the pruned model, gradient all-reduce over the ranks every step
+    # finetune (config C4): two optimizer steps on the pruned model with dropout 0.1 (scripts/finetune_ddpm_cifar10.sh:16)
+    # and a warm-up LR schedule, gradient all-reduce over the ranks every step.  The dropout masks are functions of the
+    # GLOBAL element index, so both ranks together draw exactly the masks of the single process.
     for p in model.parameters():
         p.grad = None
-    ft = pkg('train').FinetuneEngine(model, sched, lr=2e-4)
+    train = pkg('train')
+    ft = train.FinetuneEngine(model, sched, dropout=0.1, dropout_seed=7,
+                              lr_scheduler=train.get_scheduler('constant_with_warmup', 2e-4, num_warmup_steps=2))
     gen = torch.Generator().manual_seed(11)
     ft_losses = []
     for step in range(2):

@@ -122,7 +122,33 @@ def bmm_nt(a, b, alpha=1.0, out=None):
     return alpha * torch.bmm(a, b.transpose(1, 2))
 
 
-def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None):
+class _Drop:
+    """Plain-data twin of the ctypes dp_dropout descriptor; masks come from the numpy Philox restatement."""
+
+    def __init__(self, p, seed, site, step, n_off):
+        self.p, self.seed, self.site, self.step, self.n_off = p, seed, site, step, n_off
+
+
+def dropout_desc(p, seed, site, step, n_off=0):
+    return _Drop(p, seed, site, step, n_off) if p else None
+
+
+def _mult(x, drop):
+    from oracle import philox_ref
+    per = x[0].numel()
+    m = philox_ref.dropout_multipliers(x.numel(), drop.p, drop.seed, drop.site, drop.step, drop.n_off * per)
+    return torch.from_numpy(m).view(x.shape)
+
+
+def dropout_apply(x, drop, out=None):
+    y = x * _mult(x, drop)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None, drop=None):
     xc = _cat(x, x2)
     N, C = xc.shape[:2]
     xg = xc.reshape(N, G, -1)
@@ -132,10 +158,14 @@ def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None):
     y = F.group_norm(xc, G, gamma, beta, eps)
     if silu:
         y = F.silu(y)
+    if drop is not None:
+        y = y * _mult(y, drop)
     return y, torch.stack([mean, rstd], -1).reshape(N * G, 2)
 
 
-def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None):
+def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None, drop=None):
+    if drop is not None:
+        dz = dz * _mult(dz, drop)
     xc = _cat(x, x2)
     N, C, H, W = xc.shape
     cpg = C // G
@@ -272,10 +302,20 @@ def adam_ema(p_, g, m, v, ema, coef, lr, b1, b2, eps, step, ema_decay):
         ema.copy_((1 - ema_decay) * p_ + ema_decay * ema)
 
 
-def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None):
+def ddpm_step(x, eps, sqrt_a_t, sqrt_b_t, c_x0, c_xt, sigma=0.0, vnoise=None, clip=True, clip_range=1.0, out=None):
+    x0 = (x - sqrt_b_t * eps) / sqrt_a_t
+    if clip:
+        x0 = x0.clamp(-clip_range, clip_range)
+    v = c_x0 * x0 + c_xt * x
+    if vnoise is not None:
+        v = v + sigma * vnoise
+    return v
+
+
+def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None, clip_range=1.0):
     x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
     if clip:
-        x0 = x0.clamp(-1, 1)
+        x0 = x0.clamp(-clip_range, clip_range)
     v = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
     if vnoise is not None:
         v = v + std * vnoise

@@ -408,9 +408,11 @@ def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkey
             assert relerr(p.grad, P[n].grad) < 5e-5, n
 
 
-def test_multi_head_unet_refuses_to_run():
+def test_multi_head_unet_needs_the_gpu_like_any_other():
+    """Multi-head models run on the HIP engine since round 2 (tests/test_e2e_gpu.py::test_multi_head_*); on a CPU tensor the
+    refusal is the generic no-CPU-fallback one."""
     m = pkg('unet').UNet2DModel(**load_json('groups_more.json')['heads8_4lvl']['cfg'])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='no CPU'):
         m.engine()
 
 
@@ -518,7 +520,10 @@ def _cpu_engine(self):
     engine = pkg('engine')
     if self._engine is None:
         self._engine = engine.UNetEngine(self.config)
+    self._engine.packs.rebind()
     self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+    self._engine.set_dropout(self.dropout_table() if self.training else None, getattr(self, 'dropout_seed', 0),
+                             getattr(self, '_dropout_step', 0))
     return self._engine
 
 
@@ -569,7 +574,9 @@ def _cpu_step_init(self, model, scheduler, clean, noise, global_numel, loss_kind
         gb = global_batch if global_batch is not None else self.B
         self.gscale, self.lscale = 2.0 / gb, 1.0 / gb
     self.eng = model.engine()
-    self.eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
+    self._P = {n: p.detach() for n, p in model.named_parameters()}
+    self._G = {n: p.grad for n, p in model.named_parameters()}
+    self.eng.bind(self._P, self._G)
     self.acp = scheduler.alphas_cumprod
 
 
