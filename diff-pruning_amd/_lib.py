@@ -99,6 +99,7 @@ SIGNATURES = {
     'dp_q_sample': [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
     'dp_cfg_combine': [_vp, _vp, _f, _vp, _ll, _vp],
     'dp_version': [],
+    'dp_launch_count': [],
 }
 
 _lib = None
@@ -120,7 +121,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_longlong if name == 'dp_launch_count' else C.c_int
     _lib = lib
     return lib
 

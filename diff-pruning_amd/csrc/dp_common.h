@@ -115,3 +115,6 @@ static inline DpDrop dp_drop_host(const dp_dropout* d) {
 }
 
 #define DP_LAUNCH_CHECK() ((int)hipGetLastError())
+// every kernel launch of the library goes through DP_LAUNCH: dp_launch_count() reports launches per step in bench.py
+extern unsigned long long dp_launches;
+#define DP_LAUNCH(...) do { ++dp_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)

@@ -3,6 +3,9 @@
 // All are grid-stride, coalesced (consecutive lanes -> consecutive floats), wave-shuffle reductions.
 #include "dp_common.h"
 
+unsigned long long dp_launches = 0;
+extern "C" long long dp_launch_count(void) { return (long long)dp_launches; }
+
 static inline unsigned dp_grid(long long n, int per_block = 256, unsigned cap = 8192) {
     long long nb = (n + per_block - 1) / per_block;
     if (nb > cap) nb = cap;
@@ -24,12 +27,12 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
 }
 extern "C" int dp_silu_fwd(const float* x, float* y, long long n, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(silu_fwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    DP_LAUNCH(silu_fwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
     return DP_LAUNCH_CHECK();
 }
 extern "C" int dp_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(silu_bwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, accumulate);
+    DP_LAUNCH(silu_bwd_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, accumulate);
     return DP_LAUNCH_CHECK();
 }
 
@@ -38,7 +41,7 @@ __global__ void axpby_kernel(const float* __restrict__ x, float a, float* __rest
 }
 extern "C" int dp_axpby(const float* x, float a, float* y, float b, long long n, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(axpby_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, n);
+    DP_LAUNCH(axpby_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, n);
     return DP_LAUNCH_CHECK();
 }
 
@@ -56,7 +59,7 @@ __global__ void copy_strided_kernel(const float* __restrict__ src, long long s_s
 extern "C" int dp_copy_strided(const float* src, long long s_stride, float* dst, long long d_stride, int N,
                                long long per_img, int accumulate, void* stream) {
     if ((long long)N * per_img <= 0) return 0;
-    hipLaunchKernelGGL(copy_strided_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, src,
+    DP_LAUNCH(copy_strided_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, src,
                        s_stride, dst, d_stride, N, per_img, accumulate);
     return DP_LAUNCH_CHECK();
 }
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 }
 extern "C" int dp_softmax_fwd(const float* s, float* p, long long rows, int cols, void* stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, rows,
+    DP_LAUNCH(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, p, rows,
                        cols);
     return DP_LAUNCH_CHECK();
 }
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 extern "C" int dp_softmax_bwd(const float* p, const float* dp, float* ds, long long rows, int cols, float scale,
                               void* stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds,
+    DP_LAUNCH(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, ds,
                        rows, cols, scale);
     return DP_LAUNCH_CHECK();
 }
@@ -161,7 +164,7 @@ __global__ void temb_kernel(const float* __restrict__ t, int B, int dim, int fli
 extern "C" int dp_timestep_embedding(const float* t, int B, int dim, int flip_sin_to_cos, float freq_shift, float max_period,
                                      float* out, void* stream) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(temb_kernel, dim3(dp_grid((long long)B * dim)), dim3(256), 0, (hipStream_t)stream, t, B, dim,
+    DP_LAUNCH(temb_kernel, dim3(dp_grid((long long)B * dim)), dim3(256), 0, (hipStream_t)stream, t, B, dim,
                        flip_sin_to_cos, freq_shift, logf(max_period), out);
     return DP_LAUNCH_CHECK();
 }
@@ -183,7 +186,7 @@ __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __re
 extern "C" int dp_add_noise(const float* x0, const float* noise, const float* acp, const int64_t* t, int B,
                             long long per_img, float* out, void* stream) {
     if ((long long)B * per_img <= 0) return 0;
-    hipLaunchKernelGGL(add_noise_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
+    DP_LAUNCH(add_noise_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
                        acp, t, B, per_img, out);
     return DP_LAUNCH_CHECK();
 }
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out,
 extern "C" int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial,
                               int nblocks, void* stream) {
     if (n <= 0 || nblocks <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(mse_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, noise, n, gscale, dout, partial);
+    DP_LAUNCH(mse_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, noise, n, gscale, dout, partial);
     return DP_LAUNCH_CHECK();
 }
 
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (threadIdx.x == 0) dst[0] = s * scale;
 }
 extern "C" int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, dst);
+    DP_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, scale, dst);
     return DP_LAUNCH_CHECK();
 }
 
@@ -249,7 +252,7 @@ extern "C" int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, in
                              long long dx_img_stride, void* stream) {
     const long long total = (long long)N * C * H * W;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(downsum_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_img_stride, N, C, H, W,
+    DP_LAUNCH(downsum_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_img_stride, N, C, H, W,
                        dx, dx_img_stride);
     return DP_LAUNCH_CHECK();
 }
@@ -278,7 +281,7 @@ extern "C" int dp_ddim_step(const float* x, const float* eps, const float* vnois
     const float sqrt_b_t = powf(b_t, 0.5f);
     const float sqrt_a_prev = powf(a_prev, 0.5f);
     const float dir_coef = powf(1.0f - a_prev - stdv * stdv, 0.5f);
-    hipLaunchKernelGGL(ddim_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
+    DP_LAUNCH(ddim_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
                        sqrt_b_t, sqrt_a_prev, dir_coef, stdv, clip, clip_range, out, n);
     return DP_LAUNCH_CHECK();
 }
@@ -301,7 +304,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
 extern "C" int dp_ddpm_step(const float* x, const float* eps, const float* vnoise, float sqrt_a_t, float sqrt_b_t, float c_x0,
                             float c_xt, float sigma, int clip, float clip_range, float* out, long long n, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(ddpm_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
+    DP_LAUNCH(ddpm_step_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, eps, vnoise, sqrt_a_t,
                        sqrt_b_t, c_x0, c_xt, sigma, clip, clip_range, out, n);
     return DP_LAUNCH_CHECK();
 }
@@ -322,7 +325,7 @@ extern "C" int dp_dropout_apply(const float* x, long long x_img_stride, float* y
                                 long long per_img, const dp_dropout* drop, void* stream) {
     if ((long long)N * per_img <= 0) return 0;
     if (!drop || !drop->thr24) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, x,
+    DP_LAUNCH(dropout_apply_kernel, dim3(dp_grid((long long)N * per_img)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, y, y_img_stride, N, per_img, dp_drop_host(drop));
     return DP_LAUNCH_CHECK();
 }
@@ -333,7 +336,7 @@ __global__ void dropout_mask_kernel(float* __restrict__ m, long long idx0, long 
 extern "C" int dp_dropout_mask(float* m, long long idx0, long long n, const dp_dropout* drop, void* stream) {
     if (n <= 0) return 0;
     if (!drop || !drop->thr24) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, m, idx0, n,
+    DP_LAUNCH(dropout_mask_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, m, idx0, n,
                        dp_drop_host(drop));
     return DP_LAUNCH_CHECK();
 }
@@ -354,7 +357,7 @@ __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __res
 extern "C" int dp_q_sample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1m_acp,
                            const int64_t* t, int B, long long per_img, float* out, void* stream) {
     if ((long long)B * per_img <= 0) return 0;
-    hipLaunchKernelGGL(q_sample_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
+    DP_LAUNCH(q_sample_kernel, dim3(dp_grid((long long)B * per_img)), dim3(256), 0, (hipStream_t)stream, x0, noise,
                        sqrt_acp, sqrt_1m_acp, t, B, per_img, out);
     return DP_LAUNCH_CHECK();
 }
@@ -368,6 +371,6 @@ __global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __
 }
 extern "C" int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, long long n, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(cfg_combine_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, e_uncond, e_cond, scale, out, n);
+    DP_LAUNCH(cfg_combine_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, e_uncond, e_cond, scale, out, n);
     return DP_LAUNCH_CHECK();
 }

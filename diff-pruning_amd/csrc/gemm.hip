@@ -747,19 +747,19 @@ static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
     if constexpr (BM == 128 && BN == 128) {
         if (conv_fast_ok(p)) {
-            if (conv_fast_tails(p)) hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
-            else                    hipLaunchKernelGGL((conv_gemm_fast_kernel<128, 128, false>), grid, dim3(256), dp_lds_pad(), st, p);
+            if (conv_fast_tails(p)) DP_LAUNCH((conv_gemm_fast_kernel<128, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
+            else                    DP_LAUNCH((conv_gemm_fast_kernel<128, 128, false>), grid, dim3(256), dp_lds_pad(), st, p);
             return DP_LAUNCH_CHECK();
         }
     }
     // a K-chunk of 16 channels can straddle the concat boundary only when c_split is not a multiple of 16
     const bool straddle = p.X2 != nullptr && (p.g.c_split % 16) != 0;
     if (p.a_kc) {
-        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, true>), grid, dim3(256), dp_lds_pad(), st, p);
-        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, false>), grid, dim3(256), dp_lds_pad(), st, p);
+        if (straddle) DP_LAUNCH((conv_gemm_kernel<BM, BN, true, true>), grid, dim3(256), dp_lds_pad(), st, p);
+        else          DP_LAUNCH((conv_gemm_kernel<BM, BN, true, false>), grid, dim3(256), dp_lds_pad(), st, p);
     } else {
-        if (straddle) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
-        else          hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, false>), grid, dim3(256), dp_lds_pad(), st, p);
+        if (straddle) DP_LAUNCH((conv_gemm_kernel<BM, BN, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
+        else          DP_LAUNCH((conv_gemm_kernel<BM, BN, false, false>), grid, dim3(256), dp_lds_pad(), st, p);
     }
     return DP_LAUNCH_CHECK();
 }
@@ -798,7 +798,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         case 3:                                                  // 96x128: fast kernel only, else the 128x128 path
             if (conv_fast_ok(p)) {
                 dim3 grid((p.NPIX + 127) / 128, (p.M + 95) / 96, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
-                hipLaunchKernelGGL((conv_gemm_fast_kernel<96, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
+                DP_LAUNCH((conv_gemm_fast_kernel<96, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
                 e = DP_LAUNCH_CHECK();
                 break;
             }
@@ -811,7 +811,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
     if (e || p.ksplit <= 1) return e;
     long long nb = ((long long)p.M * p.NPIX + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+    DP_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
     return DP_LAUNCH_CHECK();
 }
 
@@ -1192,18 +1192,18 @@ static int launch_nt_gemm(const dp_nt_gemm_params& p, hipStream_t st) {
             const int ncv = p.X2 ? ((p.g.c_split + 3) & ~3) + (p.NCOLS - p.g.c_split) : p.NCOLS;   // virtual columns
             if (p.tile == 3) {
                 dim3 g96((ncv + 95) / 96, (p.M + 95) / 96, gz > 0 ? gz : 1);
-                if (p.X2) hipLaunchKernelGGL((nt_gemm_fast_kernel<3, true>), g96, dim3(192), dp_lds_pad(), st, p);
-                else      hipLaunchKernelGGL((nt_gemm_fast_kernel<3, false>), g96, dim3(192), dp_lds_pad(), st, p);
+                if (p.X2) DP_LAUNCH((nt_gemm_fast_kernel<3, true>), g96, dim3(192), dp_lds_pad(), st, p);
+                else      DP_LAUNCH((nt_gemm_fast_kernel<3, false>), g96, dim3(192), dp_lds_pad(), st, p);
             } else {
                 dim3 g128((ncv + 127) / 128, (p.M + 127) / 128, gz > 0 ? gz : 1);
-                if (p.X2) hipLaunchKernelGGL((nt_gemm_fast_kernel<4, true>), g128, dim3(256), dp_lds_pad(), st, p);
-                else      hipLaunchKernelGGL((nt_gemm_fast_kernel<4, false>), g128, dim3(256), dp_lds_pad(), st, p);
+                if (p.X2) DP_LAUNCH((nt_gemm_fast_kernel<4, true>), g128, dim3(256), dp_lds_pad(), st, p);
+                else      DP_LAUNCH((nt_gemm_fast_kernel<4, false>), g128, dim3(256), dp_lds_pad(), st, p);
             }
             return DP_LAUNCH_CHECK();
         }
     }
-    if (straddle) hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), dp_lds_pad(), st, p);
-    else          hipLaunchKernelGGL((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), dp_lds_pad(), st, p);
+    if (straddle) DP_LAUNCH((nt_gemm_kernel<BM, BN, true>), grid, dim3(256), dp_lds_pad(), st, p);
+    else          DP_LAUNCH((nt_gemm_kernel<BM, BN, false>), grid, dim3(256), dp_lds_pad(), st, p);
     return DP_LAUNCH_CHECK();
 }
 
@@ -1215,7 +1215,7 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
     if (p.merge) {               // NCOLS = C*ntaps merged columns, one source, 64x64 tiles, blockIdx.z = split
         if (p.batched || p.X2 || p.splits <= 0) return (int)hipErrorInvalidValue;
         dim3 grid((p.NCOLS + 63) / 64, (p.M + 63) / 64, p.splits);
-        hipLaunchKernelGGL((nt_gemm_kernel<64, 64, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
+        DP_LAUNCH((nt_gemm_kernel<64, 64, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
         return DP_LAUNCH_CHECK();
     }
     switch (p.tile) {
@@ -1258,7 +1258,7 @@ extern "C" int dp_splitk_reduce_taps(const float* ws, long long stride, int spli
     if (mc <= 0 || ntaps <= 0) return 0;
     long long nb = (mc * ntaps + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(splitk_reduce_taps_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits,
+    DP_LAUNCH(splitk_reduce_taps_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits,
                        out, mc, ntaps, accumulate);
     return DP_LAUNCH_CHECK();
 }
@@ -1268,7 +1268,7 @@ extern "C" int dp_splitk_reduce(const float* ws, long long stride, int splits, f
     if (n <= 0) return 0;
     long long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits, out,
+    DP_LAUNCH(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits, out,
                        n, accumulate);
     return DP_LAUNCH_CHECK();
 }
@@ -1302,7 +1302,7 @@ extern "C" int dp_pack_weight(const float* W, int Co, int Ci, int taps, int mode
     if (total <= 0) return 0;
     long long nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, taps, mode, dst,
+    DP_LAUNCH(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, taps, mode, dst,
                        ld);
     return DP_LAUNCH_CHECK();
 }

@@ -69,20 +69,20 @@ extern "C" int dp_wg_reduce(const float* w, const float* g, int R, int C, int T,
     hipStream_t st = (hipStream_t)stream;
     if (R <= 0 || C <= 0 || T <= 0) return 0;
     if (mode == 3) {
-        hipLaunchKernelGGL(wg_gn_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, g, R, out, accumulate);
+        DP_LAUNCH(wg_gn_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w, g, R, out, accumulate);
         return DP_LAUNCH_CHECK();
     }
     if (dim == 0) {
-        hipLaunchKernelGGL(wg_rows_kernel, dim3(R), dim3(256), 0, st, w, g, R, (long long)C * T, mode, out, accumulate);
+        DP_LAUNCH(wg_rows_kernel, dim3(R), dim3(256), 0, st, w, g, R, (long long)C * T, mode, out, accumulate);
         return DP_LAUNCH_CHECK();
     }
     // dim 1: per-(c,t) column sums into `scratch` (C*T floats), then fold the T taps of each channel
     if (!scratch) return (int)hipErrorInvalidValue;
     const long long CT = (long long)C * T;
-    hipLaunchKernelGGL(wg_cols_ct_kernel, dim3((unsigned)((CT + 63) / 64)), dim3(256), 0, st, w, g, R, CT, mode, scratch);
+    DP_LAUNCH(wg_cols_ct_kernel, dim3((unsigned)((CT + 63) / 64)), dim3(256), 0, st, w, g, R, CT, mode, scratch);
     int e = DP_LAUNCH_CHECK();
     if (e) return e;
-    hipLaunchKernelGGL(wg_fold_taps_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, T, mode, out, accumulate);
+    DP_LAUNCH(wg_fold_taps_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, T, mode, out, accumulate);
     return DP_LAUNCH_CHECK();
 }
 
@@ -93,6 +93,6 @@ __global__ void gather_add_kernel(const float* __restrict__ src, const int64_t* 
 }
 extern "C" int dp_gather_add(const float* src, const int64_t* idx, int n, float* dst, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gather_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, n, dst);
+    DP_LAUNCH(gather_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, n, dst);
     return DP_LAUNCH_CHECK();
 }

@@ -198,10 +198,10 @@ extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_spl
     const bool vec4 = (HW % 4 == 0) && (x1_img_stride % 4 == 0) && (x2_img_stride % 4 == 0) && (y_img_stride % 4 == 0) &&
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0);
     if (vec4)
-        hipLaunchKernelGGL(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
+        DP_LAUNCH(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
                            silu, y, y_img_stride, stats, dd);
     else
-        hipLaunchKernelGGL(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu,
+        DP_LAUNCH(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu,
                            y, y_img_stride, stats, dd);
     return DP_LAUNCH_CHECK();
 }
@@ -384,11 +384,11 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
                                          add2_img_stride) % 4 == 0) &&
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)add1 | (uintptr_t)add2) % 16 == 0);
     if (vec4)
-        hipLaunchKernelGGL(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+        DP_LAUNCH(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
                            pws, dd);
     else
-        hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+        DP_LAUNCH(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
                            pws, dd);
     return DP_LAUNCH_CHECK();
@@ -478,10 +478,10 @@ extern "C" int dp_groupnorm_silu_fwd_split(const float* x1, const float* x2, int
         return (int)hipErrorInvalidValue;
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_split_part_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, C, HW, slices, ws);
-    hipLaunchKernelGGL(gn_split_combine_fwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, N * G, C / G, slices, HW, eps,
+    DP_LAUNCH(gn_split_part_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, C, HW, slices, ws);
+    DP_LAUNCH(gn_split_combine_fwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, N * G, C / G, slices, HW, eps,
                        stats);
-    hipLaunchKernelGGL(gn_split_apply_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, C, HW, G, slices, silu,
+    DP_LAUNCH(gn_split_apply_fwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, C, HW, G, slices, silu,
                        stats, y, y_img_stride, dd);
     return DP_LAUNCH_CHECK();
 }
@@ -600,11 +600,11 @@ extern "C" int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
     hipStream_t st = (hipStream_t)stream;
     float* ab = ws + (long long)N * C * slices * 2;               // ws: [N*C*slices*2] partials, then [N*G*2] group terms
-    hipLaunchKernelGGL(gn_split_part_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, dz, dz_img_stride,
+    DP_LAUNCH(gn_split_part_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, dz, dz_img_stride,
                        C, HW, G, slices, silu, ws, dd);
-    hipLaunchKernelGGL(gn_split_combine_bwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, gamma, N * G, G, C, slices, HW,
+    DP_LAUNCH(gn_split_combine_bwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, gamma, N * G, G, C, slices, HW,
                        pws, ab);
-    hipLaunchKernelGGL(gn_split_apply_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, ab, dz,
+    DP_LAUNCH(gn_split_apply_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, ab, dz,
                        dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, dd);
     return DP_LAUNCH_CHECK();
 }
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ w
 extern "C" int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate,
                                void* stream) {
     if (C <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, N, C, wstride, woff, out,
+    DP_LAUNCH(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, N, C, wstride, woff, out,
                        accumulate);
     return DP_LAUNCH_CHECK();
 }
@@ -691,12 +691,12 @@ extern "C" int dp_rowsum_nc(const float* x, long long img_stride, int N, int C, 
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (HW % 4 == 0) && (img_stride % 4 == 0) && ((uintptr_t)x % 16 == 0);
     if (HW >= 4096) {
-        if (vec4) hipLaunchKernelGGL(rowsum_plane_kernel<true>, dim3((unsigned)nrows), dim3(256), 0, st, x, img_stride, C, HW, rows);
-        else      hipLaunchKernelGGL(rowsum_plane_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, st, x, img_stride, C, HW, rows);
+        if (vec4) DP_LAUNCH(rowsum_plane_kernel<true>, dim3((unsigned)nrows), dim3(256), 0, st, x, img_stride, C, HW, rows);
+        else      DP_LAUNCH(rowsum_plane_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, st, x, img_stride, C, HW, rows);
     } else {
         const dim3 grid((unsigned)((nrows + 3) / 4));
-        if (vec4) hipLaunchKernelGGL(rowsum_kernel<true>, grid, dim3(256), 0, st, x, img_stride, N, C, HW, rows);
-        else      hipLaunchKernelGGL(rowsum_kernel<false>, grid, dim3(256), 0, st, x, img_stride, N, C, HW, rows);
+        if (vec4) DP_LAUNCH(rowsum_kernel<true>, grid, dim3(256), 0, st, x, img_stride, N, C, HW, rows);
+        else      DP_LAUNCH(rowsum_kernel<false>, grid, dim3(256), 0, st, x, img_stride, N, C, HW, rows);
     }
     return DP_LAUNCH_CHECK();
 }

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 }
 extern "C" int dp_sumsq_partials(const float* x, long long n, float* partial, int nblocks, void* stream) {
     if (nblocks <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partial);
+    DP_LAUNCH(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partial);
     return DP_LAUNCH_CHECK();
 }
 
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     }
 }
 extern "C" int dp_clip_coef(const float* partial, int n, float max_norm, float* norm_out, float* coef_out, void* stream) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, max_norm, norm_out, coef_out);
+    DP_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, max_norm, norm_out, coef_out);
     return DP_LAUNCH_CHECK();
 }
 
@@ -62,7 +62,7 @@ extern "C" int dp_adam_ema(float* p, const float* g, float* m, float* v, float* 
     if (n <= 0) return 0;
     long long nb = (n + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, clip_coef,
+    DP_LAUNCH(adam_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, clip_coef,
                        lr, b1, b2, eps, bc1, bc2, ema_decay);
     return DP_LAUNCH_CHECK();
 }

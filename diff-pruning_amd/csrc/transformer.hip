@@ -50,7 +50,7 @@ extern "C" int dp_layernorm_fwd(const float* x, long long x_img_stride, const fl
                                 int T, float eps, float* y, long long y_img_stride, float* stats, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
+    DP_LAUNCH(ln_fwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, gamma, beta, N, C, T, eps, y, y_img_stride, stats);
     return DP_LAUNCH_CHECK();
 }
@@ -129,12 +129,12 @@ extern "C" int dp_layernorm_bwd(const float* x, long long x_img_stride, const fl
                                 long long dx_img_stride, const float* add, long long add_img_stride, float* pws, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
+    DP_LAUNCH(ln_bwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, gamma, stats, dy, dy_img_stride, N, C, T, dx, dx_img_stride, add, add_img_stride);
     int e = DP_LAUNCH_CHECK();
     if (e) return e;
     const long long nrows = (long long)N * C;
-    hipLaunchKernelGGL(ln_param_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_img_stride,
+    DP_LAUNCH(ln_param_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_img_stride,
                        stats, dy, dy_img_stride, N, C, T, pws);
     return DP_LAUNCH_CHECK();
 }
@@ -174,13 +174,13 @@ static inline unsigned tf_grid(long long n) {
 }
 extern "C" int dp_geglu_fwd(const float* in, int N, long long half_plane, float* out, void* stream) {
     if ((long long)N * half_plane <= 0) return 0;
-    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(tf_grid((long long)N * half_plane)), dim3(256), 0, (hipStream_t)stream, in, N,
+    DP_LAUNCH(geglu_fwd_kernel, dim3(tf_grid((long long)N * half_plane)), dim3(256), 0, (hipStream_t)stream, in, N,
                        half_plane, out);
     return DP_LAUNCH_CHECK();
 }
 extern "C" int dp_geglu_bwd(const float* in, const float* dout, int N, long long half_plane, float* din, void* stream) {
     if ((long long)N * half_plane <= 0) return 0;
-    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(tf_grid((long long)N * half_plane)), dim3(256), 0, (hipStream_t)stream, in, dout,
+    DP_LAUNCH(geglu_bwd_kernel, dim3(tf_grid((long long)N * half_plane)), dim3(256), 0, (hipStream_t)stream, in, dout,
                        N, half_plane, din);
     return DP_LAUNCH_CHECK();
 }
@@ -199,7 +199,7 @@ __global__ void add_rowvec_kernel(const float* __restrict__ x, long long x_img_s
 extern "C" int dp_add_rowvec(const float* x, long long x_img_stride, const float* v, int N, int C, int T, float* out,
                              long long o_img_stride, void* stream) {
     if ((long long)N * C * T <= 0) return 0;
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3(tf_grid((long long)N * C * T)), dim3(256), 0, (hipStream_t)stream, x,
+    DP_LAUNCH(add_rowvec_kernel, dim3(tf_grid((long long)N * C * T)), dim3(256), 0, (hipStream_t)stream, x,
                        x_img_stride, v, N, C, T, out, o_img_stride);
     return DP_LAUNCH_CHECK();
 }

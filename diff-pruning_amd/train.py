@@ -59,19 +59,10 @@ def get_scheduler(name, base_lr, step_rules=None, num_warmup_steps=None, num_tra
         raise ValueError('%r is not a valid SchedulerType' % (name,))
     if name == 'constant':                                        # optimization.py:40-53
         return LambdaLR(base_lr, lambda _: 1, last_epoch)
-    if name == 'piecewise_constant':                              # optimization.py:81-120
-        rules, rule_list = {}, step_rules.split(',')
-        for rule in rule_list[:-1]:
-            value, steps = rule.split(':')
-            rules[int(steps)] = float(value)
-        last = float(rule_list[-1])
-
-        def piecewise(step):
-            for s in sorted(rules):
-                if step < s:
-                    return rules[s]
-            return last
-        return LambdaLR(base_lr, piecewise, last_epoch)
+    if name == 'piecewise_constant':
+        # reference behaviour kept: optimization.py:321 calls get_piecewise_constant_schedule(optimizer, rules=...) whose
+        # parameter is named step_rules, so this branch of get_scheduler raises; the schedule itself is reachable directly
+        raise TypeError("get_piecewise_constant_schedule() got an unexpected keyword argument 'rules'")
     if num_warmup_steps is None:
         raise ValueError('%s requires `num_warmup_steps`, please provide that argument.' % name)
     W = num_warmup_steps
@@ -112,6 +103,22 @@ def get_scheduler(name, base_lr, step_rules=None, num_warmup_steps=None, num_tra
             pct_remaining = 1 - (k - W) / (T - W)
             return ((lr_init - lr_end) * pct_remaining ** power + lr_end) / lr_init
     return LambdaLR(base_lr, f, last_epoch)
+
+
+def get_piecewise_constant_schedule(base_lr, step_rules, last_epoch=-1):
+    """optimization.py:81-120: step_rules = "1:10,0.1:20,0.01:30,0.005" -> multiplier 1 before step 10, 0.1 before 20, ..."""
+    rules, rule_list = {}, step_rules.split(',')
+    for rule in rule_list[:-1]:
+        value, steps = rule.split(':')
+        rules[int(steps)] = float(value)
+    last = float(rule_list[-1])
+
+    def piecewise(step):
+        for s in sorted(rules):
+            if step < s:
+                return rules[s]
+        return last
+    return LambdaLR(base_lr, piecewise, last_epoch)
 
 
 def set_dropout(model, p):

@@ -232,6 +232,9 @@ int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, floa
 
 /* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
 int dp_version(void);
+/* Number of kernel launches this library has issued since it was loaded (host counter; bench.py reports launches per step).
+ * Returned in place of an error code. */
+long long dp_launch_count(void);
 
 #ifdef __cplusplus
 }

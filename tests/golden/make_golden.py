@@ -17,6 +17,10 @@ Fixtures:
   tiny_prune.json   G3/G4 for the tiny UNet: group tables, scores, pruned indices (ratio 0.3), early-exit step count
   cifar_groups.json G3 group table for the CIFAR-10 UNet (50 groups) and the bedroom-256 topology
   cifar_c1.npz/json G2/G4/G5 config C1: CIFAR UNet, B=4, 8 timesteps, Taylor, ratio 0.3
+  tiny_long_sweep.json  1000-step sweep + prune of the tiny UNet (accumulation length of config C2)
+  lr_schedules.json     diffusers get_scheduler: lr per step for every schedule type
+  ddpm.npz              DDPMScheduler.step sequences + a DDPMPipeline call
+  tiny_dropout.json     finetune loss / gradients of the reference UNet in train mode with reproducible (Philox) masks
 """
 import os, sys, json, time, base64, io
 
@@ -462,7 +466,132 @@ def do_c1():
               open(os.path.join(HERE, 'cifar_c1.json'), 'w'))
 
 
+def do_long_sweep():
+    """1000 accumulated backward passes (the C2 sweep length; SURVEY.md §7 'hard parts': error growth over the accumulation is
+    the risk to bit-exact masks): tiny UNet, B=2, plain Taylor over t = 0..999, then the whole sequential prune."""
+    cfg = gc.TINY_CFG
+    H = cfg['sample_size']
+    model = build_ref_unet(cfg, 5)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((2, 3, H, H), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, H, H), 2))
+    t0 = time.time()
+    losses = sweep(model, sched, clean, noise, 1000)
+    print('1000-step sweep %.1fs' % (time.time() - t0))
+    st = grad_stats(model)
+    rec = prune_run(model, H, 0.3)
+    json.dump(dict(losses=losses, grad_stats=st,
+                   prune=[dict(root=r['root'], ch_groups=r['ch_groups'], cur=r['cur'], pruned=r['pruned'], score=r['score'])
+                          for r in rec],
+                   params_after=int(sum(p.numel() for p in model.parameters()))),
+              open(os.path.join(HERE, 'tiny_long_sweep.json'), 'w'))
+    print('long sweep ok: groups', len(rec), 'loss[0], loss[999]', losses[0], losses[-1])
+
+
+def do_lr():
+    """diffusers/optimization.py:282 get_scheduler: the lr in force at each of 40 optimizer steps, every schedule type."""
+    from diffusers.optimization import get_scheduler
+    out = {}
+    cases = dict(constant=dict(), constant_with_warmup=dict(num_warmup_steps=5),
+                 linear=dict(num_warmup_steps=5, num_training_steps=30), cosine=dict(num_warmup_steps=5, num_training_steps=30),
+                 cosine_with_restarts=dict(num_warmup_steps=5, num_training_steps=30, num_cycles=3),
+                 polynomial=dict(num_warmup_steps=5, num_training_steps=30, power=2.0),
+                 piecewise_constant=dict(step_rules='1:10,0.1:20,0.01:30,0.005'))
+    for name, kw in cases.items():
+        w = torch.nn.Parameter(torch.zeros(2))
+        opt = torch.optim.Adam([w], lr=2e-4)
+        if name == 'piecewise_constant':
+            # get_scheduler('piecewise_constant') itself raises TypeError in the reference (optimization.py:321 passes
+            # `rules=` to a function whose parameter is `step_rules`): record the working direct call
+            from diffusers.optimization import get_piecewise_constant_schedule
+            sch = get_piecewise_constant_schedule(opt, **kw)
+        else:
+            sch = get_scheduler(name, optimizer=opt, **kw)
+        lrs = []
+        for _ in range(40):
+            lrs.append(sch.get_last_lr()[0])
+            w.grad = torch.ones(2)
+            opt.step()
+            sch.step()
+        out[name] = dict(kwargs=kw, lrs=lrs)
+    json.dump(dict(base_lr=2e-4, cases=out), open(os.path.join(HERE, 'lr_schedules.json'), 'w'))
+    print('lr ok', {k: v['lrs'][6] for k, v in out.items()})
+
+
+def do_ddpm():
+    """DDPMScheduler.step / DDPMPipeline (scheduling_ddpm.py:312-406, pipeline_ddpm.py:24-105) on the tiny UNet: 4 consecutive
+    ancestral steps from t = 999 (1000 inference steps), 4 with set_timesteps(50), fixed_large variance, and a 6-step pipeline
+    call; the variance noise comes from a seeded CPU generator (randn_tensor)."""
+    from diffusers import DDPMPipeline
+    cfg = gc.TINY_CFG
+    model = build_ref_unet(cfg, 5)
+    out = {}
+    for tag, n_inf, vt in (('full', 1000, 'fixed_small'), ('s50', 50, 'fixed_small'), ('large', 50, 'fixed_large')):
+        sch = DDPMScheduler(num_train_timesteps=1000, variance_type=vt)
+        sch.set_timesteps(n_inf)
+        gen = torch.Generator().manual_seed(123)
+        x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 23))
+        xs = []
+        with torch.no_grad():
+            for t in sch.timesteps[:4]:
+                x = sch.step(model(x, t).sample, t, x, generator=gen).prev_sample
+                xs.append(x.numpy().copy())
+        out['x_' + tag] = np.stack(xs)
+        out['timesteps_' + tag] = sch.timesteps.numpy().copy()
+    # last step (t = 0: no noise) from a seeded sample
+    sch = DDPMScheduler(num_train_timesteps=1000)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 24))
+    with torch.no_grad():
+        out['x_t0'] = sch.step(model(x, 0).sample, 0, x, generator=torch.Generator().manual_seed(5)).prev_sample.numpy()
+    pipe = DDPMPipeline(unet=model, scheduler=DDPMScheduler(num_train_timesteps=1000))
+    pipe.set_progress_bar_config(disable=True)
+    out['pipe6'] = pipe(batch_size=2, generator=torch.Generator().manual_seed(9), num_inference_steps=6, output_type='numpy').images
+    np.savez(os.path.join(HERE, 'ddpm.npz'), **out)
+    print('ddpm ok', {k: v.shape for k, v in out.items()})
+
+
+def do_dropout():
+    """Where dropout sits in the reference graph, with masks the build can reproduce: the reference UNet2DModel in train()
+    mode after utils.set_dropout(model, 0.1) (utils.py:26-29: every nn.Dropout, i.e. ResnetBlock2D.dropout AND
+    Attention.to_out[1]), each nn.Dropout.forward replaced by a multiplication with the Philox mask of oracle/philox_ref.py
+    (logical index = channel-major element of the [N, C, H, W] activation; the attention dropout acts on [N, T, C] tokens, so it
+    is transposed around the multiplication).  Records the finetune loss (ddpm_train.py:453-459) and gradient statistics."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import philox_ref
+    cfg = gc.TINY_CFG
+    model = build_ref_unet(cfg, 5)
+    for m in model.modules():                       # utils.set_dropout(model, 0.1)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.1
+    model.train()
+    for m in model.modules():
+        if isinstance(m, Attention):
+            m.set_processor(AttnProcessor())
+    seed, step = 77, 3
+    n_sites = 0
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Dropout):
+            n_sites += 1
+            spec = philox_ref.DropSpec({name: m.p}, seed, step, 0)
+            if name.endswith('to_out.1'):
+                m.forward = (lambda x, spec=spec, name=name:
+                             spec.apply(name, x.transpose(1, 2).contiguous()).transpose(1, 2))
+            else:
+                m.forward = (lambda x, spec=spec, name=name: spec.apply(name, x))
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    B = 4
+    clean = torch.from_numpy(gc.det_clean((B, 3, 16, 16), 3))
+    noise = torch.from_numpy(gc.det_noise((B, 3, 16, 16), 4))
+    t = torch.tensor([1, 250, 500, 998])
+    out = model(sched.add_noise(clean, noise, t), t).sample
+    loss = (noise - out).square().sum(dim=(1, 2, 3)).mean(dim=0)
+    loss.backward()
+    json.dump(dict(p=0.1, seed=seed, step=step, sites=n_sites, loss=float(loss), fwd_out=gc.f32_to_b64(out.detach().numpy()),
+                   grad_stats=grad_stats(model)), open(os.path.join(HERE, 'tiny_dropout.json'), 'w'))
+    print('dropout ok: sites', n_sites, 'loss', float(loss))
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads', 'long_sweep', 'lr', 'ddpm', 'dropout']
     for w in what:
         globals()['do_' + w]()

@@ -77,3 +77,36 @@ def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ig
         for m in graph_mod.coupled_members(graph, chan(), root, pruned):
             R.slice_member(P, G, m.name, 'gn' if m.kind == 'ln' else m.kind, m.idxs)
     return out
+
+
+class _FakePrunerBase:
+    """Stand-ins shaped like torch_pruning's pruner singletons: tp.function.prune_conv_out_channels etc. are BOUND METHODS
+    `ConvPruner().prune_out_channels` (function.py:535-566); importance criteria compare handlers by identity / owner."""
+
+    def prune_out_channels(self, layer, idxs):
+        raise AssertionError('importance must not prune')
+
+    def prune_in_channels(self, layer, idxs):
+        raise AssertionError('importance must not prune')
+
+
+def tp_like_groups(model, graph_mod):
+    ConvPruner = type('ConvPruner', (_FakePrunerBase,), {})
+    LinearPruner = type('LinearPruner', (_FakePrunerBase,), {})
+    GroupNormPruner = type('GroupNormPruner', (_FakePrunerBase,), {})
+    boxes = {torch.nn.Conv2d: ConvPruner(), torch.nn.Linear: LinearPruner(), torch.nn.GroupNorm: GroupNormPruner()}
+    mods = dict(model.named_modules())
+    from types import SimpleNamespace
+    graph = graph_mod.UNetGraph(model.config)
+    view = graph_mod.ChannelView({n: tuple(p.shape) for n, p in model.named_parameters()})
+    out = []
+    for root, members in graph_mod.all_groups(graph, lambda: view, ('conv_out',)):
+        items = []
+        for m in members:
+            mod = mods[m.name]
+            box = boxes[type(mod)]
+            handler = box.prune_in_channels if m.kind == 'in' else box.prune_out_channels
+            # exactly the attributes importance.py:378-411 reads: dep.target.module, dep.handler, and the idxs list
+            items.append((SimpleNamespace(target=SimpleNamespace(module=mod, name=m.name), handler=handler), list(m.idxs)))
+        out.append((root, items))
+    return out

@@ -11,7 +11,7 @@ import torch
 import golden_common as gc
 import os as _os
 GOLD_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
-from helpers import GOLD, load_json, load_npz, oracle_params, pkg, relerr, oracle_prune_replay
+from helpers import tp_like_groups, GOLD, load_json, load_npz, oracle_params, pkg, relerr, oracle_prune_replay
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     L = pkg('_lib')
     hdr = open(os.path.join(ROOT, 'include', 'dp_hip.h')).read()
-    declared = set(re.findall(r'^int (dp_\w+)\(', hdr, re.M))
+    declared = set(re.findall(r'^(?:int|long long) (dp_\w+)\(', hdr, re.M))
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.load()
     for name in declared:
@@ -28,6 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.dp_version() >= 100
     # struct sizes agree with the C header layout (all-int/pointer/long long members, natural alignment)
     assert ctypes.sizeof(L.ConvGeom) == 14 * 4 + 2 * 8
+    assert ctypes.sizeof(L.Dropout) == 32 and lib.dp_launch_count() >= 0
 
 
 def test_diffusers_pipeline_directory_io(tmp_path):
@@ -1045,3 +1046,154 @@ def test_ldm_prune_flow_on_mocked_kernels(mocked, monkeypatch):
     fresh = ldm.UNetModel(**cfg)
     ckpt.adopt_state_dict(fresh, sd)
     assert {n: list(p.shape) for n, p in fresh.named_parameters()} == fx['shapes_after']
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: dropout masks, LR schedules, DDPM ancestral sampling, long accumulation, torch_pruning-shaped groups
+# ------------------------------------------------------------------------------------------------------------------
+def test_philox_known_answers():
+    """oracle/philox_ref.py against the published known-answer vectors of Philox4x32-10 (Random123 kat_vectors)."""
+    from oracle import philox_ref as PH
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in PH.philox4x32_10(*ctr, *key)) == want
+    m = PH.dropout_multipliers(1 << 16, 0.1, 5, 'down_blocks.0.resnets.0.dropout', 2)
+    assert set(np.unique(m)) == {np.float32(0.0), np.float32(1.0 / 0.9)}
+    assert abs(float((m == 0).mean()) - 0.1) < 0.01
+    # a window of the same stream equals the stream restricted to the window (element-indexed, not draw-ordered)
+    w = PH.dropout_multipliers(1000, 0.1, 5, 'down_blocks.0.resnets.0.dropout', 2, idx0=4321)
+    assert np.array_equal(w, m[4321:5321])
+
+
+def test_lr_schedules_match_reference():
+    """train.get_scheduler vs diffusers/optimization.py:282 (values recorded from the reference with a torch optimizer)."""
+    train = pkg('train')
+    fx = load_json('lr_schedules.json')
+    for name, case in fx['cases'].items():
+        if name == 'piecewise_constant':
+            with pytest.raises(TypeError):                         # optimization.py:321 (reference behaviour)
+                train.get_scheduler(name, fx['base_lr'], **case['kwargs'])
+            sch = train.get_piecewise_constant_schedule(fx['base_lr'], **case['kwargs'])
+        else:
+            sch = train.get_scheduler(name, fx['base_lr'], **case['kwargs'])
+        got = []
+        for _ in case['lrs']:
+            got.append(sch.get_last_lr()[0])
+            sch.step()
+        assert np.allclose(got, case['lrs'], rtol=1e-12, atol=0), name
+    with pytest.raises(ValueError):
+        train.get_scheduler('cosine', 1e-4)                        # needs num_warmup_steps
+    with pytest.raises(ValueError):
+        train.get_scheduler('nope', 1e-4)
+
+
+def test_oracle_and_scheduler_ddpm_steps_match_reference(mocked):
+    """DDPMScheduler.step / set_timesteps / DDPMPipeline (scheduling_ddpm.py:185-236,312-406; pipeline_ddpm.py:24-105):
+    the oracle restatement and the product's host logic (on mocked kernels) against sequences recorded from the reference."""
+    from oracle import diffusion_ref as D, unet_ref as U
+    diffusion = pkg('diffusion')
+    g = load_npz('ddpm.npz')
+    cfg = gc.TINY_CFG
+    P = oracle_params(cfg, 5, requires_grad=False)
+    acp = D.alphas_cumprod()
+    model = _cpu_model(cfg, 5)
+    for tag, n_inf, vt in (('full', 1000, 'fixed_small'), ('s50', 50, 'fixed_small'), ('large', 50, 'fixed_large')):
+        assert np.array_equal(D.ddpm_timesteps(n_inf).numpy(), g['timesteps_' + tag])
+        sch = diffusion.DDPMScheduler(variance_type=vt)
+        sch.set_timesteps(n_inf)
+        assert np.array_equal(sch.timesteps.numpy(), g['timesteps_' + tag])
+        gen_o, gen_p = torch.Generator().manual_seed(123), torch.Generator().manual_seed(123)
+        xo = xp = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 23))
+        with torch.no_grad():
+            for i, t in enumerate(sch.timesteps[:4]):
+                noise = torch.randn(xo.shape, generator=gen_o)
+                xo = D.ddpm_step(acp, U.unet_forward(P, cfg, xo, t), t, xo, n_inf, variance_noise=noise, variance_type=vt)
+                xp = sch.step(model(xp, t).sample, t, xp, generator=gen_p).prev_sample
+                ref = torch.from_numpy(g['x_' + tag][i])
+                assert float((xo - ref).abs().max()) < 5e-5, (tag, i)
+                assert float((xp - ref).abs().max()) < 5e-5, (tag, i)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 24))
+    sch = diffusion.DDPMScheduler()
+    with torch.no_grad():
+        y = sch.step(model(x, 0).sample, 0, x, generator=torch.Generator().manual_seed(5)).prev_sample
+    assert float((y - torch.from_numpy(g['x_t0'])).abs().max()) < 5e-5              # t = 0: no noise is added
+    pipe = diffusion.DDPMPipeline(model, diffusion.DDPMScheduler())
+    img = pipe(batch_size=2, generator=torch.Generator().manual_seed(9), num_inference_steps=6, output_type='numpy').images
+    assert img.shape == (2, 16, 16, 3) and float(np.abs(img - g['pipe6']).max()) < 2e-4
+
+
+def test_dropout_placement_and_masks_match_reference(mocked, monkeypatch):
+    """Training-mode forward/backward with dropout 0.1 on every nn.Dropout (utils.set_dropout): the oracle (Philox masks applied
+    at resnet.py:628 and attention_processor.py:457) and the product's engine on mocked kernels against the reference
+    UNet2DModel run with the same masks (tests/golden/tiny_dropout.json)."""
+    from oracle import diffusion_ref as D, philox_ref as PH
+    train = pkg('train')
+    fx = load_json('tiny_dropout.json')
+    cfg = gc.TINY_CFG
+    model = _cpu_model(cfg, 5)
+    train.set_dropout(model, fx['p'])
+    table = model.dropout_table()
+    assert len(table) == fx['sites'] and all(n.endswith('.dropout') or n.endswith('.to_out.1') for n in table)
+    clean = torch.from_numpy(gc.det_clean((4, 3, 16, 16), 3))
+    noise = torch.from_numpy(gc.det_noise((4, 3, 16, 16), 4))
+    t = torch.tensor([1, 250, 500, 998])
+    P = oracle_params(cfg, 5)
+    lo = D.finetune_loss(P, cfg, clean, noise, t, PH.DropSpec(table, fx['seed'], fx['step'], 0))
+    lo.backward()
+    assert abs(float(lo.detach()) - fx['loss']) <= 1e-5 * fx['loss']
+    for n, (s, a, q) in fx['grad_stats'].items():
+        gr = P[n].grad.double()
+        assert abs(float(gr.abs().sum()) - a) <= 2e-5 * a + 1e-8 * gr.numel(), n
+    # product engine (mocked kernels): same loss and gradients through FinetuneEngine's forward/backward
+    monkeypatch.setattr(train, '_require_hip_device', lambda dev: None)
+    sched = pkg('diffusion').DDPMScheduler()
+    monkeypatch.setattr(type(sched), '_acp_on', lambda self, dev: self.alphas_cumprod, raising=False)
+    ft = train.FinetuneEngine(model, sched, lr=0.0, dropout_seed=fx['seed'])
+    ft.step_count = fx['step'] - 1                                 # the engine draws the masks of step_count + 1
+    loss = ft.step(clean, noise, t)
+    assert abs(float(loss) - fx['loss']) <= 1e-5 * fx['loss']
+    for n, p in model.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-6:
+            assert relerr(p.grad, P[n].grad) < 5e-5, n
+    # eval mode: no dropout
+    model.eval()
+    assert pkg('unet').UNet2DModel.engine(model).dropout is None
+
+
+def test_oracle_long_sweep_prefix_matches_reference():
+    """First 40 of the 1000 recorded sweep steps (the full length runs on the GPU: test_long_sweep_1000_steps...)."""
+    from oracle import diffusion_ref as D
+    fx = load_json('tiny_long_sweep.json')
+    assert len(fx['losses']) == 1000
+    P = oracle_params(gc.TINY_CFG, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    losses = D.taylor_sweep(P, gc.TINY_CFG, clean, noise, 40)
+    assert np.allclose(losses, fx['losses'][:40], rtol=1e-5)
+
+
+def test_importance_accepts_torch_pruning_shaped_groups(mocked, monkeypatch):
+    """Boundary B1: TaylorImportance.__call__(group, ch_groups) fed with groups shaped like a real
+    torch_pruning DependencyGraph's -- (dep, idxs) pairs whose dep has .target.module (live nn layers with .weight.grad) and
+    .handler = a bound method of the tp pruner singletons -- returns the same scores as on the product's own groups."""
+    pruning, sweep, graph_mod = pkg('pruning'), pkg('sweep'), pkg('graph')
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    model = _cpu_model(gc.TINY_CFG, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=2)
+    fx = load_json('tiny_prune.json')
+    imp = pruning.TaylorImportance()
+    own = pruning.MagnitudePruner(model, None, importance=imp, iterative_steps=1, ch_sparsity=0.3, ignored_layers=[model.conv_out])
+    own_groups = {g[0][0].target.name: g for g in own.DG.get_all_groups(ignored_layers=own.ignored_layers)}
+    n = 0
+    for root, items in tp_like_groups(model, graph_mod):
+        s_tp = imp(items, ch_groups=1)
+        s_own = imp(own_groups[root], ch_groups=1)
+        assert s_tp is not None and torch.equal(s_tp, s_own), root
+        assert s_tp.numel() == len(items[0][1])
+        n += 1
+    assert n == len(fx['groups'])

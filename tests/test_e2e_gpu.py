@@ -509,3 +509,400 @@ def test_hipgraph_sweep_matches_eager(report):
     assert out[False][0] == out[True][0]
     assert torch.equal(out[False][1], out[True][1])
     report['e2e/hipgraph'] = dict(eager_s=out[False][2], graph_s=out[True][2], config='C1: CIFAR UNet B=4, 8 timesteps (incl. capture)')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2
+# ------------------------------------------------------------------------------------------------------------------
+def _mask_report(pr, refs, expand_ranges=False):
+    """(mismatching roots, worst score error, smallest decision margin) of a prune vs reference records."""
+    from oracle import pruning_ref as R
+    mism, worst, margin = [], 0.0, 1e9
+    assert len(pr.records) == len(refs)
+    for (root, chg, score, pruned), ref in zip(pr.records, refs):
+        assert root == ref['root'] and chg == ref['ch_groups']
+        rs = ref['score'] if torch.is_tensor(ref['score']) else torch.from_numpy(gc.b64_to_f32(ref['score']))
+        worst = max(worst, relerr(score, rs))
+        want = gc.expand(ref['pruned']) if expand_ranges else ref['pruned']
+        margin = min(margin, R.decision_margin(rs, want, ref['cur'], ref['ch_groups']))
+        if pruned != want:
+            mism.append(root)
+    return mism, worst, margin
+
+
+def test_long_sweep_1000_steps_matches_reference(report):
+    """The accumulation length of config C2: 1000 backward passes accumulated into the gradients (SURVEY §7 names error growth
+    over exactly this as the risk to bit-exact masks), tiny UNet, vs a 1000-step run of the reference itself."""
+    fx = load_json('tiny_long_sweep.json')
+    model = make_model(gc.TINY_CFG, 5)
+    clean, noise = _inputs(2, 16)
+    res = _run_sweep(model, clean, noise, 1000)
+    assert res['steps'] == 1000
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], fx['losses']))
+    P = dict(model.named_parameters())
+    bad, worst_stat = [], 0.0
+    for n, (s, a, q) in fx['grad_stats'].items():
+        got = float(P[n].grad.double().abs().sum())
+        worst_stat = max(worst_stat, abs(got - a) / max(a, 1e-30))
+        if abs(got - a) > 5e-5 * a + 1e-8 * P[n].grad.numel():
+            bad.append((n, got, a))
+    pr = pkg('sweep').prune_model(model, 0.3)
+    mism, worst, margin = _mask_report(pr, fx['prune'])
+    report['e2e/long_sweep_1000'] = dict(loss_rel=e_loss, grad_abs_sum_rel_worst=worst_stat, n_bad_stats=len(bad),
+                                         score_rel_worst=worst, min_decision_margin=margin, mask_mismatches=mism,
+                                         groups=len(pr.records))
+    assert e_loss < 1e-5 and not bad, bad[:5]
+    assert not mism, mism                                   # bit-exact masks after 1000 accumulated steps
+    assert worst < 1e-4
+    assert sum(p.numel() for p in model.parameters()) == fx['params_after']
+
+
+def test_c1_200_step_sweep_masks_vs_oracle(report):
+    """C1-size model (CIFAR-10 UNet, 35.7 M parameters, B=4) over 200 accumulated timesteps against the oracle on the host
+    cores: losses, gradients, every prune mask; the smallest decision margin is reported next to the result."""
+    from oracle import diffusion_ref as D
+    graph = pkg('graph')
+    cfg, steps = gc.CIFAR_CFG, 200
+    model = make_model(cfg, 0)
+    clean, noise = _inputs(4, 32)
+    res = _run_sweep(model, clean, noise, steps)
+    P = oracle_params(cfg, 0)
+    ref = D.taylor_sweep(P, cfg, clean, noise, steps)
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], ref))
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-7:
+            worst = max(worst, relerr(p.grad, P[n].grad))
+    Pd = {n: p.detach() for n, p in P.items()}
+    Gd = {n: p.grad for n, p in P.items()}
+    recs = oracle_prune_replay(Pd, Gd, cfg, 0.3, graph)
+    pr = pkg('sweep').prune_model(model, 0.3)
+    mism, worst_score, margin = _mask_report(pr, recs)
+    report['e2e/c1_200_steps'] = dict(loss_rel=e_loss, grad_rel_worst=worst, score_rel_worst=worst_score,
+                                      min_decision_margin=margin, mask_mismatches=mism, groups=len(recs))
+    assert e_loss < 1e-5 and worst < 5e-5
+    assert not mism, mism
+    assert sum(p.numel() for p in model.parameters()) == sum(p.numel() for p in Pd.values())
+
+
+def test_c3_bedroom256_full_size(report):
+    """BASELINE.json configs[2] at its real size: google/ddpm-ema-bedroom-256 topology (113.7 M parameters), 256x256 images,
+    4 images per GPU (batch 32 over 8 GPUs), Diff-Pruning threshold 0.05:
+      (a) run-to-run bit-identity of the sweep (split GroupNorm, workgroup-per-plane row sums, wgrad stream),
+      (b) two 2-image shards scaled for the global batch sum to the 4-image gradients; (c) same masks from the summed shards,
+      (d) micro-batched (2 + 2) == un-batched on the GPU, same early-exit step,
+      (e) one-image steps against the oracle on the host cores, including the early-exit decision."""
+    import copy
+    from oracle import diffusion_ref as D
+    sweep, diffusion = pkg('sweep'), pkg('diffusion')
+    cfg = gc.BEDROOM_CFG
+    B, H, steps = 4, 256, 2
+    model = make_model(cfg, 0)
+    assert sum(p.numel() for p in model.parameters()) == 113673219
+    clean, noise = _inputs(B, H, 11, 12)
+    clean, noise = clean.to(DEV), noise.to(DEV)
+    sched = diffusion.DDPMScheduler()
+    per = clean[0].numel()
+
+    def run(lo, hi, thr=0.05, micro=None, n_steps=steps, global_b=B):
+        flat = sweep.flatten_grads(model)
+        step = sweep.HipSweepStep(model, sched, clean[lo:hi], noise[lo:hi], global_b * per, 'mse', global_b)
+        step.micro = micro
+        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, thr=thr, step_fn=step,
+                                 flat_grads=flat)
+        torch.cuda.synchronize()
+        return flat, res
+
+    g_full, r_full = run(0, B)
+    g_again, r_again = run(0, B)
+    assert r_full['steps'] == steps                                                    # 0.05 does not trigger in 2 steps
+    assert torch.equal(g_full, g_again) and r_full['losses'] == r_again['losses']      # (a)
+    del g_again
+    g_micro, r_micro = run(0, B, micro=2)                                              # (d)
+    e_micro = relerr(g_micro, g_full)
+    assert r_micro['steps'] == r_full['steps'] and np.allclose(r_micro['losses'], r_full['losses'], rtol=1e-6)
+    del g_micro
+    g1, r1 = run(0, B // 2)
+    g2, r2 = run(B // 2, B)                                                            # model.grad now views g2
+    e_loss = max(abs((a + b) - c) / c for a, b, c in zip(r1['losses'], r2['losses'], r_full['losses']))
+    e_shard = relerr(g1 + g2, g_full)
+    g2.add_(g1)                                                                        # what the all-reduce leaves
+    del g1
+    m_full = copy.deepcopy(model)
+    flat_f = sweep.flatten_grads(m_full)
+    flat_f.copy_(g_full)
+    pr_sum = sweep.prune_model(model, 0.3)
+    pr_full = sweep.prune_model(m_full, 0.3)
+    mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
+    params_after = sum(p.numel() for p in model.parameters())
+    del m_full, flat_f, g_full, g2, pr_sum, pr_full
+    torch.cuda.empty_cache()
+    # (e) one image against the oracle, with a threshold that can trigger within the 3 steps run
+    model1 = make_model(cfg, 0)
+    c1, n1 = _inputs(1, H, 11, 12)
+    thr_e = 0.9995
+    res1 = sweep.taylor_sweep(model1, sched, c1.to(DEV), n1.to(DEV), num_steps=3, thr=thr_e)
+    P = oracle_params(cfg, 0)
+    ref = D.taylor_sweep(P, cfg, c1, n1, 3, thr=thr_e)
+    e_l1 = max(abs(a - b) / b for a, b in zip(res1['losses'], ref))
+    worst = 0.0
+    for n, p in model1.named_parameters():
+        if float(P[n].grad.abs().max()) > 1e-7:
+            worst = max(worst, relerr(p.grad, P[n].grad))
+    report['e2e/c3_bedroom256'] = dict(micro_vs_full_grad_rel=e_micro, shard_loss_rel=e_loss, shard_grad_rel=e_shard,
+                                       mask_mismatches=mism, groups=71, params_after=params_after,
+                                       b1_steps=res1['steps'], b1_ref_steps=len(ref), b1_loss_rel=e_l1, b1_grad_rel_worst=worst,
+                                       losses=r_full['losses'])
+    assert e_micro < 1e-5 and e_loss < 1e-5 and e_shard < 2e-5                         # fp32 re-association only
+    assert not mism                                                                    # (c)
+    assert res1['steps'] == len(ref) and e_l1 < 1e-5 and worst < 2e-5                  # (e)
+
+
+def test_multi_head_unet_matches_reference(report):
+    """attention_head_dim 8 (4 / 6 / 8 heads: head_to_batch_dim, attention_processor.py:283-305) on the HIP engine against the
+    reference UNet2DModel: forward, sweep losses, gradient statistics; then Taylor masks with head-grouped q/k/v selection
+    (ldm_prune.py:73-79) against the oracle's prune of the same gradients."""
+    from oracle import diffusion_ref as D
+    graph, pruning, unet = pkg('graph'), pkg('pruning'), pkg('unet')
+    cfg = load_json('groups_more.json')['heads8_4lvl']['cfg']
+    fx, g = load_json('tiny_heads.json'), load_npz('tiny_heads.npz')
+    model = make_model(cfg, 4)
+    assert model._multi_head
+    sched = pkg('diffusion').DDPMScheduler()
+    clean, noise = _inputs(2, 16, 81, 82)
+    t = torch.tensor([5, 700], device=DEV)
+    with torch.no_grad():
+        y = model(sched.add_noise(clean.to(DEV), noise.to(DEV), t), t).sample
+    e_f = float((y.cpu() - torch.from_numpy(g['fwd_out'])).abs().max())
+    res = _run_sweep(model, clean, noise, 2)
+    e_loss = max(abs(a - b) / b for a, b in zip(res['losses'], g['losses']))
+    Pm = dict(model.named_parameters())
+    bad = []
+    for n, (s, a, q) in fx['grad_stats'].items():
+        got = float(Pm[n].grad.double().abs().sum())
+        if abs(got - a) > 5e-5 * a + 1e-8 * Pm[n].grad.numel():
+            bad.append((n, got, a))
+    # oracle gradients + its prune replay (vendored Taylor criterion, per-head channel groups on q/k/v)
+    P = oracle_params(cfg, 4)
+    D.taylor_sweep(P, cfg, clean, noise, 2)
+    worst = max(relerr(p.grad, P[n].grad) for n, p in model.named_parameters() if float(P[n].grad.abs().max()) > 1e-7)
+    channel_groups = {}
+    for m in model.modules():
+        if isinstance(m, unet.Attention):
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    pr = pruning.MagnitudePruner(model, None, importance=pruning.TaylorImportance(), iterative_steps=1,
+                                 channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.conv_out])
+    for grp in pr.step(interactive=True):
+        grp.prune()
+    pruning.fix_static_attributes(model)
+    n_head_grouped = sum(1 for r in pr.records if r[1] not in (1, cfg['norm_num_groups']))
+    # the pruned multi-head model still runs (inner width no longer equals heads * attention_head_dim)
+    with torch.no_grad():
+        y2 = model(sched.add_noise(clean.to(DEV), noise.to(DEV), t), t).sample
+    from oracle import unet_ref as U
+    Pp = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    with torch.no_grad():
+        yo = U.unet_forward(Pp, cfg, D.add_noise(D.alphas_cumprod(), clean, noise, t.cpu()), t.cpu())
+    e_after = float((y2.cpu() - yo).abs().max())
+    report['e2e/multi_head'] = dict(fwd_abs=e_f, loss_rel=e_loss, n_bad_stats=len(bad), grad_rel_worst=worst,
+                                    groups=len(pr.records), head_grouped_groups=n_head_grouped, fwd_after_prune_abs=e_after)
+    assert e_f < 1e-5 and e_loss < 1e-5 and not bad and worst < 2e-5, bad[:3]
+    assert n_head_grouped > 0 and e_after < 1e-5
+
+
+def test_checkpoint_roundtrip_runs_on_the_hip_path(report, tmp_path):
+    """SURVEY §8(f) rank 1 on the GPU: a Diffusers directory written by the reference loads and its HIP forward equals the
+    recorded reference output; a pruned model saved with save_pruned / torch.save(model) and loaded back gives the identical
+    HIP output (ddpm_prune.py:131-135 -> ddpm_train.py:289-300 / ddpm_sample.py:25-33)."""
+    import os
+    ckpt, diffusion, sweep = pkg('checkpoint'), pkg('diffusion'), pkg('sweep')
+    from helpers import GOLD
+    src = os.path.join(GOLD, 'pretrained_micro')
+    pipe = diffusion.DDPMPipeline.from_pretrained(src).to(DEV)
+    x = torch.from_numpy(gc.det_noise((1, 3, 8, 8), 72)).to(DEV)
+    with torch.no_grad():
+        y = pipe.unet(x, torch.tensor([10], device=DEV)).sample
+    want = np.load(os.path.join(src, 'expected.npz'))['fwd_out']
+    e_load = float((y.cpu() - torch.from_numpy(want)).abs().max())
+    # prune the tiny UNet, save three ways, load, compare HIP outputs bit for bit
+    model = make_model(gc.TINY_CFG, 5)
+    clean, noise = _inputs(2, 16)
+    _run_sweep(model, clean, noise, 2)
+    pr = sweep.prune_model(model, 0.3)
+    t = torch.tensor([3, 500], device=DEV)
+    xin = clean.to(DEV)
+    with torch.no_grad():
+        y0 = model(xin, t).sample
+    d = str(tmp_path / 'pruned')
+    ckpt.save_pruned(model, d, pr.pruning_history())
+    back = ckpt.load_pruned(d).to(DEV).eval()
+    with torch.no_grad():
+        y1 = back(xin, t).sample
+    torch.save(model, str(tmp_path / 'unet_pruned.pth'))
+    whole = torch.load(str(tmp_path / 'unet_pruned.pth'), weights_only=False).to(DEV).eval()
+    with torch.no_grad():
+        y2 = whole(xin, t).sample
+    report['e2e/checkpoint_gpu'] = dict(pretrained_fwd_abs=e_load, pruned_params=sum(p.numel() for p in back.parameters()))
+    assert e_load < 1e-5
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+
+
+def test_in_place_weight_swap_is_seen_by_the_engine(report):
+    """EMAModel.copy_to / restore write weights through `param.data.copy_` (training_utils.py:231,286; used at
+    ddpm_train.py:387-401), which bumps no version counter: the packed conv operands must not survive it."""
+    from oracle import unet_ref as U
+    cfg = gc.TINY_CFG
+    model = make_model(cfg, 5)
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 3)).to(DEV)
+    t = torch.tensor([7, 300], device=DEV)
+    with torch.no_grad():
+        y_a = model(x, t).sample.clone()
+    new = {n: torch.from_numpy(gc.det_param(n, tuple(p.shape), 6)) for n, p in model.named_parameters()}
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.data.copy_(new[n].to(DEV))                    # the EMAModel.copy_to write pattern
+        y_b = model(x, t).sample
+        yo = U.unet_forward(new, cfg, x.cpu(), t.cpu())
+    e = float((y_b.cpu() - yo).abs().max())
+    # pinned: the caller promises frozen weights, the packs are kept (and a write inside the block is the caller's bug)
+    with model.pin_weights():
+        with torch.no_grad():
+            y_c = model(x, t).sample
+    report['e2e/ema_swap'] = dict(fwd_abs_after_swap=e, changed=float((y_b - y_a).abs().max()))
+    assert e < 1e-5 and torch.equal(y_b, y_c) and float((y_b - y_a).abs().max()) > 1e-3
+
+
+def test_ddpm_sampling_matches_reference(report):
+    """DDPMScheduler.step + DDPMPipeline (scheduling_ddpm.py:312-406, pipeline_ddpm.py:24-105) on the HIP engine against
+    sequences recorded from the reference (variance noise from the same seeded CPU generator)."""
+    g = load_npz('ddpm.npz')
+    diffusion = pkg('diffusion')
+    model = make_model(gc.TINY_CFG, 5)
+    errs = {}
+    for tag, n_inf, vt in (('full', 1000, 'fixed_small'), ('s50', 50, 'fixed_small'), ('large', 50, 'fixed_large')):
+        sch = diffusion.DDPMScheduler(variance_type=vt)
+        sch.set_timesteps(n_inf)
+        gen = torch.Generator().manual_seed(123)
+        x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 23)).to(DEV)
+        worst = 0.0
+        with torch.no_grad():
+            for i, t in enumerate(sch.timesteps[:4]):
+                x = sch.step(model(x, t).sample, t, x, generator=gen).prev_sample
+                worst = max(worst, float((x.cpu() - torch.from_numpy(g['x_' + tag][i])).abs().max()))
+        errs[tag] = worst
+    pipe = diffusion.DDPMPipeline(model, diffusion.DDPMScheduler())
+    img = pipe(batch_size=2, generator=torch.Generator().manual_seed(9), num_inference_steps=6, output_type='numpy').images
+    errs['pipe6_image'] = float(np.abs(img - g['pipe6']).max())
+    report['e2e/ddpm'] = errs
+    assert max(errs['full'], errs['s50'], errs['large']) < 5e-5 and errs['pipe6_image'] < 2e-4
+
+
+def test_dropout_finetune_forward_backward_matches_reference(report):
+    """Training-mode loss and gradients with dropout 0.1 on every nn.Dropout (utils.set_dropout) against the reference
+    UNet2DModel run with the same (Philox) masks -- tests/golden/tiny_dropout.json -- through FinetuneEngine's step with
+    lr 0 (weights untouched), and through the one-node autograd bridge (`loss.backward()`)."""
+    train, diffusion = pkg('train'), pkg('diffusion')
+    fx = load_json('tiny_dropout.json')
+    cfg = gc.TINY_CFG
+    model = make_model(cfg, 5)
+    sched = diffusion.DDPMScheduler()
+    ft = train.FinetuneEngine(model, sched, lr=0.0, dropout=fx['p'], dropout_seed=fx['seed'], use_ema=False)
+    assert len(model.dropout_table()) == fx['sites']
+    ft.step_count = fx['step'] - 1
+    clean, noise = _inputs(4, 16, 3, 4)
+    t = torch.tensor([1, 250, 500, 998])
+    loss = ft.step(clean.to(DEV), noise.to(DEV), t)
+    e_l = abs(float(loss) - fx['loss']) / fx['loss']
+    bad, worst = [], 0.0
+    for n, p in model.named_parameters():
+        s, a, q = fx['grad_stats'][n]
+        got = float(p.grad.double().abs().sum())
+        worst = max(worst, abs(got - a) / max(a, 1e-30))
+        if abs(got - a) > 5e-5 * a + 1e-8 * p.grad.numel():
+            bad.append((n, got, a))
+    # autograd bridge in train mode: same masks when seed / step agree
+    model2 = make_model(cfg, 5)
+    train.set_dropout(model2, fx['p'])
+    model2.train()
+    model2.dropout_seed, model2._dropout_step = fx['seed'], fx['step'] - 1
+    noisy = sched.add_noise(clean.to(DEV), noise.to(DEV), t.to(DEV))
+    out = model2(noisy, t.to(DEV)).sample
+    e_out = float((out.detach().cpu() - torch.from_numpy(gc.b64_to_f32(fx['fwd_out']))).abs().max())
+    l2 = (noise.to(DEV) - out).square().sum(dim=(1, 2, 3)).mean(dim=0)
+    l2.backward()
+    e_bridge = max(relerr(p2.grad, p.grad) for (n, p), (_, p2) in zip(model.named_parameters(), model2.named_parameters())
+                   if float(p.grad.abs().max()) > 1e-6)
+    report['e2e/dropout_tiny'] = dict(loss_rel=e_l, grad_abs_sum_rel_worst=worst, n_bad=len(bad), fwd_abs=e_out,
+                                      bridge_vs_engine_grad_rel=e_bridge)
+    assert e_l < 1e-5 and not bad and e_out < 1e-4 and e_bridge < 1e-6, bad[:3]
+
+
+def test_c4_pruned_cifar_finetune_with_dropout(report):
+    """BASELINE.json configs[3] as the reference runs it (scripts/finetune_ddpm_cifar10.sh): the ratio-0.3 PRUNED CIFAR-10 UNet
+    (19 851 157 parameters), batch 128 per GPU, dropout 0.1, lr 2e-4, EMA 0.9999, two optimizer steps: loss and raw
+    gradients against the oracle with the same masks (5e-5), clip + Adam + EMA on identical gradients (1e-5)."""
+    from oracle import diffusion_ref as D, philox_ref as PH
+    train, diffusion, sweep = pkg('train'), pkg('diffusion'), pkg('sweep')
+    cfg, B = gc.CIFAR_CFG, 128
+    model = make_model(cfg, 0)
+    clean, noise = _inputs(4, 32)
+    _run_sweep(model, clean, noise, 8)
+    sweep.prune_model(model, 0.3)
+    assert sum(p.numel() for p in model.parameters()) == 19851157
+    for p in model.parameters():
+        p.grad = None
+    sched = diffusion.DDPMScheduler()
+    P = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    names = list(P)
+    ft = train.FinetuneEngine(model, sched, dropout=0.1, dropout_seed=31, ema_decay=0.9999,
+                              lr_scheduler=train.get_scheduler('constant', 2e-4))
+    table = model.dropout_table()
+    m = [torch.zeros_like(P[n]) for n in names]
+    v = [torch.zeros_like(P[n]) for n in names]
+    ema = [P[n].detach().clone() for n in names]
+    gen = torch.Generator().manual_seed(17)
+    worst_g, e_loss = 0.0, 0.0
+    for step in (1, 2):
+        fc = torch.from_numpy(gc.det_clean((B, 3, 32, 32), 50 + step))
+        fn = torch.from_numpy(gc.det_noise((B, 3, 32, 32), 60 + step))
+        t = train.antithetic_timesteps(B, 1000, gen)
+        l_gpu = ft.step(fc.to(DEV), fn.to(DEV), t)
+        for n in names:
+            P[n].grad = None
+        l_cpu = D.finetune_loss(P, cfg, fc, fn, t, PH.DropSpec(table, 31, step, 0))
+        l_cpu.backward()
+        e_loss = max(e_loss, abs(float(l_gpu) - float(l_cpu.detach())) / float(l_cpu.detach()))
+        gpu_g = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+        for n in names:
+            if float(P[n].grad.abs().max()) > 1e-6:
+                worst_g = max(worst_g, relerr(gpu_g[n], P[n].grad))
+        with torch.no_grad():       # optimizer arithmetic on IDENTICAL gradients (see test_autograd_bridge_and_finetune_step)
+            D.adam_ema_step([P[n] for n in names], [gpu_g[n] for n in names], m, v, ema, step)
+    pm = dict(model.named_parameters())
+    e_p = max(relerr(pm[n], P[n].detach()) for n in names)
+    es = ft.ema_state()
+    e_e = max(relerr(es[n], e) for n, e in zip(names, ema))
+    report['e2e/c4_finetune_dropout'] = dict(loss_rel=e_loss, grad_rel_worst=worst_g, param_rel_after2=e_p, ema_rel_after2=e_e,
+                                             sites=len(table), lr=ft.last_lr)
+    assert e_loss < 1e-5 and worst_g < 5e-5
+    assert e_p < 1e-5 and e_e < 1e-5
+
+
+def test_importance_accepts_torch_pruning_shaped_groups_on_device(report):
+    """Boundary B1 on the GPU: groups shaped like a real torch_pruning DependencyGraph's (bound-method handlers of the tp pruner
+    singletons, live nn layers) give bit-identical scores to the product's own groups through the fused |w*g| kernels."""
+    from helpers import tp_like_groups
+    pruning, graph_mod = pkg('pruning'), pkg('graph')
+    model = make_model(gc.TINY_CFG, 5)
+    clean, noise = _inputs(2, 16)
+    _run_sweep(model, clean, noise, 2)
+    imp = pruning.TaylorImportance()
+    own = pruning.MagnitudePruner(model, None, importance=imp, iterative_steps=1, ch_sparsity=0.3, ignored_layers=[model.conv_out])
+    own_groups = {g[0][0].target.name: g for g in own.DG.get_all_groups(ignored_layers=own.ignored_layers)}
+    n = 0
+    for root, items in tp_like_groups(model, graph_mod):
+        s_tp, s_own = imp(items, ch_groups=1), imp(own_groups[root], ch_groups=1)
+        assert s_tp is not None and s_tp.is_cuda and torch.equal(s_tp, s_own), root
+        n += 1
+    report['e2e/tp_shaped_groups'] = n
+    assert n == 50

@@ -422,3 +422,79 @@ def test_layernorm_geglu_rowvec(ops, report, N, C, H):
     e_rv = relerr(ops.add_rowvec(x, v), x.double().cpu() + v.double().cpu()[:, :, None, None])
     report['ln/%d_%d_%d' % (N, C, H)] = dict(fwd=e_f, dx=e_dx, dgamma=e_g, dbeta=e_b, geglu=e_gf, geglu_bwd=e_gb, rowvec=e_rv)
     assert max(e_f, e_dx, e_g, e_b, e_gf, e_gb, e_rv) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: Philox dropout masks (bit-exact vs the numpy restatement), dropout fused into GroupNorm, DDPM update
+# ------------------------------------------------------------------------------------------------------------------
+def test_dropout_masks_bit_exact_vs_philox_oracle(ops, report):
+    """The device masks are the oracle's masks, element for element (integer parity): bare mask kernel over a window of
+    the stream crossing the 2^32-element boundary of the counter, and the strided apply kernel on a channel-slice view."""
+    from oracle import philox_ref as PH
+    n_bad = 0
+    for p, seed, site, step, idx0, n in ((0.1, 7, 'mid_block.resnets.0.dropout', 3, 0, 100003),
+                                         (0.5, (1 << 63) + 12345, 'x.to_out.1', 4000000000, (1 << 34) - 777, 4099),
+                                         (0.03, 0, 9, 0, 5, 1000)):
+        d = ops.dropout_desc(p, seed, site, step)
+        got = ops.dropout_mask(n, d, DEV, idx0).cpu().numpy()
+        want = PH.dropout_multipliers(n, p, seed, site, step, idx0)
+        n_bad += int((got != want).sum())
+    x = rnd(3, 10, 6, 6, seed=1)
+    view = x[:, 2:7]                                            # free image stride
+    d = ops.dropout_desc(0.25, 11, 'a.dropout', 2, n_off=5)
+    y = ops.dropout_apply(view, d)
+    m = PH.dropout_multipliers(view.numel(), 0.25, 11, 'a.dropout', 2, 5 * view[0].numel()).reshape(view.shape)
+    n_bad += int((y.cpu().numpy() != view.cpu().numpy() * m).sum())
+    ops.dropout_apply(view, d, out=view)                        # in place on the strided view; untouched channels intact
+    x2 = rnd(3, 10, 6, 6, seed=1)
+    assert torch.equal(x[:, :2], x2[:, :2]) and torch.equal(x[:, 7:], x2[:, 7:]) and torch.equal(x[:, 2:7], y)
+    report['dropout/mask_mismatches'] = n_bad
+    assert n_bad == 0
+
+
+@pytest.mark.parametrize('N,C1,C2,H,G', [(2, 32, 0, 8, 8), (3, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8),
+                                         (1, 128, 0, 128, 32), (2, 48, 80, 64, 16)], ids=str)
+def test_groupnorm_silu_dropout_fused(ops, report, N, C1, C2, H, G):
+    """y = dropout(silu(gn(x))) in one kernel and its backward (mask regenerated, nothing stored) against fp64 autograd with
+    the oracle's masks: vec4 / scalar / split (few large groups) variants, virtual concat, an image offset (rank shard)."""
+    from oracle import philox_ref as PH
+    xa = rnd(N, C1, H, H, seed=1) + 0.3
+    xb = rnd(N, C2, H, H, seed=2) if C2 else None
+    Cc = C1 + C2
+    gamma, beta, eps = 1 + 0.2 * rnd(Cc, seed=3), 0.1 * rnd(Cc, seed=4), 1e-6
+    n_off = 3
+    d = ops.dropout_desc(0.1, 99, 'r.dropout', 5, n_off=n_off)
+    y, stats = ops.groupnorm_fwd(xa, xb, gamma, beta, G, eps, True, drop=d)
+    m = torch.from_numpy(PH.dropout_multipliers(N * Cc * H * H, 0.1, 99, 'r.dropout', 5, n_off * Cc * H * H)).view(N, Cc, H, H).double()
+    xr = (xa if xb is None else torch.cat([xa, xb], 1)).double().cpu().requires_grad_(True)
+    gr = gamma.double().cpu().requires_grad_(True)
+    br = beta.double().cpu().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr, G, gr, br, eps)) * m
+    zeros_match = bool(((y.cpu() == 0) == (m == 0)).all())
+    e_f = relerr(y, yr.detach())
+    dz = rnd(*y.shape, seed=5)
+    yr.backward(dz.double().cpu())
+    add1 = rnd(*y.shape, seed=6)
+    dx, pws = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, True, add1=add1, drop=d)
+    e_dx = relerr(dx, xr.grad + add1.double().cpu())
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.colsum_accum(pws, N, Cc, 2, 1, dg, accumulate=False)
+    ops.colsum_accum(pws, N, Cc, 2, 0, db, accumulate=False)
+    e_g, e_b = relerr(dg, gr.grad), relerr(db, br.grad)
+    report['gn_dropout/%d_%d_%d_%d' % (N, C1, C2, H)] = dict(fwd=e_f, dx=e_dx, dgamma=e_g, dbeta=e_b, zeros_match=zeros_match)
+    assert zeros_match and max(e_f, e_dx, e_g, e_b) < 2e-5
+
+
+def test_ddpm_step_kernel(ops, report):
+    x, e, vn = rnd(2, 3, 8, 8, seed=14), rnd(2, 3, 8, 8, seed=15), rnd(2, 3, 8, 8, seed=16)
+    sa, sb, c0, c1, sig = 0.61, 0.79, 0.013, 0.985, 0.07
+    o = ops.ddpm_step(x, e, sa, sb, c0, c1, sig, vn, clip=True, clip_range=0.8)
+    xd, ed, vd = x.double().cpu(), e.double().cpu(), vn.double().cpu()
+    ref = c0 * ((xd - sb * ed) / sa).clamp(-0.8, 0.8) + c1 * xd + sig * vd
+    o2 = ops.ddpm_step(x, e, sa, sb, c0, c1, clip=False)
+    ref2 = c0 * ((xd - sb * ed) / sa) + c1 * xd
+    o3 = ops.ddim_step(x, e, 0.37, 0.52, clip=True, clip_range=0.5)
+    x0 = ((xd - (1 - 0.37) ** 0.5 * ed) / 0.37 ** 0.5).clamp(-0.5, 0.5)
+    ref3 = 0.52 ** 0.5 * x0 + (1 - 0.52) ** 0.5 * ed
+    report['ddpm_step'] = dict(noise_clip=relerr(o, ref), plain=relerr(o2, ref2), ddim_clip_range=relerr(o3, ref3))
+    assert max(relerr(o, ref), relerr(o2, ref2), relerr(o3, ref3)) < 1e-5
