@@ -133,6 +133,7 @@ def main():
     if args.graph:
         step.capture()
         step(0)
+    step.finish()
     flat.zero_()
     lib = ops._lib()
     barrier()
@@ -143,6 +144,7 @@ def main():
         losses.append(step(k))
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (GPU runs asynchronously)
     launches_per_step = (lib.dp_launch_count() - launches0) / args.steps
+    step.finish()                                 # fold the second half-batch pipeline's gradients in (once per sweep)
     torch.cuda.synchronize()
     t_sweep = time.perf_counter() - t0
     t_allreduce = 0.0
@@ -170,7 +172,10 @@ def main():
         model2 = model2.to(dev).eval()
         sweep.flatten_grads(model2)
         step2 = sweep.HipSweepStep(model2, sched, clean, noise, world * B * clean[0].numel(), 'mse', world * B)
-        step2.eng.overlap_wgrad = False      # per-kernel durations: one kernel on the GPU at a time
+        step2.eng.overlap_wgrad = False      # per-kernel durations: one kernel on the GPU at a time, at the shapes of the
+        if step2._half is not None:          # timed region (half-batch kernels when two pipelines are used)
+            step2._half['serial'] = True
+            step2._half['eng'].overlap_wgrad = False
         step2(0)
         torch.cuda.synchronize()
         ops._prof = []
@@ -236,6 +241,7 @@ def main():
                        'host_enqueue_ms_per_step': t_enqueue / args.steps * 1e3,
                        'kernel_launches_per_step': launches_per_step, 'grad_allreduce_ms': t_allreduce * 1e3,
                        'wgrad_stream_overlap': bool(step.eng.overlap_wgrad), 'hipgraph': bool(args.graph),
+                       'half_batch_pipelines': 2 if step._half is not None else 1,
                        'pruned_groups': len(pr.records), 'params_after': n_params_after,
                        'loss_first_last': [loss_vals[0], loss_vals[-1]]},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -43,12 +43,17 @@ class NtGemmParams(C.Structure):
                 ('batched', C.c_int),
                 ('out', C.c_void_p), ('o_bs', LL), ('ldo', C.c_int), ('accumulate', C.c_int),
                 ('alpha', C.c_float), ('merge', C.c_int), ('ocs', LL),
-                ('o_tap_stride', LL), ('o_col_stride', C.c_int), ('_pad2', C.c_int), ('col_bias', C.c_void_p)]
+                ('o_tap_stride', LL), ('o_col_stride', C.c_int), ('xcd', C.c_int), ('col_bias', C.c_void_p)]
 
 
 class Dropout(C.Structure):
     _fields_ = [('thr24', C.c_uint), ('scale', C.c_float), ('seed', C.c_ulonglong), ('site', C.c_uint), ('step', C.c_uint),
                 ('n_off', LL)]
+
+
+class ColsumItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('wstride', C.c_int),
+                ('woff', C.c_int), ('accumulate', C.c_int), ('_pad', C.c_int)]
 
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL
@@ -70,6 +75,7 @@ SIGNATURES = {
     'dp_groupnorm_silu_bwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
                                     _vp, _ll, _vp, _i, _vp, _dr, _vp],
     'dp_colsum_accum': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    'dp_colsum_accum_batch': [C.POINTER(ColsumItem), _i, _vp],
     'dp_rowsum_nc': [_vp, _ll, _i, _i, _i, _vp, _vp],
     'dp_silu_fwd': [_vp, _vp, _ll, _vp],
     'dp_silu_bwd': [_vp, _vp, _vp, _ll, _i, _vp],
@@ -79,7 +85,9 @@ SIGNATURES = {
     'dp_softmax_bwd': [_vp, _vp, _vp, _ll, _i, _f, _vp],
     'dp_timestep_embedding': [_vp, _i, _i, _i, _f, _f, _vp, _vp],
     'dp_add_noise': [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
-    'dp_mse_fwd_bwd': [_vp, _vp, _ll, _f, _vp, _vp, _i, _vp],
+    'dp_mse_fwd_bwd': [_vp, _vp, _ll, _f, _vp, _vp, _i, _vp, _vp],
+    'dp_early_exit_update': [_vp, _f, _vp, _vp, _i, _vp],
+    'dp_zero_if_stopped': [_vp, _ll, _vp, _vp],
     'dp_sum_partials': [_vp, _i, _f, _vp, _vp],
     'dp_downsum2x2': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],
     'dp_wg_reduce': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],

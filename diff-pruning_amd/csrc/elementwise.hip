@@ -195,8 +195,13 @@ extern "C" int dp_add_noise(const float* x0, const float* noise, const float* ac
 // eps-loss: partial[blk] = sum (out-noise)^2 over a fixed contiguous slice, dout = gscale*(out-noise)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ noise, long long n,
-                                                  float gscale, float* __restrict__ dout, float* __restrict__ partial) {
+                                                  float gscale, float* __restrict__ dout, float* __restrict__ partial,
+                                                  const float* __restrict__ stop_state) {
     __shared__ float red[4];
+    // Diff-Pruning early exit kept on the device (dp_early_exit_update): once the sweep has stopped, later timesteps that the
+    // host had already enqueued get dOut = 0 -- every gradient of such a step is an exact zero and the += epilogues add
+    // nothing, so overshoot steps are exact no-ops and the host need not read the loss after every step.
+    if (stop_state && stop_state[1] != 0.f) gscale = 0.f;
     const long long per = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     long long hi = lo + per;
@@ -211,9 +216,43 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out,
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 extern "C" int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial,
-                              int nblocks, void* stream) {
+                              int nblocks, const float* stop_state, void* stream) {
     if (n <= 0 || nblocks <= 0) return (int)hipErrorInvalidValue;
-    DP_LAUNCH(mse_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, noise, n, gscale, dout, partial);
+    DP_LAUNCH(mse_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, noise, n, gscale, dout, partial, stop_state);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diff-Pruning early exit on the device (ddpm_prune.py:104-106 / ddpm_exp/prune.py:249-256), fp32 like the reference's
+// 0-d tensors:  if (loss > loss_max) loss_max = loss;  if (loss < loss_max * thr) stop.
+// state = [loss_max, stopped (0/1), executed steps]; the loss of executed step k is kept in losses[k].
+// ---------------------------------------------------------------------------------------------
+__global__ void early_exit_update_kernel(const float* __restrict__ loss, float thr, float* __restrict__ state,
+                                         float* __restrict__ losses, int max_steps) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || state[1] != 0.f) return;
+    const float l = loss[0];
+    const int k = (int)state[2];
+    if (k < max_steps) losses[k] = l;
+    state[2] = (float)(k + 1);
+    float mx = state[0];
+    if (l > mx) mx = l;
+    state[0] = mx;
+    if (l < __fmul_rn(mx, thr)) state[1] = 1.f;
+}
+extern "C" int dp_early_exit_update(const float* loss, float thr, float* state, float* losses, int max_steps, void* stream) {
+    DP_LAUNCH(early_exit_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, thr, state, losses, max_steps);
+    return DP_LAUNCH_CHECK();
+}
+
+// x *= (stopped ? 0 : 1): the ddpm_exp flavour tests the threshold BEFORE the backward pass, so dOut of the breaking step
+// itself has to be cancelled after the state update
+__global__ void scale_if_stopped_kernel(float* __restrict__ x, long long n, const float* __restrict__ state) {
+    if (state[1] == 0.f) return;
+    GS_LOOP(i, n) x[i] = 0.f;
+}
+extern "C" int dp_zero_if_stopped(float* x, long long n, const float* state, void* stream) {
+    if (n <= 0) return 0;
+    DP_LAUNCH(scale_if_stopped_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, state);
     return DP_LAUNCH_CHECK();
 }
 

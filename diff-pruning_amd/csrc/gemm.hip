@@ -1025,15 +1025,34 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (NW == 4) ? (wave >> 1) * 64 : wave * 32;
     const int wn0 = (NW == 4) ? (wave & 1) * 64 : 0;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int z = blockIdx.z;
+    // Workgroup -> (tile, tap, split).  Workgroup b is dispatched to XCD b % 8 and every XCD has its own L2: with the plain
+    // (x, y, z) order the gx*gy*ntaps workgroups that read ONE pixel range (one split) are spread over all 8 XCDs and each L2
+    // fetches its own copy of dy / x (FETCH_SIZE 2.5x the operands, profiles/round1_pmc_bench_traffic.json).  p.xcd: XCD
+    // x owns a contiguous run of the split-major order, so the workgroups of a split share one L2.  Bijective for any grid.
+    int bx = blockIdx.x, by = blockIdx.y, split, tap;
+    if (p.xcd) {
+        const int gxy = gridDim.x * gridDim.y;
+        const int per_split = gxy * p.ntaps;
+        const int nwg = per_split * p.splits;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, k = b >> 3;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        split = __builtin_amdgcn_readfirstlane(v / per_split);
+        const int rem = v - split * per_split;
+        tap = __builtin_amdgcn_readfirstlane(rem / gxy);
+        const int rem2 = rem - tap * gxy;
+        by = __builtin_amdgcn_readfirstlane(rem2 / (int)gridDim.x);
+        bx = rem2 - by * (int)gridDim.x;
+    } else {
+        split = blockIdx.z / p.ntaps;
+        tap = blockIdx.z - split * p.ntaps;
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
 
     const ConvGeom& g = p.g;
     const int HoWo = g.Ho * g.Wo;
     const int HsWs = g.Hs * g.Ws;
-    const int split = z / p.ntaps;
-    const int tap = z - split * p.ntaps;
     const int ky = tap / g.kw;
     const int kx = tap - ky * g.kw;
     const int p_begin = split * p.p_per_split;

@@ -647,6 +647,66 @@ extern "C" int dp_colsum_accum(const float* ws, int N, int C, int wstride, int w
     return DP_LAUNCH_CHECK();
 }
 
+// Many column sums in ONE launch: the bias / GroupNorm-parameter gradients of a whole backward pass (~215 sums per CIFAR step,
+// each a few microseconds of work behind a kernel boundary) are queued by the host and reduced together at the end of the
+// pass.  Same per-item arithmetic and summation order as colsum_kernel (bit-identical results).
+#define DP_COLSUM_BATCH 80
+struct ColsumBatch {
+    int n;
+    int blk_start[DP_COLSUM_BATCH + 1];
+    dp_colsum_item e[DP_COLSUM_BATCH];
+};
+
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumBatch b) {
+    __shared__ float part[4][64];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.blk_start[i + 1]) ++i;           // block-uniform scan over <= 80 entries
+    const dp_colsum_item& it = b.e[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - b.blk_start[i]) * 64 + lane;
+    const int N = it.N, C = it.C, wstride = it.wstride, woff = it.woff;
+    const float* __restrict__ ws = it.src;
+    float s = 0.f;
+    if (c < C) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int n = wave;
+        for (; n + 12 < N; n += 16) {
+            s0 += ws[((long long)n * C + c) * wstride + woff];
+            s1 += ws[((long long)(n + 4) * C + c) * wstride + woff];
+            s2 += ws[((long long)(n + 8) * C + c) * wstride + woff];
+            s3 += ws[((long long)(n + 12) * C + c) * wstride + woff];
+        }
+        for (; n < N; n += 4) s0 += ws[((long long)n * C + c) * wstride + woff];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        it.dst[c] = it.accumulate ? it.dst[c] + t : t;
+    }
+}
+
+extern "C" int dp_colsum_accum_batch(const dp_colsum_item* items, int n, void* stream) {
+    for (int lo = 0; lo < n; lo += DP_COLSUM_BATCH) {
+        ColsumBatch b;
+        b.n = 0;
+        int blocks = 0;
+        for (int i = lo; i < n && b.n < DP_COLSUM_BATCH; ++i) {
+            if (items[i].C <= 0) continue;
+            b.blk_start[b.n] = blocks;
+            b.e[b.n] = items[i];
+            blocks += (items[i].C + 63) / 64;
+            ++b.n;
+        }
+        b.blk_start[b.n] = blocks;
+        if (!b.n) continue;
+        DP_LAUNCH(colsum_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return DP_LAUNCH_CHECK();
+}
+
 // rows[n*C + c] = sum_hw x[n*img_stride + c*HW + hw].  One wavefront per (n,c) plane for small planes, one workgroup per
 // plane from 4096 pixels on (256x256 feature maps: 65536 pixels per plane would be 1024 dependent adds per lane);
 // 16-byte loads and 4 independent partial sums per lane when the planes are aligned.  Fixed summation order.

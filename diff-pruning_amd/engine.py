@@ -115,6 +115,9 @@ class UNetEngine:
         # the backward regenerates them, nothing is stored (csrc/dp_common.h).
         self.dropout = None
         self.drop_seed, self.drop_step, self.drop_n_off = 0, 0, 0
+        # bias / GroupNorm-parameter gradient sums are queued during the backward pass and reduced together at its end
+        self.defer_colsum = not os.environ.get('DP_NO_COLSUM_BATCH')
+        self._cq = None
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -129,6 +132,23 @@ class UNetEngine:
         if not self.dropout:
             return None
         return ops.dropout_desc(self.dropout.get(site, 0.0), self.drop_seed, site, self.drop_step, self.drop_n_off)
+
+    def _colsum(self, ws, N, C, wstride, woff, out):
+        """out[c] += sum_n ws[(n*C + c)*wstride + woff] -- now, or with everything else at the end of backward()."""
+        if self._cq is not None:
+            self._cq.add(ws, N, C, wstride, woff, out, True)
+        else:
+            ops.colsum_accum(ws, N, C, wstride, woff, out, True)
+
+    def _begin_backward(self):
+        self._cq = ops.ColsumQueue() if (self.defer_colsum and hasattr(ops, 'ColsumQueue')) else None
+
+    def _end_backward(self):
+        """Join the weight-gradient stream, then flush the queued sums (their sources were produced on either stream)."""
+        self._join_side()
+        if self._cq is not None:
+            self._cq.flush()
+            self._cq = None
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
@@ -156,7 +176,7 @@ class UNetEngine:
         w = self.P[name + '.weight']
         ops.linear_wgrad(dy2d, x2d, self.G[name + '.weight'], accumulate=True)
         if (name + '.bias') in self.P:
-            ops.colsum_accum(dy2d, dy2d.shape[0], dy2d.shape[1], 1, 0, self.G[name + '.bias'], True)
+            self._colsum(dy2d, dy2d.shape[0], dy2d.shape[1], 1, 0, self.G[name + '.bias'])
         if not need_dx:
             return None
         return ops.linear_dgrad(dy2d, w, out=dx_out, accumulate=dx_accumulate)
@@ -190,7 +210,7 @@ class UNetEngine:
                     rows = ops.rowsum_nc(dy)
                 if alpha != 1.0:
                     rows = ops.axpby(rows, alpha, torch.empty_like(rows), 0.0)
-                ops.colsum_accum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'], True)
+                self._colsum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'])
 
         side = self._side_stream(dy, x, x2, rows)
         if side is None:
@@ -205,8 +225,8 @@ class UNetEngine:
 
     def _gn_param_grads(self, name, pws):
         N, C = pws.shape[0], pws.shape[1]
-        ops.colsum_accum(pws, N, C, 2, 1, self.G[name + '.weight'], True)
-        ops.colsum_accum(pws, N, C, 2, 0, self.G[name + '.bias'], True)
+        self._colsum(pws, N, C, 2, 1, self.G[name + '.weight'])
+        self._colsum(pws, N, C, 2, 0, self.G[name + '.bias'])
 
     # ---- ResnetBlock2D (resnet.py:589-639) -----------------------------------------------------
     def resnet_fwd(self, pre, xa, xb, semb, out_scale, save, names=RES_DIFFUSERS, G=None, eps=None):
@@ -397,6 +417,7 @@ class UNetEngine:
         nb = len(boc)
         G = cfg['norm_num_groups']
         sample, t_emb, h1, a1, emb, semb, xo, no, sto, n_skips = ctx.pop('_head')
+        self._begin_backward()
         d_semb = torch.zeros_like(semb)
         hw = tuple(xo.shape[2:])
         dno = self._conv_bwd('conv_out', dout, no, None, _SPEC3, hw)
@@ -461,6 +482,6 @@ class UNetEngine:
         d_a1 = self._linear_bwd('time_embedding.linear_2', d_emb, a1)
         d_h1 = ops.silu_bwd(h1, d_a1)
         self._linear_bwd('time_embedding.linear_1', d_h1, t_emb, need_dx=False)
-        self._join_side()
+        self._end_backward()
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

@@ -230,8 +230,8 @@ class LdmEngine(UNetEngine):
 
     def _ln_param_grads(self, name, pws):
         N, C = pws.shape[0], pws.shape[1]
-        ops.colsum_accum(pws, N, C, 2, 1, self.G[name + '.weight'], True)
-        ops.colsum_accum(pws, N, C, 2, 0, self.G[name + '.bias'], True)
+        self._colsum(pws, N, C, 2, 1, self.G[name + '.weight'])
+        self._colsum(pws, N, C, 2, 0, self.G[name + '.bias'])
 
     def st_bwd(self, pre, dout, extra=None):
         (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale) = self.ctx.pop(pre)
@@ -333,6 +333,7 @@ class LdmEngine(UNetEngine):
         assert ctx is not None
         inp, out, mid = ldm_blocks(cfg)
         x, t_emb, h1, a1, emb, semb, ho, no, sto = ctx.pop('_head')
+        self._begin_backward()
         d_semb = torch.zeros_like(semb)
         dno = self._conv_bwd('out.2', dout, no, None, _SPEC3, tuple(ho.shape[2:]))
         dx, pws = ops.groupnorm_bwd(ho, None, P['out.0.weight'], P['out.0.bias'], sto, dno, 32, True)
@@ -380,6 +381,6 @@ class LdmEngine(UNetEngine):
         d_a1 = self._linear_bwd('time_embed.2', d_emb, a1)
         d_h1 = ops.silu_bwd(h1, d_a1)
         self._linear_bwd('time_embed.0', d_h1, t_emb, need_dx=False)
-        self._join_side()
+        self._end_backward()
         assert not ctx, 'unconsumed context: %s' % list(ctx)
         self.ctx = None

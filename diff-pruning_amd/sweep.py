@@ -11,9 +11,12 @@ each rank scales its loss / gradient by 1/numel_global, the early-exit test uses
 all-reduce of the flat gradient buffer (RCCL over xGMI when the process group is 'nccl').  Importance is
 non-linear in the gradient, so scores are only ever computed from the reduced gradients.
 """
+import os
+
 import torch
 
 from . import ops
+from .engine import UNetEngine
 
 
 def flatten_grads(model):
@@ -36,8 +39,10 @@ class HipSweepStep:
     exceed the 2 GiB-per-tensor limit of the buffer descriptors (e.g. 256x256 images at batch >= 64 per GPU)."""
     _graph = None
     micro = None
+    _half = None
+    stop_state = None          # device [loss_max, stopped, steps] of the on-device Diff-Pruning early exit (taylor_sweep)
 
-    def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None):
+    def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None, halves=None):
         if clean.device.type != 'cuda':
             raise RuntimeError('the sweep runs on the MI355X HIP kernels only (no CPU fallback)')
         self.model, self.scheduler = model, scheduler
@@ -53,8 +58,47 @@ class HipSweepStep:
         self._G = {n: p.grad for n, p in model.named_parameters()}
         self.eng.bind(self._P, self._G)
         self.acp = scheduler._acp_on(clean.device)
+        # Two half-batch pipelines on two HIP streams (the gradient is linear in the images, exactly the property the
+        # multi-GPU path relies on): the second half runs through its own engine -- same parameters, own context, own weight-
+        # gradient stream -- into a SECOND flat gradient buffer that is added to the first once, in finish().  Every
+        # convolution of one half is a single round of workgroups with a memory-bound ramp and tail; two independent
+        # kernel streams fill each other's ramps and hide the HBM-bound GroupNorm / reduction kernels of one half under the
+        # MFMA kernels of the other.  Same kernels, fixed order: run-to-run bit-identical; vs. one pipeline the sums are
+        # re-associated like a 2-rank data-parallel run.
+        if halves is None:
+            halves = int(os.environ.get('DP_HALVES', '2' if self.B >= 32 and self.B % 2 == 0 else '1'))
+        if halves == 2 and self.B >= 2 and isinstance(self.eng, UNetEngine) and type(self.eng) is UNetEngine:
+            self._setup_second_half()
+
+    def _setup_second_half(self):
+        dev = self.clean.device
+        total = sum(g.numel() for g in self._G.values())
+        flat2 = torch.zeros(total, dtype=torch.float32, device=dev)
+        G2, off = {}, 0
+        for n, g in self._G.items():
+            G2[n] = flat2[off:off + g.numel()].view_as(g)
+            off += g.numel()
+        eng2 = UNetEngine(self.eng.cfg)
+        eng2.packs = self.eng.packs                       # frozen weights: one set of packed operands for both halves
+        eng2.bind(self._P, G2)
+        eng2.set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off + self.B // 2)
+        self.eng.bind(self._P, self._G)
+        self.eng.prepare_packs()                          # packed before the second stream's first read
+        self._half = dict(eng=eng2, G=G2, flat=flat2, stream=torch.cuda.Stream(device=dev), h=self.B // 2, serial=False)
+
+    def finish(self):
+        """Fold the second pipeline's gradients into the parameters' .grad buffers (once per sweep)."""
+        if self._half is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._half['stream'])
+            for n, g in self._G.items():
+                g2 = self._half['G'][n]
+                ops.axpby(g2.reshape(-1), 1.0, g.reshape(-1), 1.0)
+            self._half['flat'].zero_()
 
     def _step(self, t):
+        if self._half is not None and self.micro is None:
+            return self._two_half_step(t)
         if self.micro is None or self.B <= self.micro:
             return self._micro_step(self.clean, self.noise, t)
         total = None
@@ -64,13 +108,31 @@ class HipSweepStep:
             total = l if total is None else ops.axpby(l, 1.0, total, 1.0)
         return total
 
+    def _two_half_step(self, t):
+        hf = self._half
+        h = hf['h']
+        cur = torch.cuda.current_stream()
+        s1 = cur if hf['serial'] else hf['stream']        # serial: both halves on one stream (per-kernel timing in bench.py)
+        s1.wait_stream(cur)
+        t.record_stream(s1)
+        la = self._micro_step(self.clean[:h], self.noise[:h], t[:h])
+        with torch.cuda.stream(s1):
+            eng = hf['eng']
+            noisy = ops.add_noise(self.clean[h:], self.noise[h:], self.acp, t[h:])
+            out = eng.forward(noisy, t[h:], save=True)
+            lb, dout = ops.mse_fwd_bwd(out, self.noise[h:], self.gscale, self.lscale, stop_state=self.stop_state)
+            eng.backward(dout)
+        cur.wait_stream(s1)
+        lb.record_stream(cur)
+        return ops.axpby(lb, 1.0, la, 1.0)
+
     def _micro_step(self, clean, noise, t):
         # any model(...) / model.engine() call between two sweep steps (a no-grad evaluation, the autograd bridge) re-binds
         # the engine without -- or with temporary -- gradient buffers: bind ours again
         self.eng.bind(self._P, self._G)
         noisy = ops.add_noise(clean, noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
-        loss, dout = ops.mse_fwd_bwd(out, noise, self.gscale, self.lscale)
+        loss, dout = ops.mse_fwd_bwd(out, noise, self.gscale, self.lscale, stop_state=self.stop_state)
         self.eng.backward(dout)
         return loss
 
@@ -83,10 +145,12 @@ class HipSweepStep:
         self.eng.bind(self._P, self._G)
         noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
         out = self.eng.forward(noisy, t, save=True)
-        loss, self._dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
+        loss, self._dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale, stop_state=self.stop_state)
         return loss
 
-    def backward_pending(self):
+    def backward_pending(self, cancel_if_stopped=False):
+        if cancel_if_stopped and self.stop_state is not None:
+            ops.zero_if_stopped(self._dout, self.stop_state)      # the breaking step itself contributes no gradient
         self.eng.backward(self._dout)
         self._dout = None
 
@@ -116,9 +180,15 @@ class HipSweepStep:
         return self._step(t)          # [1] device tensor: this rank's share of L_t
 
 
+def _f32_lt_prod(loss, loss_max, thr):
+    """`loss < loss_max * thr` as the reference evaluates it: 0-d fp32 tensors, the product rounded to fp32."""
+    import numpy as np
+    return bool(np.float32(loss) < np.float32(loss_max) * np.float32(thr))
+
+
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
                  step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False, micro_batch=None,
-                 accumulate_breaking_step=True):
+                 accumulate_breaking_step=True, device_exit=True, poll_every=8):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
 
     thr=None: plain Taylor.  thr=x: Diff-Pruning early exit.  accumulate_breaking_step=True is ddpm_prune.py:102-106
@@ -127,7 +197,9 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
 
     clean_images / noise: this rank's shard.  `group`: torch.distributed process group (None = default group if
     torch.distributed is initialised, single process otherwise).  `step_fn(k) -> local loss tensor` lets the
-    multi-process CPU tests drive the same control flow with a different per-step engine."""
+    multi-process CPU tests drive the same control flow with a different per-step engine.
+    device_exit / poll_every: keep the Diff-Pruning early-exit state on the device and read the stop flag every
+    `poll_every` timesteps (False: read the loss on the host after every step, as the reference does)."""
     import torch.distributed as dist
     use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     B_local = clean_images.shape[0]
@@ -152,7 +224,32 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     two_phase = thr is not None and not accumulate_breaking_step
     if two_phase and use_graph:
         raise ValueError('use_graph replays forward + backward as one unit: not available with accumulate_breaking_step=False')
-    for k in range(num_steps):
+    on_device = (thr is not None and device_exit and not use_graph and isinstance(step_fn, HipSweepStep)
+                 and hasattr(ops, 'early_exit_update') and clean_images.device.type == 'cuda')
+    if on_device:
+        # The early-exit state lives on the device: no host read of the loss per step.  Timesteps enqueued after the stop are
+        # exact no-ops (dOut = 0), the host looks at the flag every `poll_every` steps, and the scalar-loss all-reduce of the
+        # data-parallel path is stream-ordered (RCCL), so nothing blocks the host between polls.
+        dev = clean_images.device
+        state = torch.zeros(3, dtype=torch.float32, device=dev)
+        losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=dev)
+        step_fn.stop_state = state
+        k = 0
+        while k < num_steps:
+            l = step_fn.forward_loss(k) if two_phase else step_fn(k)
+            if use_dist:
+                dist.all_reduce(l, group=group)
+            ops.early_exit_update(l, thr, state, losses_dev)
+            if two_phase:
+                step_fn.backward_pending(cancel_if_stopped=True)
+            k += 1
+            if k % poll_every == 0 or k == num_steps:
+                if float(state[1]) != 0.0:                  # one host sync per poll_every timesteps
+                    break
+        step_fn.stop_state = None
+        steps = int(float(state[2]))
+        losses = [float(v) for v in losses_dev[:steps].cpu()]
+    for k in range(0 if not on_device else num_steps, num_steps):
         if two_phase:
             l = step_fn.forward_loss(k)
             steps += 1
@@ -162,7 +259,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
             losses.append(lv)
             if lv > loss_max:
                 loss_max = lv
-            if lv < loss_max * thr:
+            if _f32_lt_prod(lv, loss_max, thr):
                 step_fn.discard_pending()
                 break
             step_fn.backward_pending()
@@ -176,10 +273,12 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
             losses.append(lv)
             if lv > loss_max:
                 loss_max = lv
-            if lv < loss_max * thr:
+            if _f32_lt_prod(lv, loss_max, thr):
                 break
         else:
             pending.append(l)
+    if hasattr(step_fn, 'finish'):
+        step_fn.finish()
     if pending:
         stacked = torch.cat([p.reshape(1) for p in pending])
         if use_dist:

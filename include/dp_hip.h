@@ -72,8 +72,9 @@ typedef struct dp_nt_gemm_params {
     float* out; long long o_bs; int ldo; int accumulate;
     float alpha; int merge;                /* merge: bit 0 = taps folded into the columns (NCOLS = C*ntaps), bit 1 = mirrored taps */
     long long ocs;                         /* merge: output element (row, c, tap) at row*ldo + c*ocs + tap */
-    long long o_tap_stride; int o_col_stride; int _pad2;   /* 0 = defaults (1, ntaps); (M*NCOLS, 1) with ldo = NCOLS gives
+    long long o_tap_stride; int o_col_stride; int xcd;       /* 0 = defaults (1, ntaps); (M*NCOLS, 1) with ldo = NCOLS gives
                                               tap-major partials [tap][m][c] whose stores are contiguous */
+    /* xcd != 0 (fast weight-gradient kernel only): XCD-aware workgroup order, the workgroups of one split share an L2 */
     const float* col_bias;                 /* optional [NCOLS]: added per output column by split 0 (nn.Linear bias), or NULL */
 } dp_nt_gemm_params;
 int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
@@ -145,6 +146,13 @@ int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int c_split, l
 /* out[c*ostride] (+)= sum_n ws[(n*C + c)*wstride + woff]   (deterministic, n ascending) */
 int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate, void* stream);
 
+/* The same for n independent items in one launch (per 80 items): dst[c] (+)= sum_n src[(n*C + c)*wstride + woff].  The host
+ * queues the bias / GroupNorm-parameter gradient sums of a whole backward pass and flushes them together. */
+typedef struct dp_colsum_item {
+    const float* src; float* dst; int N, C, wstride, woff, accumulate, _pad;
+} dp_colsum_item;
+int dp_colsum_accum_batch(const dp_colsum_item* items, int n, void* stream);
+
 /* rows[n*C + c] = sum_hw x[n*img_stride + c*HW + hw]  (bias / time-embedding-projection gradients) */
 int dp_rowsum_nc(const float* x, long long img_stride, int N, int C, int HW, float* rows, void* stream);
 
@@ -171,7 +179,15 @@ int dp_add_noise(const float* x0, const float* noise, const float* acp, const in
 /* loss partial sums + dOut for the eps-prediction loss.
  * dout = gscale * (out - noise);  partial[block] = sum (out-noise)^2 over the block's slice.
  * F.mse_loss (ddpm_prune.py:101): gscale = 2/numel;  sum-CHW/mean-B loss (ddpm_train.py:459): gscale = 2/B. */
-int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial, int nblocks, void* stream);
+int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gscale, float* dout, float* partial, int nblocks,
+                   const float* stop_state, void* stream);
+/* Diff-Pruning early exit kept on the device (ddpm_prune.py:104-106: `if loss > loss_max: loss_max = loss; if loss <
+ * loss_max * thr: break`, fp32 as the reference's 0-d tensors).  state = [loss_max, stopped, executed steps] (zero-initialised),
+ * losses[k] = loss of executed step k.  Once stopped, dp_mse_fwd_bwd(stop_state = state) produces dOut = 0, so timesteps the
+ * host enqueued past the stop are exact no-ops on the accumulated gradients; the host polls `stopped` every few steps.
+ * dp_zero_if_stopped cancels an already computed dOut (ddpm_exp flavour: threshold test before the backward pass). */
+int dp_early_exit_update(const float* loss, float thr, float* state, float* losses, int max_steps, void* stream);
+int dp_zero_if_stopped(float* x, long long n, const float* state, void* stream);
 /* dst[0] = scale * sum_i partial[i]  (single block, fixed order) */
 int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* stream);
 

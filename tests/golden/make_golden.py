@@ -18,6 +18,7 @@ Fixtures:
   cifar_groups.json G3 group table for the CIFAR-10 UNet (50 groups) and the bedroom-256 topology
   cifar_c1.npz/json G2/G4/G5 config C1: CIFAR UNet, B=4, 8 timesteps, Taylor, ratio 0.3
   tiny_long_sweep.json  1000-step sweep + prune of the tiny UNet (accumulation length of config C2)
+  cifar_long_sweep.json the same on the CIFAR-10 UNet at B=4 (~8 min of the reference on 8 CPU threads)
   lr_schedules.json     diffusers get_scheduler: lr per step for every schedule type
   ddpm.npz              DDPMScheduler.step sequences + a DDPMPipeline call
   tiny_dropout.json     finetune loss / gradients of the reference UNet in train mode with reproducible (Philox) masks
@@ -486,6 +487,27 @@ def do_long_sweep():
                    params_after=int(sum(p.numel() for p in model.parameters()))),
               open(os.path.join(HERE, 'tiny_long_sweep.json'), 'w'))
     print('long sweep ok: groups', len(rec), 'loss[0], loss[999]', losses[0], losses[-1])
+
+
+def do_c1_long():
+    """C2's accumulation length on the C1-size model: CIFAR-10 UNet (35.7 M parameters), B=4, plain Taylor over t = 0..999,
+    then the whole sequential prune at ratio 0.3 (scores + masks of all 50 groups)."""
+    cfg = gc.CIFAR_CFG
+    model = build_ref_unet(cfg, 0)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((4, 3, 32, 32), 1))
+    noise = torch.from_numpy(gc.det_noise((4, 3, 32, 32), 2))
+    t0 = time.time()
+    losses = sweep(model, sched, clean, noise, 1000)
+    print('C1-size 1000-step sweep %.1fs' % (time.time() - t0))
+    st = grad_stats(model)
+    rec = prune_run(model, 32, 0.3)
+    json.dump(dict(losses=losses, grad_stats=st,
+                   prune=[dict(root=r['root'], ch_groups=r['ch_groups'], cur=r['cur'], pruned=r['pruned'], score=r['score'])
+                          for r in rec],
+                   params_after=int(sum(p.numel() for p in model.parameters()))),
+              open(os.path.join(HERE, 'cifar_long_sweep.json'), 'w'))
+    print('c1 long ok: groups', len(rec), 'params', sum(p.numel() for p in model.parameters()))
 
 
 def do_lr():

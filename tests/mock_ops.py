@@ -252,7 +252,7 @@ def add_noise(x0, noise, acp, t, out=None):
     return (a ** 0.5)[:, None, None, None] * x0 + ((1 - a) ** 0.5)[:, None, None, None] * noise
 
 
-def mse_fwd_bwd(out, noise, gscale, loss_scale, want_grad=True):
+def mse_fwd_bwd(out, noise, gscale, loss_scale, want_grad=True, stop_state=None):
     d = out - noise
     return (loss_scale * d.square().sum()).reshape(1), (gscale * d if want_grad else None)
 

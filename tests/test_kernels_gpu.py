@@ -498,3 +498,48 @@ def test_ddpm_step_kernel(ops, report):
     ref3 = 0.52 ** 0.5 * x0 + (1 - 0.52) ** 0.5 * ed
     report['ddpm_step'] = dict(noise_clip=relerr(o, ref), plain=relerr(o2, ref2), ddim_clip_range=relerr(o3, ref3))
     assert max(relerr(o, ref), relerr(o2, ref2), relerr(o3, ref3)) < 1e-5
+
+
+def test_colsum_batch_equals_immediate(ops, report):
+    """Queued column sums (one launch per 80 items) are bit-identical to the immediate launches, accumulate included."""
+    q = ops.ColsumQueue()
+    want, got = [], []
+    for i, (N, C, ws, wo) in enumerate([(256, 256, 2, 1), (256, 256, 2, 0), (7, 90, 1, 0), (128, 513, 1, 0), (3, 64, 2, 1)] * 40):
+        src = rnd(N, C, ws, seed=100 + i)
+        a, b = rnd(C, seed=300 + i), None
+        b = a.clone()
+        ops.colsum_accum(src, N, C, ws, wo, a, True)
+        q.add(src, N, C, ws, wo, b, True)
+        want.append(a)
+        got.append(b)
+    q.flush()
+    assert not q.items
+    bad = sum(0 if torch.equal(a, b) else 1 for a, b in zip(want, got))
+    report['colsum_batch/items'] = dict(n=len(want), mismatching=bad)
+    assert bad == 0
+
+
+def test_wgrad_xcd_order_is_a_pure_relabelling(ops, report, monkeypatch):
+    """The XCD-aware workgroup order of the fast weight-gradient kernel only changes WHICH workgroup computes a (tile, tap,
+    split): results are bit-identical to the plain order, for grids whose size is / is not a multiple of 8 and two sources."""
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    bad = 0
+    for (N, C1, C2, Cout, H) in ((32, 256, 0, 256, 16), (16, 128, 128, 128, 32), (8, 90, 180, 180, 16), (24, 256, 0, 384, 8)):
+        x = rnd(N, C1, H, H, seed=1)
+        x2 = rnd(N, C2, H, H, seed=2) if C2 else None
+        dy = rnd(N, Cout, H, H, seed=3)
+        outs = []
+        for flag in ('1', None):
+            if flag:
+                monkeypatch.setenv('DP_NO_XCD', flag)
+            else:
+                monkeypatch.delenv('DP_NO_XCD')
+            gw = torch.zeros(Cout, C1 + C2, 3, 3, device=DEV)
+            ops.conv_wgrad(dy, x, x2, gw, spec, accumulate=False)
+            outs.append(gw)
+        bad += 0 if torch.equal(outs[0], outs[1]) else 1
+        ref = torch.nn.grad.conv2d_weight((x if x2 is None else torch.cat([x, x2], 1)).double().cpu(), (Cout, C1 + C2, 3, 3),
+                                          dy.double().cpu(), padding=1)
+        assert relerr(outs[1], ref) < 2e-5
+    report['wgrad_xcd/mismatching_shapes'] = bad
+    assert bad == 0
