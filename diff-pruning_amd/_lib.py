@@ -30,7 +30,7 @@ class ConvGemmParams(C.Structure):
                 ('alpha', C.c_float), ('post_scale', C.c_float),
                 ('bias', C.c_void_p), ('tadd', C.c_void_p), ('tadd_stride', LL),
                 ('res', C.c_void_p), ('r_img_stride', LL),
-                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p)]
+                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('x_guard', C.c_int), ('_pad1', C.c_int)]
 
 
 class NtGemmParams(C.Structure):

@@ -509,7 +509,14 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
 #define DP_FAST_MINBLOCKS 4
 #endif
 // TAILS = false: every chunk is 16 channels wide (C % 16 == 0, split % 16 == 0): the K-tile bookkeeping is one scalar compare.
-template <int BM, int BN, bool TAILS>
+// X4 (output rows a multiple of 4 pixels wide, at most one padding column per side): the B tile is fetched with TWO
+//   16-byte LDS-DMA loads per lane instead of eight 4-byte ones -- a lane owns 4 consecutive pixels of one channel row,
+//   32 lanes one 128-pixel row, a wave-instruction two rows (1 KB).  The loads are only 4-byte aligned for the shifted
+//   taps (legal for buffer loads; probed with tools/probe/lds_probe_x4.hip, range check per dword).  Vertical padding is
+//   still the per-lane out-of-range offset; a horizontal shift makes the one element that falls on the left / right
+//   image border read its neighbour row instead of zero: the owning lane overwrites it with 0.0f after its own
+//   vmcnt(0) and before the barrier (6 of 9 taps, two ds_write_b32 for 1/8 .. 1/2 of the lanes).
+template <int BM, int BN, bool TAILS, bool X4>
 __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
     // BM = 128: waves 2x2, each 64x64 as interleaved 32x32 sub-tiles (64 apart).  BM = 96 (pruned widths such as 90 or
     // 180 channels lose 30 % of a 128-row tile): waves 1x4, each all 96 rows x 32 columns.
@@ -599,15 +606,45 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
                 if (dp_gather(g, ho, wo, ky, t - ky * g.kw, off)) vmask |= 1u << t;
             }
     }
-    unsigned b_voff[8];
+    // X4: lane = (row of the wave's pair, pixel group): pixels n0 + 4*g4 .. +3 of channel rows 8*j + 2*wave + rsub
+    const int g4 = lane & 31, rsub = lane >> 5;
+    unsigned x_pix1 = 0, x_pix2 = 0, vrow = 0;
+    bool fix_l = false, fix_r = false;
+    if constexpr (X4) {
+        const int gp = n0 + 4 * g4;
+        const bool gv = gp < p.NPIX;
+        const int pp = gv ? gp : 0;
+        const int img = pp / HoWo;
+        const int r = pp - img * HoWo;
+        const int ho = r / g.Wo;
+        const int wo = r - ho * g.Wo;
+        const unsigned lin = (unsigned)(ho * g.Ws + wo + (2 * wave + rsub) * HsWs);
+        x_pix1 = (unsigned)((long long)img * g.x1_img_stride) + lin;
+        x_pix2 = (unsigned)((long long)img * g.x2_img_stride) + lin;
+        if (gv) {
+            const int kh = ntaps / g.kw;
+            for (int ky = 0; ky < kh; ++ky)
+                if ((unsigned)(ho + ky - g.pad_t) < (unsigned)g.Hs) vrow |= 1u << ky;
+            fix_l = g.pad_l == 1 && wo == 0;                                  // tap column 0 reads column -1
+            fix_r = wo + 3 + (g.kw - 1 - g.pad_l) >= g.Ws;                    // the last tap column reads column Ws
+        }
+    }
+    unsigned b_voff[X4 ? 2 : 8];
     // (re)build the per-lane offsets for a chunk of `cw` valid channels from source `first`: rows beyond cw are
     // permanently out of range (zeros), so the K loop itself carries no channel test.  Runs only when the source or the
     // width changes (at most 4 times per workgroup).
     auto set_chunk = [&](bool first, int cw) {
-        const unsigned b = first ? b_pix1 : b_pix2;
+        if constexpr (X4) {
+            const unsigned b = first ? x_pix1 : x_pix2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            b_voff[j] = (bk0 + 2 * j < cw) ? (b + (unsigned)(2 * j * HsWs)) * 4u + (IMM_MAX - 1024u * (j & 3)) : DP_OOB;
+            for (int j = 0; j < 2; ++j)
+                b_voff[j] = (8 * j + 2 * wave + rsub < cw) ? (b + (unsigned)(8 * j * HsWs)) * 4u + IMM_MAX : DP_OOB;
+        } else {
+            const unsigned b = first ? b_pix1 : b_pix2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                b_voff[j] = (bk0 + 2 * j < cw) ? (b + (unsigned)(2 * j * HsWs)) * 4u + (IMM_MAX - 1024u * (j & 3)) : DP_OOB;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) a_voff[j] = (a_k[j] < cw) ? a_base[j] : DP_OOB;
     };
@@ -618,7 +655,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     //  that takes them as its scalar offset gets wrapped in a waterfall loop)
     int ch = __builtin_amdgcn_readfirstlane(it0 / ntaps);
     int tap = it0 - ch * ntaps;
-    int kx;
+    int kx, kyc;
     bool first = ch < nch1;
     int cw = (ch < nch) ? chunk_width(ch) : BK;
     set_chunk(first, cw);
@@ -627,6 +664,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     unsigned a_soff, b_soff;
     auto chunk_offsets = [&]() {                                 // offsets of (ch, tap): full recompute (rare)
         const int ky = __builtin_amdgcn_readfirstlane(tap / g.kw);
+        kyc = ky;
         kx = tap - ky * g.kw;
         const int cbase = first ? ch * BK : C1 + (ch - nch1) * BK;       // first channel of the chunk in the concat order
         a_soff = (unsigned)(tap * C + cbase) * a_row_bytes;
@@ -647,21 +685,45 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
         }
-        const bool tv = (vmask >> tap) & 1u;
         const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
-        dp_static_for<0, 8>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            unsigned o = tv ? b_voff[j] : DP_OOB;
-            asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(Bs + 8 * (j >> 2) * BN), 4, (int)o, (int)b_soff,
-                                                     1024 * (j & 3), 0);
-        });
+        if constexpr (X4) {
+            const bool tv = (vrow >> kyc) & 1u;
+            float* B4 = smem + A_SZ + buf * STAGE + 2 * wave * BN;           // this wave's row pair of pass 0
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned o = tv ? b_voff[j] : DP_OOB;
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(B4 + 8 * j * BN), 16, (int)o, (int)b_soff, 0, 0);
+            }
+        } else {
+            const bool tv = (vmask >> tap) & 1u;
+            dp_static_for<0, 8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                unsigned o = tv ? b_voff[j] : DP_OOB;
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(Bs + 8 * (j >> 2) * BN), 4, (int)o, (int)b_soff,
+                                                         1024 * (j & 3), 0);
+            });
+        }
+    };
+    // X4: zero the border element of the tile that has just landed in `buf` (tap column state = the tile's)
+    const int kx_last = g.kw - 1, r_over = g.kw - 1 - g.pad_l;
+    auto fix_border = [&](int buf) {
+        if constexpr (X4) {
+            float* B4 = smem + A_SZ + buf * STAGE + 2 * wave * BN + 4 * lane;
+            if (kx == 0 && g.pad_l == 1) {
+                if (fix_l) { B4[0] = 0.f; B4[8 * BN] = 0.f; }
+            }
+            if (kx == kx_last && r_over == 1) {
+                if (fix_r) { B4[3] = 0.f; B4[8 * BN + 3] = 0.f; }
+            }
+        }
     };
     auto advance = [&]() {                                       // next K tile (chunk outer, tap inner)
         ++tap; ++kx;
         a_soff += a_tap_step;
         b_soff += 4u;
-        if (kx == g.kw) { kx = 0; b_soff += b_row_step; }
+        if (kx == g.kw) { kx = 0; ++kyc; b_soff += b_row_step; }
         if (tap == ntaps) {
             tap = 0; ++ch;
             if constexpr (!TAILS) {
@@ -690,6 +752,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     if (nIter > 0) {
         dma_tile(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fix_border(0);
         __syncthreads();
         for (int it = 0; it < nIter; ++it) {
             const int buf = it & 1;
@@ -725,6 +788,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fix_border(buf ^ 1);
             __syncthreads();
         }
     }
@@ -742,13 +806,29 @@ static bool conv_fast_tails(const dp_conv_gemm_params& p) {
     return (p.C % 16) != 0 || (p.X2 && (p.g.c_split % 16) != 0);
 }
 
+// 16-byte B-tile loads: 4 consecutive output pixels = 4 consecutive input columns of one row, <= 1 padding column per side
+static bool conv_fast_x4(const dp_conv_gemm_params& p) {
+    const dp_conv_geom& g = p.g;
+    if ((!p.x_guard && g.pad_l > 0) || getenv("DP_NO_X4") || g.kw < 1 || p.ntaps % g.kw) return false;
+    const int kh = p.ntaps / g.kw;
+    if (kh > 8) return false;
+    if (p.ntaps == 1 && g.pad_l == 0 && g.pad_t == 0 && g.Ws == g.Wo && g.Hs == g.Ho) return (g.Ho * g.Wo) % 4 == 0;
+    return g.Wo % 4 == 0 && g.Ws >= 4 && g.pad_l >= 0 && g.pad_l <= 1 && g.kw - 1 - g.pad_l >= 0 && g.kw - 1 - g.pad_l <= 1;
+}
+
+template <int BM, bool TAILS>
+static void launch_conv_fast(const dp_conv_gemm_params& p, dim3 grid, hipStream_t st) {
+    if (conv_fast_x4(p)) DP_LAUNCH((conv_gemm_fast_kernel<BM, 128, TAILS, true>), grid, dim3(256), dp_lds_pad(), st, p);
+    else                 DP_LAUNCH((conv_gemm_fast_kernel<BM, 128, TAILS, false>), grid, dim3(256), dp_lds_pad(), st, p);
+}
+
 template <int BM, int BN>
 static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     dim3 grid((p.NPIX + BN - 1) / BN, (p.M + BM - 1) / BM, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
     if constexpr (BM == 128 && BN == 128) {
         if (conv_fast_ok(p)) {
-            if (conv_fast_tails(p)) DP_LAUNCH((conv_gemm_fast_kernel<128, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
-            else                    DP_LAUNCH((conv_gemm_fast_kernel<128, 128, false>), grid, dim3(256), dp_lds_pad(), st, p);
+            if (conv_fast_tails(p)) launch_conv_fast<128, true>(p, grid, st);
+            else                    launch_conv_fast<128, false>(p, grid, st);
             return DP_LAUNCH_CHECK();
         }
     }
@@ -764,6 +844,21 @@ static int launch_conv_gemm(const dp_conv_gemm_params& p, hipStream_t st) {
     return DP_LAUNCH_CHECK();
 }
 
+// sum_z ws[z*stride] in ascending z (the fixed order that makes split-K deterministic).  The loads of 8 partials are issued
+// together and only the ADDS are ordered: one dependent memory latency per 8 splits instead of one per split (these kernels
+// were latency-, not bandwidth-bound: 13-60 us for a few MB).  Adding 0.0f for the missing tail entries changes nothing.
+__device__ __forceinline__ float dp_splitk_sum(const float* __restrict__ ws, long long stride, int splits) {
+    float a = 0.f;
+    for (int z = 0; z < splits; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (z + j < splits) ? ws[(long long)(z + j) * stride] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    return a;
+}
+
 // out = epilogue(sum_z ws[z][m][pix])  -- fixed summation order; same epilogue arithmetic as the fused path
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const dp_conv_gemm_params p) {
     const long long total = (long long)p.M * p.NPIX;
@@ -771,8 +866,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const dp_conv
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int m = (int)(i / p.NPIX);
         const int pix = (int)(i - (long long)m * p.NPIX);
-        float a = 0.f;
-        for (int z = 0; z < p.ksplit; ++z) a += p.ws[(long long)z * total + i];
+        const float a = dp_splitk_sum(p.ws + i, total, p.ksplit);
         const int img = pix / HoWo;
         const int r_in = pix - img * HoWo;
         float v = p.alpha * a;
@@ -798,7 +892,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         case 3:                                                  // 96x128: fast kernel only, else the 128x128 path
             if (conv_fast_ok(p)) {
                 dim3 grid((p.NPIX + 127) / 128, (p.M + 95) / 96, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
-                DP_LAUNCH((conv_gemm_fast_kernel<96, 128, true>), grid, dim3(256), dp_lds_pad(), st, p);
+                launch_conv_fast<96, true>(p, grid, st);
                 e = DP_LAUNCH_CHECK();
                 break;
             }
@@ -1252,8 +1346,7 @@ extern "C" int dp_nt_gemm(const dp_nt_gemm_params* pp, void* stream) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, long long stride, int splits,
                                                             float* __restrict__ out, long long n, int accumulate) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(long long)k * stride + i];
+        const float s = dp_splitk_sum(ws + i, stride, splits);
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -1264,8 +1357,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_taps_kernel(const float* __
                                                                  int accumulate) {
     const long long n = mc * ntaps;
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(long long)k * stride + j];
+        const float s = dp_splitk_sum(ws + j, stride, splits);
         const long long tap = j / mc;
         const long long o = (j - tap * mc) * ntaps + tap;
         out[o] = accumulate ? out[o] + s : s;

@@ -116,6 +116,23 @@ def _extent_bytes(x):
     return n
 
 
+ACT_GUARD = 4       # floats in front of every activation this module allocates (16 bytes: vector alignment is kept)
+
+
+def empty_act(shape, device):
+    """Activation buffer with ACT_GUARD readable floats in front of it: the 16-byte loads of the fast convolution kernel
+    read one element to the left of an image row (dp_conv_gemm_params.x_guard)."""
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.empty(n + ACT_GUARD, dtype=_f32, device=device)[ACT_GUARD:].view(shape)
+
+
+def _guarded(x):
+    """True when at least one float in front of x's first element belongs to the same allocation."""
+    return x is None or x.storage_offset() >= 1
+
+
 def as4d(x):
     """[B, C] -> [B, C, 1, 1] view (Linear layers use the conv kernels with H = W = 1)."""
     return x if x.dim() == 4 else x.view(x.shape[0], x.shape[1], 1, 1)
@@ -211,12 +228,13 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
     Cin = C1 + C2
     Ho, Wo = spec.out_hw(Hs, Ws)
     if out is None:
-        out = torch.empty((N, Cout, Ho, Wo), dtype=_f32, device=x.device)
+        out = empty_act((N, Cout, Ho, Wo), x.device)
     so = _chk_act(out)
     assert out.shape == (N, Cout, Ho, Wo)
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(wp), 0, ld, 0
     p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
+    p.x_guard = 1 if (_guarded(x) and _guarded(x2)) else 0
     p.a_bytes, p.x1_bytes, p.x2_bytes = wp.numel() * 4, _extent_bytes(x), _extent_bytes(x2)
     p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
                 C1 if x2 is not None else Cin, s1, s2)
@@ -244,12 +262,13 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     N, Cout, Ho, Wo = dy.shape
     Hv, Wv = in_hw
     if out is None:
-        out = torch.empty((N, Cin, Hv, Wv), dtype=_f32, device=dy.device)
+        out = empty_act((N, Cin, Hv, Wv), dy.device)
     so = _chk_act(out)
     assert out.shape == (N, Cin, Hv, Wv)
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(wd), 0, ldd, 0
     p.X1, p.X2, p.x_bs = _p(dy), None, 0
+    p.x_guard = 1 if _guarded(dy) else 0
     p.a_bytes, p.x1_bytes, p.x2_bytes = wd.numel() * 4, _extent_bytes(dy), 0
     # dX[h] = sum_ky' dY[(h + ky' - (k-1-pad)) / stride] Wflip[ky']
     padp = spec.k - 1 - spec.pad
@@ -268,6 +287,7 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
 
 _ws_cache = {}
 WGRAD_BLOCKS = 1024          # target workgroups per wgrad launch (256 CUs x 4 resident workgroups)
+WGRAD_MIN_PIX = int(os.environ.get('DP_WGRAD_MIN_PIX', '128'))      # fewest pixels per split-K slice of a weight gradient
 
 
 def _workspace(n, device):
@@ -313,7 +333,7 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
         if a96 < 0.9 * a128:
             tile, bm, bn = 3, 96, 96
     tiles = -(-Cout // bm) * -(-Cin // bn) * taps
-    splits = max(1, min(WGRAD_BLOCKS // tiles, P // 512 if P >= 1024 else 1))     # floor: never spill into a 2nd round
+    splits = max(1, min(WGRAD_BLOCKS // tiles, P // WGRAD_MIN_PIX if P >= 2 * WGRAD_MIN_PIX else 1))     # floor: never spill into a 2nd round
     if max_splits is not None:
         splits = max(1, min(splits, max_splits))
     pps = -(-P // splits)
@@ -367,7 +387,7 @@ def _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in):
         p.g = _geom(Hs, Ws, Ho, Wo, Ho, Wo, spec.k, 1, 1, spec.pad, spec.pad, 0, Cout, _chk_act(dy), 0)
         p.ldo, p.ocs, p.merge = taps, Cin * taps, 3
     tiles = -(-M // 64) * -(-(Cg * taps) // 64)
-    splits = max(1, min(WGRAD_BLOCKS // tiles, P // 512 if P >= 1024 else 1))
+    splits = max(1, min(WGRAD_BLOCKS // tiles, P // WGRAD_MIN_PIX if P >= 2 * WGRAD_MIN_PIX else 1))
     pps = (-(-P // splits) + 31) & ~31
     splits = -(-P // pps)
     p.A, p.a_bs, p.a_img_stride = _p(rows), 0, _chk_act(rows)
@@ -408,6 +428,7 @@ def bmm_tn(a, b, alpha=1.0, out=None, accumulate=False):
     p = L.ConvGemmParams()
     p.A, p.a_bs, p.lda, p.a_kc = _p(a), K * M, M, 0
     p.X1, p.X2, p.x_bs = _p(b), None, K * Nn
+    p.x_guard = 1                                    # one tap, no padding: nothing is read in front of b
     p.a_bytes, p.x1_bytes, p.x2_bytes = K * M * 4, K * Nn * 4, 0
     p.g = _bgeom(Nn, K)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
@@ -577,7 +598,7 @@ def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None, drop=None):
         C2 = x2.shape[1]
     Cc = C1 + C2
     if out is None:
-        out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
+        out = empty_act((N, Cc, H, W), x.device)
     stats = torch.empty((N * G, 2), dtype=_f32, device=x.device)
     so = _chk_act(out)
     sl = _gn_slices(N, G, H * W, (x, x2, out), (s1, s2, so))
@@ -604,7 +625,7 @@ def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=Non
         C2 = x2.shape[1]
     Cc = C1 + C2
     if out is None:
-        out = torch.empty((N, Cc, H, W), dtype=_f32, device=x.device)
+        out = empty_act((N, Cc, H, W), x.device)
     pws = torch.empty((N, Cc, 2), dtype=_f32, device=x.device)
     sd, so = _chk_act(dz), _chk_act(out)
     sa1 = _chk_act(add1) if add1 is not None else 0
@@ -721,7 +742,7 @@ def add_noise(x0, noise, acp, t_long, out=None):
     B = x0.shape[0]
     per = x0.numel() // B
     if out is None:
-        out = torch.empty_like(x0)
+        out = empty_act(tuple(x0.shape), x0.device)
     assert t_long.dtype == torch.int64 and x0.is_contiguous() and noise.is_contiguous()
     assert x0.dtype == _f32 and noise.dtype == _f32 and x0.is_cuda and noise.is_cuda and t_long.is_cuda and acp.is_cuda, \
         'add_noise takes fp32 device tensors (and an int64 device timestep vector)'
@@ -740,7 +761,7 @@ def mse_fwd_bwd(out, noise, gscale, loss_scale, want_grad=True, stop_state=None)
     assert out.is_contiguous() and noise.is_contiguous()
     assert out.dtype == _f32 and noise.dtype == _f32 and out.is_cuda and noise.is_cuda and noise.numel() == n, \
         'mse_fwd_bwd takes fp32 device tensors of equal size'
-    dout = torch.empty_like(out) if want_grad else None
+    dout = empty_act(tuple(out.shape), out.device) if want_grad else None
     partial = torch.empty(MSE_BLOCKS, dtype=_f32, device=out.device)
     loss = torch.empty(1, dtype=_f32, device=out.device)
     L.check(_lib().dp_mse_fwd_bwd(_p(out), _p(noise), n, gscale, _p(dout), _p(partial), MSE_BLOCKS, _p(stop_state), _stream()),
@@ -766,7 +787,7 @@ def downsum2x2(dy, out=None):
     N, Cc, H2, W2 = dy.shape
     H, W = H2 // 2, W2 // 2
     if out is None:
-        out = torch.empty((N, Cc, H, W), dtype=_f32, device=dy.device)
+        out = empty_act((N, Cc, H, W), dy.device)
     L.check(_lib().dp_downsum2x2(_p(dy), sd, N, Cc, H, W, _p(out), _chk_act(out), _stream()), 'dp_downsum2x2')
     return out
 

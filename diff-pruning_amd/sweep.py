@@ -65,8 +65,11 @@ class HipSweepStep:
         # kernel streams fill each other's ramps and hide the HBM-bound GroupNorm / reduction kernels of one half under the
         # MFMA kernels of the other.  Same kernels, fixed order: run-to-run bit-identical; vs. one pipeline the sums are
         # re-associated like a 2-rank data-parallel run.
+        # [measured, round 2, B=256 CIFAR] 92.9 ms/step with two pipelines vs 89.6 with one: the half-size launches
+        # (512 workgroups = two per CU) run at 107 instead of 122 TFLOP/s and the overlap does not buy that back, so the
+        # default stays ONE pipeline; `halves=2` / DP_HALVES=2 remains selectable (tested: same masks, bit-reproducible).
         if halves is None:
-            halves = int(os.environ.get('DP_HALVES', '2' if self.B >= 32 and self.B % 2 == 0 else '1'))
+            halves = int(os.environ.get('DP_HALVES', '1'))
         if halves == 2 and self.B >= 2 and isinstance(self.eng, UNetEngine) and type(self.eng) is UNetEngine:
             self._setup_second_half()
 

@@ -48,6 +48,10 @@ typedef struct dp_conv_gemm_params {
     const float* res; long long r_img_stride;
     int accumulate; int ksplit;            /* ksplit > 1: split the K loop over blockIdx.z, partials in ws (non-batched only) */
     float* ws;                             /* >= ksplit*M*NPIX floats when ksplit > 1 */
+    int x_guard; int _pad1;                /* 1: the 4 bytes in front of X1 (and X2) are readable memory.  The 16-byte B-tile
+                                              loads of the stride-1 fast kernel read one element to the left of an image
+                                              row for the shifted taps (overwritten with 0 in LDS); for the first row of the
+                                              tensor that element lies in front of it.  0 = use the 4-byte loads. */
 } dp_conv_gemm_params;
 int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
 

@@ -543,3 +543,49 @@ def test_wgrad_xcd_order_is_a_pure_relabelling(ops, report, monkeypatch):
         assert relerr(outs[1], ref) < 2e-5
     report['wgrad_xcd/mismatching_shapes'] = bad
     assert bad == 0
+
+
+def test_conv_fast_x4_loads_equal_dword_loads(ops, report, monkeypatch):
+    """The 16-byte B-tile loads of the fast convolution kernel (4 pixels per lane, border element zeroed in LDS) put exactly the
+    values of the 4-byte path into LDS: forward, dgrad and the attention products are bit-identical with and without them."""
+    bad = []
+
+    def guarded(t):                 # the 16-byte loads need one readable float in front of the tensor (x_guard)
+        g = ops.empty_act(tuple(t.shape), t.device)
+        g.copy_(t)
+        assert g.storage_offset() >= 1
+        return g
+
+    cases = [(4, 128, 0, 128, 32, 3), (3, 256, 0, 256, 16, 3), (5, 96, 160, 256, 8, 3), (9, 64, 0, 80, 4, 3), (2, 90, 180, 180, 16, 3),
+             (3, 128, 64, 96, 12, 1), (6, 256, 0, 256, 2, 1), (2, 37, 0, 70, 8, 3)]
+    for (N, C1, C2, Cout, H, k) in cases:
+        xa = guarded(rnd(N, C1, H, H, seed=1))
+        xb = guarded(rnd(N, C2, H, H, seed=2)) if C2 else None
+        w = rnd(Cout, C1 + C2, k, k, seed=3, scale=0.05)
+        b = rnd(Cout, seed=4)
+        dy = guarded(rnd(N, Cout, H, H, seed=5))
+        spec = ops.ConvSpec(k, 1, k // 2, 0)
+        wp, ld = ops.pack_weight(w, 0)
+        wd, ldd = ops.pack_weight(w, 1)
+        outs = []
+        for flag in ('1', None):
+            if flag:
+                monkeypatch.setenv('DP_NO_X4', flag)
+            else:
+                monkeypatch.delenv('DP_NO_X4')
+            y = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b)
+            d = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H))
+            outs.append((y, d))
+        if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+            bad.append((N, C1, C2, Cout, H, k))
+        ref = ref_conv(xa if xb is None else torch.cat([xa, xb], 1), w, b, 1, k // 2, 0, False)
+        assert relerr(outs[1][0], ref) < 2e-5
+    q, kk = rnd(4, 256, 256, seed=7), rnd(4, 256, 256, seed=8)
+    monkeypatch.setenv('DP_NO_X4', '1')
+    s0 = ops.bmm_tn(q, kk, alpha=0.0625)
+    monkeypatch.delenv('DP_NO_X4')
+    s1 = ops.bmm_tn(q, kk, alpha=0.0625)
+    if not torch.equal(s0, s1):
+        bad.append('bmm_tn')
+    report['conv_x4/mismatching'] = bad
+    assert not bad, bad

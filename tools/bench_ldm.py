@@ -19,7 +19,7 @@ for _ in range(5): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print('fwd+bwd B=6: %.1f ms  (%.1f TFLOP/s at 625 GFLOP/latent-step)  loss %.4f' % (dt * 1e3, 625e9 * B / dt / 1e12, float(l)))
 x2 = torch.randn(12, 3, 64, 64, device='cuda'); c2 = torch.randn(12, 1, 512, device='cuda'); t2 = torch.full((12,), 500, device='cuda')
-with torch.no_grad():
+with torch.no_grad(), m.pin_weights():          # a sampling loop: the weights are frozen, pack once
     for _ in range(2): m(x2, t2, context=c2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): m(x2, t2, context=c2)

@@ -33,7 +33,7 @@ print('finetune (C4) pruned CIFAR UNet B=%d: %.1f ms/step, %.0f images/s, %.1f T
 
 B = 256
 x = torch.randn(B, 3, 32, 32, device=dev); t = torch.full((B,), 500, device=dev, dtype=torch.long)
-with torch.no_grad():
+with torch.no_grad(), m.pin_weights():          # a sampling loop: the weights are frozen, pack once
     for _ in range(2): m(x, t)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): y = m(x, t).sample
