@@ -106,6 +106,7 @@ SIGNATURES = {
     'dp_add_rowvec': [_vp, _ll, _vp, _i, _i, _i, _vp, _ll, _vp],
     'dp_q_sample': [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
     'dp_cfg_combine': [_vp, _vp, _f, _vp, _ll, _vp],
+    'dp_u8_to_float': [_vp, _i, _i, _i, _i, _i, _vp, _ll, _i, C.c_uint, _i, _dr, _vp],
     'dp_version': [],
     'dp_launch_count': [],
 }

@@ -413,3 +413,63 @@ extern "C" int dp_cfg_combine(const float* e_uncond, const float* e_cond, float 
     DP_LAUNCH(cfg_combine_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, e_uncond, e_cond, scale, out, n);
     return DP_LAUNCH_CHECK();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Input pipeline on the device (utils.py:8-58, ddpm_exp/datasets/__init__.py:30-60,176-192): decoded uint8 images ->
+// fp32 NCHW training batch in one pass:  ToTensor (x / 255)  ->  RandomHorizontalFlip(p)  ->  Normalize(0.5, 0.5)
+// [(v - 0.5) / 0.5, the reference's two roundings] or data_transform's `2 v - 1`, optional uniform dequantization
+// (v / 256 * 255 + u / 256).  The flip decision of image n and the dequantization noise are Philox functions of
+// (seed, stream id, step, global image / element index): reproducible on the host and independent of the sharding.
+// src layout: hwc = 1 -> [N][H][W][C] (PIL / image folders), 0 -> [N][C][H][W] (CIFAR-10 python batches).
+// ---------------------------------------------------------------------------------------------
+__global__ void u8_to_float_kernel(const unsigned char* __restrict__ src, int hwc, int N, int C, int H, int W,
+                                   float* __restrict__ out, long long out_img_stride, int mode, unsigned flip_thr24,
+                                   int dequant, DpDrop rng) {
+    const long long per = (long long)C * H * W;
+    const long long total = (long long)N * per;
+    GS_LOOP(i, total) {
+        const long long n = i / per;
+        const long long r = i - n * per;
+        const int w = (int)(r % W);
+        const long long ch = r / W;
+        const int h = (int)(ch % H);
+        const int c = (int)(ch / H);
+        int ws = w;
+        if (flip_thr24) {
+            const unsigned long long gi = (unsigned long long)(rng.n_off + n);
+            const uint4 d = dp_philox4x32_10(make_uint4((unsigned)gi, (unsigned)(gi >> 32), rng.site, rng.step), rng.seed_lo, rng.seed_hi);
+            if ((d.x >> 8) < flip_thr24) ws = W - 1 - w;
+        }
+        const long long si = hwc ? (((n * H + h) * W + ws) * C + c) : (((n * C + c) * H + h) * (long long)W + ws);
+        float v = (float)src[si] / 255.0f;
+        if (dequant) {
+            const unsigned long long e = (unsigned long long)((rng.n_off + n) * per + r);
+            const unsigned long long q = e >> 2;
+            const uint4 d = dp_philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), rng.site ^ 0x9E3779B9u, rng.step), rng.seed_lo, rng.seed_hi);
+            const unsigned word = (e & 3) == 0 ? d.x : (e & 3) == 1 ? d.y : (e & 3) == 2 ? d.z : d.w;
+            v = v / 256.0f * 255.0f + ((float)(word >> 8) * (1.0f / 16777216.0f)) / 256.0f;
+        }
+        if (mode == 1) v = (v - 0.5f) / 0.5f;            // transforms.Normalize(mean=0.5, std=0.5)
+        else if (mode == 2) v = 2.0f * v - 1.0f;         // data_transform: rescaled
+        out[n * out_img_stride + r] = v;
+    }
+}
+extern "C" int dp_u8_to_float(const unsigned char* src, int hwc, int N, int C, int H, int W, float* out,
+                              long long out_img_stride, int mode, unsigned flip_thr24, int dequant, const dp_dropout* rng,
+                              void* stream) {
+    const long long total = (long long)N * C * H * W;
+    if (total <= 0) return 0;
+    if ((flip_thr24 || dequant) && !rng) return (int)hipErrorInvalidValue;
+    DpDrop d{};
+    if (rng) {
+        d.seed_lo = (unsigned)(rng->seed & 0xffffffffull);
+        d.seed_hi = (unsigned)(rng->seed >> 32);
+        d.site = rng->site;
+        d.step = rng->step;
+        d.n_off = rng->n_off;
+    }
+    DP_LAUNCH(u8_to_float_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, src, hwc, N, C, H, W, out,
+              out_img_stride, mode, flip_thr24, dequant, d);
+    return DP_LAUNCH_CHECK();
+}

@@ -1,0 +1,181 @@
+"""Data input pipeline: the datasets and transforms of the reference's training scripts with the
+per-pixel work on the device.
+
+  utils.py:8-24      UnlabeledImageFolder           -> UnlabeledImageFolder (same file discovery: recursive glob per extension)
+  utils.py:31-58     get_dataset: CIFAR-10 = RandomHorizontalFlip + ToTensor + Normalize(0.5, 0.5);
+                     image folders = Resize(256) + RandomCrop(256) + the same three
+  ddpm_exp/datasets/__init__.py:30-60,176-192   Resize + flip + ToTensor, then data_transform (uniform dequantization, 2x - 1)
+  ddpm_train.py:313-318   DataLoader(shuffle=True)  -> DeviceLoader
+
+Host side (decode, resize, crop, shuffle) stays on the CPU like torchvision's PIL transforms; the device receives uint8 pixels
+(a quarter of the fp32 bytes over PCIe) and ONE HIP kernel (dp_u8_to_float) does ToTensor + flip + normalisation.  Random
+decisions (flip per image, dequantisation noise, crop offsets, shuffling) are counter-based -- functions of (seed, epoch, global
+sample index) -- so every rank of a data-parallel run can build its own shard of the same global batch without communication.
+torchvision is not part of this repository's environment: the three transforms are restated from their definitions
+(ToTensor = x / 255; Normalize = (x - mean) / std; RandomHorizontalFlip = reverse W with probability p).
+"""
+import glob
+import math
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import ops, _lib as L
+
+NORMALIZE, RESCALE, RAW = 1, 2, 0
+
+
+class UnlabeledImageFolder:
+    """utils.py:8-24.  `transform` receives and returns a PIL image (host-side Resize / crop); items are uint8 HWC arrays."""
+
+    def __init__(self, root, transform=None, exts=("*.jpg", "*.png", "*.jpeg", "*.webp")):
+        self.root, self.transform = root, transform
+        self.files = []
+        for ext in exts:      # the reference formats '**/*.{}'.format("*.jpg") -> '**/*.*.jpg'; kept: same files found
+            self.files.extend(glob.glob(os.path.join(root, '**/*.{}'.format(ext)), recursive=True))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        img = Image.open(self.files[idx]).convert('RGB')
+        if self.transform is not None:
+            img = self.transform(img)
+        return np.asarray(img, dtype=np.uint8)
+
+
+class Cifar10Batches:
+    """The python pickles torchvision's CIFAR10 reads (`cifar-10-batches-py/data_batch_1..5`, `test_batch`): uint8 [N, 3, 32, 32]."""
+    hwc = False
+
+    def __init__(self, root, train=True):
+        base = os.path.join(root, 'cifar-10-batches-py')
+        names = ['data_batch_%d' % i for i in range(1, 6)] if train else ['test_batch']
+        data = []
+        for n in names:
+            with open(os.path.join(base, n), 'rb') as f:
+                entry = pickle.load(f, encoding='latin1')
+            data.append(np.asarray(entry['data'], dtype=np.uint8))
+        self.data = np.concatenate(data).reshape(-1, 3, 32, 32)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        return self.data[idx]
+
+
+class ArrayDataset:
+    """uint8 images already in memory: [N, H, W, C] (hwc=True) or [N, C, H, W]."""
+
+    def __init__(self, array, hwc=True):
+        self.data, self.hwc = np.ascontiguousarray(array, dtype=np.uint8), hwc
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        return self.data[idx]
+
+
+def resize_shorter_side(size):
+    """transforms.Resize(size) on a PIL image: shorter side -> size, bilinear (torchvision's default for PIL inputs)."""
+    def f(img):
+        from PIL import Image
+        w, h = img.size
+        if (w <= h and w == size) or (h <= w and h == size):
+            return img
+        if w < h:
+            return img.resize((size, int(size * h / w)), Image.BILINEAR)
+        return img.resize((int(size * w / h), size), Image.BILINEAR)
+    return f
+
+
+def epoch_permutation(n, seed, epoch):
+    """DataLoader(shuffle=True): a permutation of the dataset per epoch, identical on every rank."""
+    return np.random.default_rng([int(seed) & 0xFFFFFFFF, int(epoch)]).permutation(n)
+
+
+def crop_offsets(n_off, count, max_y, max_x, seed, epoch):
+    """RandomCrop offsets of global samples n_off .. n_off+count-1 (a function of the sample index, not of the draw order)."""
+    r = np.random.default_rng([int(seed) & 0xFFFFFFFF, int(epoch), 0xC0])
+    ys = r.integers(0, max_y + 1, size=n_off + count)[n_off:] if max_y > 0 else np.zeros(count, dtype=np.int64)
+    xs = r.integers(0, max_x + 1, size=n_off + count)[n_off:] if max_x > 0 else np.zeros(count, dtype=np.int64)
+    return ys, xs
+
+
+def to_device_batch(u8, hwc, device, mode=NORMALIZE, flip_p=0.5, seed=0, epoch=0, n_off=0, dequant=False, out=None):
+    """uint8 batch (numpy or torch, host or device) -> fp32 [N, C, H, W] on `device` through dp_u8_to_float.
+    n_off: global index of the first sample (flip decisions and noise are functions of the global index)."""
+    if device.type != 'cuda':
+        raise RuntimeError('the input pipeline kernel runs on the MI355X only')
+    t = torch.as_tensor(u8)
+    if t.dtype != torch.uint8 or t.dim() != 4:
+        raise ValueError('expected a 4-D uint8 batch')
+    if t.device.type != 'cuda':
+        t = t.contiguous().pin_memory().to(device, non_blocking=True)
+    t = t.contiguous()
+    if hwc:
+        N, H, W, Cc = t.shape
+    else:
+        N, Cc, H, W = t.shape
+    if out is None:
+        out = ops.empty_act((N, Cc, H, W), device)
+    d = L.Dropout()
+    d.seed, d.site, d.step, d.n_off = int(seed) & 0xFFFFFFFFFFFFFFFF, 0xF11B, int(epoch) & 0xFFFFFFFF, int(n_off)
+    thr = int(math.ceil(flip_p * (1 << 24))) if flip_p else 0
+    import ctypes as C
+    L.check(L.load().dp_u8_to_float(C.c_void_p(t.data_ptr()), 1 if hwc else 0, N, Cc, H, W, C.c_void_p(out.data_ptr()),
+                                    out.stride(0), mode, thr, 1 if dequant else 0, C.byref(d), ops._stream()),
+            'dp_u8_to_float')
+    out._keepalive = t            # the uint8 staging buffer must outlive the asynchronous kernel
+    return out
+
+
+class DeviceLoader:
+    """`for batch in DeviceLoader(dataset, 128, device)`: shuffled (optional), sharded over ranks, decoded on the host,
+    transformed on the device.  rank / world: this rank takes samples [rank * B, (rank + 1) * B) of every global batch of
+    world * B (ddpm_train.py's per-device train_batch_size under accelerate)."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, mode=NORMALIZE, flip_p=0.5, crop=None,
+                 dequant=False, rank=0, world=1, drop_last=False):
+        self.ds, self.B, self.device = dataset, batch_size, torch.device(device)
+        self.shuffle, self.seed, self.mode, self.flip_p, self.crop, self.dequant = shuffle, seed, mode, flip_p, crop, dequant
+        self.rank, self.world, self.drop_last = rank, world, drop_last
+        self.epoch = 0
+
+    def __len__(self):
+        g = self.B * self.world
+        n = len(self.ds)
+        return n // g if self.drop_last else -(-n // g)
+
+    def __iter__(self):
+        n = len(self.ds)
+        order = epoch_permutation(n, self.seed, self.epoch) if self.shuffle else np.arange(n)
+        g = self.B * self.world
+        hwc = getattr(self.ds, 'hwc', True)
+        for b in range(len(self)):
+            lo = b * g + self.rank * self.B
+            idx = order[lo:min(lo + self.B, (b + 1) * g, n)]
+            if len(idx) == 0:
+                return
+            items = [self.ds[int(i)] for i in idx]
+            if self.crop is not None:                                   # transforms.RandomCrop(crop) on HWC arrays
+                ys, xs = crop_offsets(lo, len(items), items[0].shape[0] - self.crop, items[0].shape[1] - self.crop,
+                                      self.seed, self.epoch)
+                items = [it[y:y + self.crop, x:x + self.crop] for it, y, x in zip(items, ys, xs)]
+            yield to_device_batch(np.stack(items), hwc, self.device, self.mode, self.flip_p, self.seed, self.epoch, lo,
+                                  self.dequant)
+        self.epoch += 1
+
+
+def get_dataset(name_or_path, root='./data'):
+    """utils.py:31-58 (the transforms live in DeviceLoader / the device kernel): 'cifar10' or an image directory."""
+    if name_or_path.lower() == 'cifar10':
+        return Cifar10Batches(os.path.join(root)), dict(crop=None)
+    if os.path.isdir(name_or_path):
+        return UnlabeledImageFolder(name_or_path, transform=resize_shorter_side(256)), dict(crop=256)
+    raise ValueError('unknown dataset %r' % (name_or_path,))

@@ -251,6 +251,14 @@ int dp_q_sample(const float* x0, const float* noise, const float* sqrt_acp, cons
 int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, long long n, void* stream);
 
 /* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
+/* Input pipeline (utils.py:8-58 get_dataset transforms; ddpm_exp/datasets/__init__.py:176-192 data_transform): decoded
+ * uint8 images -> fp32 NCHW batch: x/255 (ToTensor), horizontal flip of image n with probability flip_thr24 / 2^24
+ * (RandomHorizontalFlip; Philox decision on counter (n_off + n, 0, rng.site, rng.step), key rng.seed), mode 1:
+ * (v - 0.5)/0.5 (Normalize(0.5, 0.5)), mode 2: 2v - 1 (rescaled), mode 0: none; dequant != 0: v/256*255 + u/256 first.
+ * hwc != 0: src is [N][H][W][C], else [N][C][H][W].  rng: only seed / site / step / n_off are read. */
+int dp_u8_to_float(const unsigned char* src, int hwc, int N, int C, int H, int W, float* out, long long out_img_stride,
+                   int mode, unsigned flip_thr24, int dequant, const dp_dropout* rng, void* stream);
+
 int dp_version(void);
 /* Number of kernel launches this library has issued since it was loaded (host counter; bench.py reports launches per step).
  * Returned in place of an error code. */

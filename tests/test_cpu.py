@@ -1197,3 +1197,57 @@ def test_importance_accepts_torch_pruning_shaped_groups(mocked, monkeypatch):
         assert s_tp.numel() == len(items[0][1])
         n += 1
     assert n == len(fx['groups'])
+
+
+def test_data_pipeline_host_logic(tmp_path, monkeypatch):
+    """Row f4 host side (utils.py:8-58): image-folder discovery, CIFAR python batches, per-epoch shuffling and rank sharding --
+    with the device kernel replaced by the oracle transform, two ranks together produce exactly the single-rank global batches."""
+    from PIL import Image
+    from oracle import data_ref
+    data = pkg('data')
+    rng = np.random.default_rng(0)
+    root = tmp_path / 'imgs'
+    (root / 'sub').mkdir(parents=True)
+    imgs = []
+    for i in range(6):
+        a = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+        imgs.append(a)
+        Image.fromarray(a).save(str(root / ('sub' if i % 2 else '.') / ('im%d.x.png' % i)))       # name.*.png, see utils.py:14
+    ds = data.UnlabeledImageFolder(str(root), exts=('*.png',))
+    assert len(ds) == 6 and ds[0].dtype == np.uint8 and ds[0].shape == (20, 24, 3)
+    got = sorted(ds[i].tobytes() for i in range(6))
+    assert got == sorted(a.tobytes() for a in imgs)                    # lossless PNG round trip, every file found once
+    ds2 = data.UnlabeledImageFolder(str(root), transform=data.resize_shorter_side(10), exts=('*.png',))
+    assert ds2[0].shape == (10, 12, 3)
+    # CIFAR-10 python batches
+    base = tmp_path / 'c10' / 'cifar-10-batches-py'
+    base.mkdir(parents=True)
+    allb = []
+    import pickle
+    for k in range(1, 6):
+        arr = rng.integers(0, 256, (4, 3072), dtype=np.uint8)
+        allb.append(arr)
+        with open(str(base / ('data_batch_%d' % k)), 'wb') as f:
+            pickle.dump({'data': arr, 'labels': [0] * 4}, f)
+    c10 = data.Cifar10Batches(str(tmp_path / 'c10'))
+    assert len(c10) == 20 and c10[5].shape == (3, 32, 32) and np.array_equal(c10.data.reshape(20, -1), np.concatenate(allb))
+    # loader: sharding + shuffling with the device step mocked by the oracle transform
+    calls = []
+
+    def fake(u8, hwc, device, mode, flip_p, seed, epoch, n_off, dequant, out=None):
+        calls.append(n_off)
+        return data_ref.transform_batch(u8, hwc, mode, flip_p, seed, epoch, n_off, dequant)
+    monkeypatch.setattr(data, 'to_device_batch', fake)
+    one = list(data.DeviceLoader(c10, 8, 'cpu', seed=5))
+    r0 = list(data.DeviceLoader(c10, 4, 'cpu', seed=5, rank=0, world=2))
+    r1 = list(data.DeviceLoader(c10, 4, 'cpu', seed=5, rank=1, world=2))
+    assert len(one) == 3 and [b.shape[0] for b in one] == [8, 8, 4]
+    for a, b0, b1 in zip(one, r0, r1):
+        assert torch.equal(a, torch.cat([b0, b1]))
+    flat = torch.cat(one)
+    assert flat.shape == (20, 3, 32, 32) and float(flat.min()) >= -1 and float(flat.max()) <= 1
+    # every sample exactly once per epoch (up to its flip)
+    perm = data.epoch_permutation(20, 5, 0)
+    ref = data_ref.transform_batch(c10.data[perm], False, 1, 0.5, 5, 0, 0)
+    assert torch.equal(flat, ref)
+    assert not np.array_equal(perm, data.epoch_permutation(20, 5, 1))

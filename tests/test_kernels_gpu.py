@@ -589,3 +589,29 @@ def test_conv_fast_x4_loads_equal_dword_loads(ops, report, monkeypatch):
         bad.append('bmm_tn')
     report['conv_x4/mismatching'] = bad
     assert not bad, bad
+
+
+def test_input_pipeline_kernel_bit_exact(ops, report):
+    """Row f4: uint8 -> fp32 NCHW with ToTensor / RandomHorizontalFlip / Normalize (or data_transform) in one kernel, bit-exact
+    against the oracle restatement (same flip decisions, same fp32 operation order), both source layouts, a rank offset."""
+    import importlib
+    from oracle import data_ref
+    data = importlib.import_module('diff-pruning_amd.data')
+    rng = np.random.default_rng(3)
+    bad = []
+    for hwc, shape in ((True, (9, 32, 32, 3)), (False, (5, 3, 32, 32)), (True, (2, 17, 23, 3))):
+        u8 = rng.integers(0, 256, shape, dtype=np.uint8)
+        for mode, flip, dq, n_off in ((1, 0.5, False, 0), (2, 0.5, True, 11), (0, 0.0, False, 3), (1, 0.25, False, 1 << 33)):
+            got = data.to_device_batch(u8, hwc, torch.device(DEV), mode, flip, seed=77, epoch=4, n_off=n_off, dequant=dq)
+            want = data_ref.transform_batch(u8, hwc, mode, flip, 77, 4, n_off, dq)
+            if not torch.equal(got.cpu(), want):
+                bad.append((hwc, shape, mode, flip, dq, float((got.cpu() - want).abs().max())))
+    report['data_pipeline/mismatching'] = bad
+    assert not bad, bad
+    # loader end to end on the device: two ranks == one global batch
+    ds = data.ArrayDataset(rng.integers(0, 256, (20, 3, 32, 32), dtype=np.uint8), hwc=False)
+    one = torch.cat(list(data.DeviceLoader(ds, 8, DEV, seed=9)))
+    two = []
+    for b0, b1 in zip(data.DeviceLoader(ds, 4, DEV, seed=9, rank=0, world=2), data.DeviceLoader(ds, 4, DEV, seed=9, rank=1, world=2)):
+        two += [b0, b1]
+    assert torch.equal(one, torch.cat(two)) and one.shape == (20, 3, 32, 32)
