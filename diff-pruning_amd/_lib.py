@@ -30,7 +30,7 @@ class ConvGemmParams(C.Structure):
                 ('alpha', C.c_float), ('post_scale', C.c_float),
                 ('bias', C.c_void_p), ('tadd', C.c_void_p), ('tadd_stride', LL),
                 ('res', C.c_void_p), ('r_img_stride', LL),
-                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('x_guard', C.c_int), ('_pad1', C.c_int)]
+                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('x_guard', C.c_int), ('act', C.c_int)]
 
 
 class NtGemmParams(C.Structure):
@@ -107,6 +107,11 @@ SIGNATURES = {
     'dp_q_sample': [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _vp],
     'dp_cfg_combine': [_vp, _vp, _f, _vp, _ll, _vp],
     'dp_u8_to_float': [_vp, _i, _i, _i, _i, _i, _vp, _ll, _i, C.c_uint, _i, _dr, _vp],
+    'dp_pool2d': [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp],
+    'dp_resize_bilinear': [_vp, _ll, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
+    'dp_ssim': [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    'dp_ssim_workspace': [_i, _i, _i, _i],
+    'dp_mse_per_image': [_vp, _vp, _i, _ll, _vp, _vp],
     'dp_version': [],
     'dp_launch_count': [],
 }
@@ -130,7 +135,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_longlong if name == 'dp_launch_count' else C.c_int
+        fn.restype = C.c_longlong if name in ('dp_launch_count', 'dp_ssim_workspace') else C.c_int
     _lib = lib
     return lib
 

@@ -473,3 +473,200 @@ extern "C" int dp_u8_to_float(const unsigned char* src, int hwc, int N, int C, i
               out_img_stride, mode, flip_thr24, dequant, d);
     return DP_LAUNCH_CHECK();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// FID / SSIM evaluation glue (fid_score.py:100-322, inception.py:16-340, ddpm_exp/compute_ssim.py:14-53)
+// ---------------------------------------------------------------------------------------------
+// 3x3-style pooling over NCHW planes: mode 0 = max (padding excluded, as F.max_pool2d), mode 1 = average over the VALID taps
+// only (F.avg_pool2d(..., count_include_pad=False), the TensorFlow behaviour the FID Inception patches in).
+__global__ void pool2d_kernel(const float* __restrict__ x, long long x_img_stride, int N, int C, int H, int W, int k, int stride,
+                              int pad, int mode, int Ho, int Wo, float* __restrict__ y, long long y_img_stride) {
+    const long long per = (long long)C * Ho * Wo;
+    const long long total = (long long)N * per;
+    GS_LOOP(i, total) {
+        const long long n = i / per;
+        const long long r = i - n * per;
+        const int wo = (int)(r % Wo);
+        const long long ch = r / Wo;
+        const int ho = (int)(ch % Ho);
+        const long long c = ch / Ho;
+        const float* xp = x + n * x_img_stride + c * (long long)H * W;
+        float acc = mode == 0 ? -INFINITY : 0.f;
+        int cnt = 0;
+        for (int ky = 0; ky < k; ++ky) {
+            const int h = ho * stride + ky - pad;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int w = wo * stride + kx - pad;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const float v = xp[(long long)h * W + w];
+                acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+                ++cnt;
+            }
+        }
+        y[n * y_img_stride + r] = mode == 0 ? acc : acc / (float)cnt;
+    }
+}
+extern "C" int dp_pool2d(const float* x, long long x_img_stride, int N, int C, int H, int W, int k, int stride, int pad, int mode,
+                         float* y, long long y_img_stride, void* stream) {
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long long total = (long long)N * C * Ho * Wo;
+    if (total <= 0) return 0;
+    DP_LAUNCH(pool2d_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_img_stride, N, C, H, W, k, stride, pad,
+              mode, Ho, Wo, y, y_img_stride);
+    return DP_LAUNCH_CHECK();
+}
+
+// F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) followed by y = a * v + b (inception.py:147-154:
+// resize to 299x299, then 2x - 1).  Source index arithmetic in fp32 exactly as ATen's area_pixel_compute_source_index.
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, long long x_img_stride, int N, int C, int H, int W, int Ho,
+                                       int Wo, float a, float b, float* __restrict__ y) {
+    const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    const long long per = (long long)C * Ho * Wo;
+    const long long total = (long long)N * per;
+    GS_LOOP(i, total) {
+        const long long n = i / per;
+        const long long r = i - n * per;
+        const int wo = (int)(r % Wo);
+        const long long ch = r / Wo;
+        const int ho = (int)(ch % Ho);
+        const long long c = ch / Ho;
+        float fh = sh * ((float)ho + 0.5f) - 0.5f;
+        float fw = sw * ((float)wo + 0.5f) - 0.5f;
+        if (fh < 0.f) fh = 0.f;
+        if (fw < 0.f) fw = 0.f;
+        const int h0 = (int)fh, w0 = (int)fw;
+        const int h1 = h0 + (h0 < H - 1 ? 1 : 0), w1 = w0 + (w0 < W - 1 ? 1 : 0);
+        const float lh1 = fh - (float)h0, lw1 = fw - (float)w0;
+        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        const float* xp = x + n * x_img_stride + c * (long long)H * W;
+        const float v = lh0 * (lw0 * xp[(long long)h0 * W + w0] + lw1 * xp[(long long)h0 * W + w1]) +
+                        lh1 * (lw0 * xp[(long long)h1 * W + w0] + lw1 * xp[(long long)h1 * W + w1]);
+        y[i] = a * v + b;
+    }
+}
+extern "C" int dp_resize_bilinear(const float* x, long long x_img_stride, int N, int C, int H, int W, int Ho, int Wo, float a,
+                                  float b, float* y, void* stream) {
+    const long long total = (long long)N * C * Ho * Wo;
+    if (total <= 0) return 0;
+    DP_LAUNCH(resize_bilinear_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_img_stride, N, C, H, W, Ho, Wo,
+              a, b, y);
+    return DP_LAUNCH_CHECK();
+}
+
+// SSIM (Wang et al. 2004 as implemented by pytorch_msssim.ssim, which compute_ssim.py:43 calls with data_range = 1,
+// size_average = False): 11-tap Gaussian (sigma 1.5) "valid" filtering of x, y, x^2, y^2, xy per channel plane, then the mean of
+// the SSIM map.  One workgroup per (plane, 16x16 output tile): the (16+10)^2 input patch of x and y sits in LDS, the
+// horizontal pass writes 5 maps of 26x16 to LDS, the vertical pass produces the tile's SSIM values and their sum.
+// part[(plane * tiles) + tile] = sum of the tile's SSIM values; sq[...] = sum of squared differences of the whole tile patch
+// core (for the per-image MSE of compute_ssim.py:45).  Reduced in a fixed order by ssim_finish_kernel.
+#define SSIM_T 16
+#define SSIM_K 11
+__constant__ float dp_ssim_win[SSIM_K];
+__global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict__ x, const float* __restrict__ y, int H, int W,
+                                                        int tiles_x, float C1, float C2, float* __restrict__ part) {
+    constexpr int P = SSIM_T + SSIM_K - 1;                 // 26
+    __shared__ float sx[P][P + 1], sy[P][P + 1];
+    __shared__ float hm[5][P][SSIM_T + 1];
+    __shared__ float red[4];
+    const int plane = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int Ho = H - SSIM_K + 1, Wo = W - SSIM_K + 1;
+    const int h0 = ty * SSIM_T, w0 = tx * SSIM_T;
+    const float* xp = x + (long long)plane * H * W;
+    const float* yp = y + (long long)plane * H * W;
+    for (int e = threadIdx.x; e < P * P; e += 256) {
+        const int r = e / P, c = e - r * P;
+        const int h = h0 + r, w = w0 + c;
+        const bool v = h < H && w < W;
+        sx[r][c] = v ? xp[(long long)h * W + w] : 0.f;
+        sy[r][c] = v ? yp[(long long)h * W + w] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < P * SSIM_T; e += 256) {          // horizontal pass
+        const int r = e / SSIM_T, c = e - r * SSIM_T;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SSIM_K; ++k) {
+            const float g = dp_ssim_win[k], u = sx[r][c + k], v = sy[r][c + k];
+            a0 += g * u; a1 += g * v; a2 += g * (u * u); a3 += g * (v * v); a4 += g * (u * v);
+        }
+        hm[0][r][c] = a0; hm[1][r][c] = a1; hm[2][r][c] = a2; hm[3][r][c] = a3; hm[4][r][c] = a4;
+    }
+    __syncthreads();
+    float s = 0.f;
+    {
+        const int r = threadIdx.x / SSIM_T, c = threadIdx.x - r * SSIM_T;      // 256 threads = 16 x 16 outputs
+        if (h0 + r < Ho && w0 + c < Wo) {
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < SSIM_K; ++k) {
+                const float g = dp_ssim_win[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] += g * hm[q][r + k][c];
+            }
+            const float mu1 = m[0], mu2 = m[1];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+            const float cs = (2.f * s12 + C2) / (s1 + s2 + C2);
+            s = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs;
+        }
+    }
+    s = dp_block_sum_256(s, red);
+    if (threadIdx.x == 0) part[(long long)plane * gridDim.x + blockIdx.x] = s;
+}
+// out[n] = mean_c ( sum_tiles part / (Ho*Wo) )
+__global__ void ssim_finish_kernel(const float* __restrict__ part, int N, int C, int tiles, float inv_cnt, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (int t = 0; t < tiles; ++t) s += part[((long long)n * C + c) * tiles + t];
+        acc += s * inv_cnt;
+    }
+    out[n] = acc / (float)C;
+}
+extern "C" int dp_ssim(const float* x, const float* y, int N, int C, int H, int W, float data_range, float* part, float* out,
+                       void* stream) {
+    if (N <= 0) return 0;
+    if (H < SSIM_K || W < SSIM_K) return (int)hipErrorInvalidValue;
+    static bool win_set = false;
+    if (!win_set) {                                  // pytorch_msssim._fspecial_gauss_1d(11, 1.5): exp(-x^2 / (2 sigma^2)), normalised
+        float g[SSIM_K], tot = 0.f;
+        for (int i = 0; i < SSIM_K; ++i) { const float d = (float)(i - SSIM_K / 2); g[i] = expf(-(d * d) / (2.f * 1.5f * 1.5f)); tot += g[i]; }
+        for (int i = 0; i < SSIM_K; ++i) g[i] /= tot;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dp_ssim_win), g, sizeof(g)) != hipSuccess) return (int)hipGetLastError();
+        win_set = true;
+    }
+    const int Ho = H - SSIM_K + 1, Wo = W - SSIM_K + 1;
+    const int tx = (Wo + SSIM_T - 1) / SSIM_T, ty = (Ho + SSIM_T - 1) / SSIM_T;
+    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
+    DP_LAUNCH(ssim_tile_kernel, dim3(tx * ty, N * C), dim3(256), 0, (hipStream_t)stream, x, y, H, W, tx, C1, C2, part);
+    DP_LAUNCH(ssim_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, N, C, tx * ty,
+              1.0f / (float)(Ho * Wo), out);
+    return DP_LAUNCH_CHECK();
+}
+extern "C" long long dp_ssim_workspace(int N, int C, int H, int W) {
+    const int Ho = H - SSIM_K + 1, Wo = W - SSIM_K + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    return (long long)N * C * ((Wo + SSIM_T - 1) / SSIM_T) * ((Ho + SSIM_T - 1) / SSIM_T);
+}
+
+// out[n] = mean over the image of (a - b)^2   (compute_ssim.py:45: mse_loss(reduction='none').mean(dim=(1,2,3)))
+__global__ __launch_bounds__(256) void mse_per_image_kernel(const float* __restrict__ a, const float* __restrict__ b, long long per,
+                                                            float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* ap = a + (long long)blockIdx.x * per;
+    const float* bp = b + (long long)blockIdx.x * per;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < per; i += 256) { const float d = ap[i] - bp[i]; s += d * d; }
+    s = dp_block_sum_256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s / (float)per;
+}
+extern "C" int dp_mse_per_image(const float* a, const float* b, int N, long long per, float* out, void* stream) {
+    if (N <= 0 || per <= 0) return 0;
+    DP_LAUNCH(mse_per_image_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a, b, per, out);
+    return DP_LAUNCH_CHECK();
+}

@@ -163,6 +163,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const dp_conv_gemm_params& p,
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] *= p.post_scale;
+        if (p.act == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
         if (p.accumulate) {
             float t[8];
 #pragma unroll
@@ -874,6 +878,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const dp_conv
         if (p.tadd) v += p.tadd[(long long)img * p.tadd_stride + m];
         if (p.res) v += p.res[(long long)img * p.r_img_stride + (long long)m * HoWo + r_in];
         v *= p.post_scale;
+        if (p.act == 1) v = fmaxf(v, 0.f);
         float* o = p.out + (long long)img * p.o_img_stride + (long long)m * HoWo + r_in;
         if (p.accumulate) v += *o;
         *o = v;

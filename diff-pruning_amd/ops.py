@@ -197,14 +197,27 @@ def _geom(Ho, Wo, Hs, Ws, Hv, Wv, kw, stride, sden, pad_t, pad_l, ups, c_split, 
 
 
 class ConvSpec:
-    """Forward geometry of one convolution (kernel k x k, stride, top/left padding, fused nearest x2 upsample)."""
-    __slots__ = ('k', 'stride', 'pad', 'ups')
+    """Forward geometry of one convolution (kernel k x k, stride, top/left padding, fused nearest x2 upsample).
+    General form (forward only; the FID Inception network's 1x7 / 7x1 / 5x5 / valid stride-2 convolutions):
+    ConvSpec.general(kh, kw, stride, pad_h, pad_w) -- symmetric zero padding, output floor((H + 2 pad - k) / stride) + 1."""
+    __slots__ = ('k', 'stride', 'pad', 'ups', 'kh', 'kw', 'pad_h', 'pad_w', 'sym')
 
     def __init__(self, k=3, stride=1, pad=1, ups=0):
         self.k, self.stride, self.pad, self.ups = k, stride, pad, ups
+        self.kh = self.kw = k
+        self.pad_h = self.pad_w = pad
+        self.sym = False
+
+    @classmethod
+    def general(cls, kh, kw, stride=1, pad_h=0, pad_w=0):
+        s = cls(kh, stride, pad_h, 0)
+        s.kh, s.kw, s.pad_h, s.pad_w, s.sym = kh, kw, pad_h, pad_w, True
+        return s
 
     def out_hw(self, Hs, Ws):
         Hv, Wv = Hs << self.ups, Ws << self.ups
+        if self.sym:
+            return (Hv + 2 * self.pad_h - self.kh) // self.stride + 1, (Wv + 2 * self.pad_w - self.kw) // self.stride + 1
         if self.stride == 1:
             return Hv + 2 * self.pad - self.k + 1, Wv + 2 * self.pad - self.k + 1
         # stride 2: pad == 0 means the reference's asymmetric (0,1,0,1) zero pad (resnet.py:213-215)
@@ -214,7 +227,7 @@ class ConvSpec:
 
 
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
-                 accumulate=False):
+                 accumulate=False, relu=False):
     """out[N, Cout, Ho, Wo] = conv(cat(x, x2)) (+bias) (+tadd[n, co]) (+res) ; * post_scale.
     wp/ld: pack_weight(w, 0).  tadd: [N, Cout] per-image per-channel addend (time-embedding projection)."""
     s1 = _chk_act(x)
@@ -236,9 +249,10 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
     p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
     p.x_guard = 1 if (_guarded(x) and _guarded(x2)) else 0
     p.a_bytes, p.x1_bytes, p.x2_bytes = wp.numel() * 4, _extent_bytes(x), _extent_bytes(x2)
-    p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
+    p.g = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.kw, spec.stride, 1, spec.pad_h, spec.pad_w, spec.ups,
                 C1 if x2 is not None else Cin, s1, s2)
-    p.M, p.C, p.NPIX, p.ntaps, p.batches = Cout, Cin, N * Ho * Wo, spec.k * spec.k, 1
+    p.M, p.C, p.NPIX, p.ntaps, p.batches = Cout, Cin, N * Ho * Wo, spec.kh * spec.kw, 1
+    p.act = 1 if relu else 0
     p.tile = pick_tile(Cout, N * Ho * Wo)
     _prefer_tile96(p)
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0

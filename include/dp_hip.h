@@ -33,7 +33,7 @@ typedef struct dp_conv_geom {
  * a_kc = 0: A is a packed weight  A[(tap*C + c)*lda + m]  (m contiguous, lda % 4 == 0, zero padded)
  * a_kc = 1: A[m*lda + c]  (c contiguous; taps must be 1)
  * Epilogue: v = alpha*acc (+bias[m]) (+tadd[img*tadd_stride + m]) (+res[img*r_img_stride + m*HoWo + r]);
- *           v *= post_scale; out = accumulate ? out + v : v.
+ *           v *= post_scale; (act: v = max(v, 0)); out = accumulate ? out + v : v.
  * ksplit > 1 (small pixel counts): the K loop is split over workgroups, raw partial tiles go to ws and a second
  * kernel sums them in a fixed order and applies the same epilogue (deterministic). */
 typedef struct dp_conv_gemm_params {
@@ -48,7 +48,8 @@ typedef struct dp_conv_gemm_params {
     const float* res; long long r_img_stride;
     int accumulate; int ksplit;            /* ksplit > 1: split the K loop over blockIdx.z, partials in ws (non-batched only) */
     float* ws;                             /* >= ksplit*M*NPIX floats when ksplit > 1 */
-    int x_guard; int _pad1;                /* 1: the 4 bytes in front of X1 (and X2) are readable memory.  The 16-byte B-tile
+    int x_guard; int act;                  /* act = 1: ReLU after post_scale (BasicConv2d of the FID Inception network).
+                                              x_guard = 1: the 4 bytes in front of X1 (and X2) are readable memory.  The 16-byte B-tile
                                               loads of the stride-1 fast kernel read one element to the left of an image
                                               row for the shifted taps (overwritten with 0 in LDS); for the first row of the
                                               tensor that element lies in front of it.  0 = use the 4-byte loads. */
@@ -251,6 +252,20 @@ int dp_q_sample(const float* x0, const float* noise, const float* sqrt_acp, cons
 int dp_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, long long n, void* stream);
 
 /* version / build info (smoke-tested by the CPU suite: library loads, symbols resolve) */
+/* ---- FID / SSIM evaluation: fid_score.py:100-322, inception.py:16-340, compute_ssim.py:14-53 ---- */
+/* k x k pooling, symmetric padding; mode 0: F.max_pool2d, mode 1: F.avg_pool2d(count_include_pad=False) (inception.py:238,266,300,333) */
+int dp_pool2d(const float* x, long long x_img_stride, int N, int C, int H, int W, int k, int stride, int pad, int mode,
+              float* y, long long y_img_stride, void* stream);
+/* y = a * bilinear_resize(x -> Ho x Wo, align_corners = False) + b   (inception.py:147-154: 299 x 299, then 2x - 1) */
+int dp_resize_bilinear(const float* x, long long x_img_stride, int N, int C, int H, int W, int Ho, int Wo, float a, float b,
+                       float* y, void* stream);
+/* out[n] = SSIM(x_n, y_n) as pytorch_msssim.ssim(x, y, data_range, size_average=False) (compute_ssim.py:43): 11-tap Gaussian,
+ * sigma 1.5, valid filtering per channel, mean over the map, mean over channels.  x, y contiguous [N][C][H][W];
+ * part: workspace of dp_ssim_workspace(N, C, H, W) floats.  dp_mse_per_image: compute_ssim.py:45. */
+int dp_ssim(const float* x, const float* y, int N, int C, int H, int W, float data_range, float* part, float* out, void* stream);
+long long dp_ssim_workspace(int N, int C, int H, int W);
+int dp_mse_per_image(const float* a, const float* b, int N, long long per, float* out, void* stream);
+
 /* Input pipeline (utils.py:8-58 get_dataset transforms; ddpm_exp/datasets/__init__.py:176-192 data_transform): decoded
  * uint8 images -> fp32 NCHW batch: x/255 (ToTensor), horizontal flip of image n with probability flip_thr24 / 2^24
  * (RandomHorizontalFlip; Philox decision on counter (n_off + n, 0, rng.site, rng.step), key rng.seed), mode 1:

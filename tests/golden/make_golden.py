@@ -510,6 +510,32 @@ def do_c1_long():
     print('c1 long ok: groups', len(rec), 'params', sum(p.numel() for p in model.parameters()))
 
 
+def do_fid():
+    """fid_score.py:182-262 on seeded feature matrices: the reference's own calculate_frechet_distance (imported with stub
+    `torchvision` / `inception` modules: only numpy / scipy code is executed) and its np.mean / np.cov statistics."""
+    import types
+    tv = types.ModuleType('torchvision')
+    tv.transforms = types.ModuleType('torchvision.transforms')
+    inc = types.ModuleType('inception')
+    inc.InceptionV3 = type('InceptionV3', (), dict(BLOCK_INDEX_BY_DIM={64: 0, 192: 1, 768: 2, 2048: 3}))
+    for n, m in (('torchvision', tv), ('torchvision.transforms', tv.transforms), ('inception', inc)):
+        sys.modules.setdefault(n, m)
+    import fid_score
+    out = []
+    for dims, n1, n2, seed in ((64, 300, 250, 1), (192, 400, 400, 2), (48, 40, 60, 3)):
+        r = np.random.default_rng(seed)
+        mix = r.standard_normal((dims, dims)) / np.sqrt(dims)
+        a = np.maximum(r.standard_normal((n1, dims)) @ mix + 0.3, 0).astype(np.float32)          # non-negative, correlated features
+        b = np.maximum(r.standard_normal((n2, dims)) @ (mix * 1.1) + 0.35, 0).astype(np.float32)
+        m1, s1 = np.mean(a.astype(np.float64), axis=0), np.cov(a.astype(np.float64), rowvar=False)
+        m2, s2 = np.mean(b.astype(np.float64), axis=0), np.cov(b.astype(np.float64), rowvar=False)
+        out.append(dict(dims=dims, n1=n1, n2=n2, seed=seed, fid=float(fid_score.calculate_frechet_distance(m1, s1, m2, s2)),
+                        fid_self=float(fid_score.calculate_frechet_distance(m1, s1, m1, s1)),
+                        mu1_sum=float(m1.sum()), trace1=float(np.trace(s1))))
+    json.dump(out, open(os.path.join(HERE, 'fid.json'), 'w'))
+    print('fid ok', [o['fid'] for o in out])
+
+
 def do_lr():
     """diffusers/optimization.py:282 get_scheduler: the lr in force at each of 40 optimizer steps, every schedule type."""
     from diffusers.optimization import get_scheduler
@@ -614,6 +640,6 @@ def do_dropout():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads', 'long_sweep', 'lr', 'ddpm', 'dropout']
+    what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads', 'long_sweep', 'lr', 'ddpm', 'dropout', 'fid']
     for w in what:
         globals()['do_' + w]()

@@ -110,3 +110,39 @@ def tp_like_groups(model, graph_mod):
             items.append((SimpleNamespace(target=SimpleNamespace(module=mod, name=m.name), handler=handler), list(m.idxs)))
         out.append((root, items))
     return out
+
+
+def fid_features(dims, n1, n2, seed):
+    """The seeded feature matrices of tests/golden/fid.json (make_golden.py do_fid)."""
+    r = np.random.default_rng(seed)
+    mix = r.standard_normal((dims, dims)) / np.sqrt(dims)
+    a = np.maximum(r.standard_normal((n1, dims)) @ mix + 0.3, 0).astype(np.float32)
+    b = np.maximum(r.standard_normal((n2, dims)) @ (mix * 1.1) + 0.35, 0).astype(np.float32)
+    return a, b
+
+
+def inception_state_dict(seed):
+    """Seeded weights for the FID Inception (torchvision key names): He-scaled convolutions, BatchNorm statistics away from
+    the identity so that the folding is exercised."""
+    import importlib
+    m = importlib.import_module('diff-pruning_amd.metrics')
+    sd = {}
+    for k, v in m.FIDInception3().state_dict().items():
+        r = np.random.default_rng([zlib_crc(k), seed])
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.tensor(1)
+        elif k.endswith('conv.weight') or k == 'fc.weight':
+            fan = int(np.prod(v.shape[1:]))
+            sd[k] = torch.from_numpy((r.standard_normal(tuple(v.shape)) * np.sqrt(2.0 / fan)).astype(np.float32))
+        elif k.endswith('running_var'):
+            sd[k] = torch.from_numpy((0.5 + r.random(tuple(v.shape))).astype(np.float32))
+        elif k.endswith('bn.weight'):
+            sd[k] = torch.from_numpy((0.8 + 0.4 * r.random(tuple(v.shape))).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy((0.1 * r.standard_normal(tuple(v.shape))).astype(np.float32))
+    return sd
+
+
+def zlib_crc(s):
+    import zlib
+    return zlib.crc32(s.encode())

@@ -1251,3 +1251,38 @@ def test_data_pipeline_host_logic(tmp_path, monkeypatch):
     ref = data_ref.transform_batch(c10.data[perm], False, 1, 0.5, 5, 0, 0)
     assert torch.equal(flat, ref)
     assert not np.array_equal(perm, data.epoch_permutation(20, 5, 1))
+
+
+def test_fid_oracle_and_host_math_match_reference():
+    """Row f3: the Frechet distance and the activation statistics against values computed by fid_score.py itself
+    (tests/golden/fid.json): the oracle restatement and the product's host-side function (scipy sqrtm, as in the reference)."""
+    from oracle import metrics_ref as M
+    from helpers import fid_features
+    metrics = pkg('metrics')
+    for fx in load_json('fid.json'):
+        a, b = fid_features(fx['dims'], fx['n1'], fx['n2'], fx['seed'])
+        m1, s1 = M.activation_statistics(a)
+        m2, s2 = M.activation_statistics(b)
+        assert abs(m1.sum() - fx['mu1_sum']) < 1e-9 * abs(fx['mu1_sum']) and abs(np.trace(s1) - fx['trace1']) < 1e-9 * fx['trace1']
+        for f in (M.frechet_distance, metrics.calculate_frechet_distance):
+            assert abs(f(m1, s1, m2, s2) - fx['fid']) < 1e-8 * fx['fid']
+            assert abs(f(m1, s1, m1, s1) - fx['fid_self']) < 1e-6
+    # the holder tree carries torchvision's key names (what the FID weight file is keyed by) and its parameter count
+    sd = metrics.FIDInception3().state_dict()
+    assert 'Mixed_7c.branch3x3dbl_3b.bn.running_var' in sd and 'Mixed_6a.branch3x3dbl_3.conv.weight' in sd
+    assert sum(v.numel() for k, v in sd.items() if 'num_batches' not in k and not k.startswith('fc.')
+               and 'running' not in k) == 21785568          # Inception3 without AuxLogits and fc (torchvision: 21.8 M)
+    with pytest.raises(RuntimeError):
+        metrics.InceptionV3()(torch.zeros(1, 3, 32, 32))            # no CPU fallback
+
+
+def test_ssim_oracle_properties():
+    """SSIM restatement (pytorch_msssim semantics): identical images -> 1, symmetric, decreasing with noise."""
+    from oracle import metrics_ref as M
+    r = np.random.default_rng(0)
+    x = torch.from_numpy(r.random((3, 3, 32, 32)).astype(np.float32))
+    y = (x + 0.1 * torch.from_numpy(r.standard_normal((3, 3, 32, 32)).astype(np.float32))).clamp(0, 1)
+    z = (x + 0.3 * torch.from_numpy(r.standard_normal((3, 3, 32, 32)).astype(np.float32))).clamp(0, 1)
+    assert torch.allclose(M.ssim(x, x), torch.ones(3, dtype=torch.float64))
+    assert torch.allclose(M.ssim(x, y), M.ssim(y, x))
+    assert (M.ssim(x, y) > M.ssim(x, z)).all() and (M.ssim(x, z) > 0).all()

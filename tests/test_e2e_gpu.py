@@ -968,3 +968,71 @@ def test_two_half_batch_pipelines_match_single_pipeline(report):
     report['e2e/two_half_pipelines'] = dict(grad_rel=e_g, loss_rel=e_l, mask_mismatches=mism, exit_steps=(e2['steps'], e1['steps']))
     assert e_g < 2e-5 and e_l < 1e-6 and not mism
     assert e2['steps'] == e1['steps'] and np.allclose(e2['losses'], e1['losses'], rtol=1e-6)
+
+
+def test_fid_inception_forward_and_statistics(report):
+    """Row f3: the FID Inception network on the HIP kernels (BatchNorm folded, one conv + bias + ReLU launch per BasicConv2d,
+    branches written into channel slices) against the oracle's PyTorch restatement with seeded weights (torchvision is absent:
+    network parity unpinned), every output block; then the streaming mean / covariance and the Frechet distance against numpy
+    on the device features and against the values fid_score.py itself produced for seeded feature matrices."""
+    from oracle import metrics_ref as M
+    from helpers import inception_state_dict, fid_features
+    metrics = pkg('metrics')
+    sd = inception_state_dict(3)
+    net = metrics.InceptionV3([0, 1, 2, 3], state_dict=sd).to(DEV)
+    img = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    outs = net(img.to(DEV))
+    refs = M.inception_forward(sd, img, (0, 1, 2, 3))
+    errs = [relerr(o, r) for o, r in zip(outs, refs)]
+    assert [tuple(o.shape) for o in outs] == [(3, 64, 73, 73), (3, 192, 35, 35), (3, 768, 17, 17), (3, 2048, 1, 1)]
+    # no resize (299 x 299 input straight in) and the default single-block call
+    net3 = metrics.InceptionV3(resize_input=False, state_dict=sd).to(DEV)
+    big = torch.rand(2, 3, 299, 299, generator=torch.Generator().manual_seed(2))
+    e_big = relerr(net3(big.to(DEV))[0], M.inception_forward(sd, big, (3,), resize_input=False)[0])
+    # streaming statistics on the device vs numpy on the same rows, three uneven batches
+    fx = load_json('fid.json')[1]
+    a, b = fid_features(fx['dims'], fx['n1'], fx['n2'], fx['seed'])
+    mus, sigmas = [], []
+    for feats in (a, b):
+        st = metrics.FeatureStats(fx['dims'], torch.device(DEV))
+        for lo, hi in ((0, 100), (100, 101), (101, len(feats))):
+            st.update(torch.from_numpy(feats[lo:hi]).to(DEV))
+        mu, sg = st.finalize()
+        rm, rs = M.activation_statistics(feats)
+        mus.append(mu)
+        sigmas.append(sg)
+        assert np.abs(mu - rm).max() < 1e-6 and np.abs(sg - rs).max() < 2e-6 * np.abs(rs).max()
+    fid = metrics.calculate_frechet_distance(mus[0], sigmas[0], mus[1], sigmas[1])
+    report['e2e/fid'] = dict(block_rel_errs=errs, no_resize_rel=e_big, fid=fid, fid_reference=fx['fid'])
+    assert max(errs) < 5e-5 and e_big < 5e-5                      # ~95 fp32 layers deep
+    assert abs(fid - fx['fid']) < 1e-4 * fx['fid']
+
+
+def test_compare_directories_ssim_and_fid_paths(report, tmp_path):
+    """compute_ssim.py / fid_score.py entry points over directories of PNG samples (PIL decode on the host, ToTensor on the
+    device): mean SSIM / MSE vs the oracle, FID of a directory against itself = 0 and against saved statistics (--save-stats)."""
+    from PIL import Image
+    from oracle import metrics_ref as M
+    from helpers import inception_state_dict
+    metrics = pkg('metrics')
+    rng = np.random.default_rng(5)
+    d1, d2 = tmp_path / 'a', tmp_path / 'b'
+    d1.mkdir(); d2.mkdir()
+    A = rng.integers(0, 256, (12, 32, 32, 3), dtype=np.uint8)
+    B = np.clip(A.astype(np.int32) + rng.integers(-30, 31, A.shape), 0, 255).astype(np.uint8)
+    for i in range(12):
+        Image.fromarray(A[i]).save(str(d1 / ('%03d.png' % i)))
+        Image.fromarray(B[i]).save(str(d2 / ('%03d.png' % i)))
+    s, m = metrics.compare_directories(str(d1), str(d2), DEV, batch_size=5)
+    ta = torch.from_numpy(A).permute(0, 3, 1, 2).float() / 255
+    tb = torch.from_numpy(B).permute(0, 3, 1, 2).float() / 255
+    s_ref = float(M.ssim(ta, tb).mean())
+    m_ref = float(((ta - tb) ** 2).mean())
+    net = metrics.InceptionV3([0], state_dict=inception_state_dict(3)).to(DEV)          # 64-dim features: 12 samples suffice
+    f_self = metrics.calculate_fid_given_paths([str(d1), str(d1)], 5, DEV, 64, model=net)
+    f_ab = metrics.calculate_fid_given_paths([str(d1), str(d2)], 5, DEV, 64, model=net)
+    metrics.save_fid_stats([str(d1), str(tmp_path / 'a_stats.npz')], 5, DEV, 64, model=net)
+    f_npz = metrics.calculate_fid_given_paths([str(tmp_path / 'a_stats.npz'), str(d2)], 5, DEV, 64, model=net)
+    report['e2e/ssim_fid_paths'] = dict(ssim=s, ssim_ref=s_ref, mse=m, mse_ref=m_ref, fid_self=f_self, fid_ab=f_ab, fid_npz=f_npz)
+    assert abs(s - s_ref) < 1e-5 and abs(m - m_ref) < 1e-6 * max(m_ref, 1e-9) + 1e-9
+    assert abs(f_self) < 1e-3 and f_ab > 0 and abs(f_ab - f_npz) < 1e-6 * max(f_ab, 1.0)

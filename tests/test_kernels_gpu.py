@@ -615,3 +615,58 @@ def test_input_pipeline_kernel_bit_exact(ops, report):
     for b0, b1 in zip(data.DeviceLoader(ds, 4, DEV, seed=9, rank=0, world=2), data.DeviceLoader(ds, 4, DEV, seed=9, rank=1, world=2)):
         two += [b0, b1]
     assert torch.equal(one, torch.cat(two)) and one.shape == (20, 3, 32, 32)
+
+
+def test_pool_resize_ssim_kernels(ops, report):
+    """Row f3 glue kernels against PyTorch: pooling with TensorFlow-style averages, ATen-exact bilinear resize, SSIM, MSE."""
+    import importlib
+    from oracle import metrics_ref as M
+    metrics = importlib.import_module('diff-pruning_amd.metrics')
+    x = rnd(3, 20, 35, 35, seed=1)
+    xd = x.double().cpu()
+    res = {}
+    res['avg_3_1_1'] = relerr(metrics.pool2d(x, 3, 1, 1, 'avg'), F.avg_pool2d(xd, 3, 1, 1, count_include_pad=False))
+    res['max_3_1_1'] = relerr(metrics.pool2d(x, 3, 1, 1, 'max'), F.max_pool2d(xd, 3, 1, 1))
+    res['max_3_2_0'] = relerr(metrics.pool2d(x, 3, 2, 0, 'max'), F.max_pool2d(xd, 3, 2))
+    view = rnd(2, 30, 17, 17, seed=2)[:, 4:20]
+    res['max_view'] = relerr(metrics.pool2d(view, 3, 2, 0, 'max'), F.max_pool2d(view.double().cpu(), 3, 2))
+    img = torch.rand(4, 3, 32, 32, device=DEV)
+    got = metrics.resize_bilinear(img, (299, 299), 2.0, -1.0)
+    want = 2 * F.interpolate(img.cpu(), size=(299, 299), mode='bilinear', align_corners=False) - 1
+    res['resize_299'] = float((got.cpu() - want).abs().max())
+    img2 = torch.rand(2, 3, 300, 280, device=DEV)
+    res['resize_down'] = float((metrics.resize_bilinear(img2, (299, 299)).cpu()
+                                - F.interpolate(img2.cpu(), size=(299, 299), mode='bilinear', align_corners=False)).abs().max())
+    a = torch.rand(5, 3, 32, 32, device=DEV)
+    b = (a + 0.1 * torch.randn_like(a)).clamp(0, 1)
+    res['ssim_32'] = relerr(metrics.ssim(a, b), M.ssim(a.cpu(), b.cpu()))
+    a2 = torch.rand(2, 3, 70, 45, device=DEV)
+    b2 = (a2 + 0.2 * torch.randn_like(a2)).clamp(0, 1)
+    res['ssim_70x45'] = relerr(metrics.ssim(a2, b2), M.ssim(a2.cpu(), b2.cpu()))
+    res['ssim_self'] = float((metrics.ssim(a, a) - 1).abs().max())
+    res['mse'] = relerr(metrics.mse_per_image(a, b), F.mse_loss(a.double().cpu(), b.double().cpu(), reduction='none').mean(dim=(1, 2, 3)))
+    report['metrics_kernels'] = res
+    assert res['resize_299'] < 2e-6 and res['resize_down'] < 2e-6 and res['ssim_self'] < 1e-5
+    assert max(res['avg_3_1_1'], res['max_3_1_1'], res['max_3_2_0'], res['max_view'], res['ssim_32'], res['ssim_70x45'], res['mse']) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(5, 3, 1, 7, 1, 0, 3), (4, 24, 7, 1, 1, 3, 0), (3, 16, 5, 5, 1, 2, 2), (3, 8, 3, 3, 2, 0, 0),
+                                   (2, 32, 1, 3, 1, 0, 1), (2, 48, 1, 1, 1, 0, 0)], ids=str)
+def test_general_conv_forward_relu(ops, report, shape):
+    """Non-square / valid / strided forward convolutions with the bias + ReLU epilogue (the FID Inception's BasicConv2d)."""
+    N, Cin, kh, kw, stride, ph, pw = shape
+    Cout, H, W = 40, 17, 17
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, kh, kw, seed=2, scale=1.0 / math.sqrt(Cin * kh * kw))
+    b = rnd(Cout, seed=3)
+    spec = ops.ConvSpec.general(kh, kw, stride, ph, pw)
+    wp, ld = ops.pack_weight(w, 0)
+    y = ops.conv_forward(x, None, wp, ld, Cout, spec, bias=b, relu=True)
+    ref = F.relu(F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=stride, padding=(ph, pw)))
+    assert y.shape == ref.shape
+    e = relerr(y, ref)
+    big = torch.zeros(N, Cout + 6, y.shape[2], y.shape[3], device=DEV)
+    ops.conv_forward(x, None, wp, ld, Cout, spec, bias=b, relu=True, out=big[:, 3:3 + Cout])
+    e2 = relerr(big[:, 3:3 + Cout], ref)
+    report['conv_general/%s' % (shape,)] = dict(fwd=e, slice=e2)
+    assert max(e, e2) < 2e-5 and float(big[:, :3].abs().max()) == 0
