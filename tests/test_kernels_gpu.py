@@ -610,11 +610,13 @@ def test_input_pipeline_kernel_bit_exact(ops, report):
     assert not bad, bad
     # loader end to end on the device: two ranks == one global batch
     ds = data.ArrayDataset(rng.integers(0, 256, (20, 3, 32, 32), dtype=np.uint8), hwc=False)
-    one = torch.cat(list(data.DeviceLoader(ds, 8, DEV, seed=9)))
-    two = []
-    for b0, b1 in zip(data.DeviceLoader(ds, 4, DEV, seed=9, rank=0, world=2), data.DeviceLoader(ds, 4, DEV, seed=9, rank=1, world=2)):
-        two += [b0, b1]
-    assert torch.equal(one, torch.cat(two)) and one.shape == (20, 3, 32, 32)
+    one = list(data.DeviceLoader(ds, 8, DEV, seed=9))
+    r0 = list(data.DeviceLoader(ds, 4, DEV, seed=9, rank=0, world=2))
+    r1 = list(data.DeviceLoader(ds, 4, DEV, seed=9, rank=1, world=2))
+    assert [b.shape[0] for b in one] == [8, 8, 4] and len(r0) == 3 and len(r1) == 2       # the last global batch holds 4 samples
+    for a, b0, b1 in zip(one, r0, r1):
+        assert torch.equal(a, torch.cat([b0, b1]))
+    assert torch.equal(one[2], r0[2])
 
 
 def test_pool_resize_ssim_kernels(ops, report):
