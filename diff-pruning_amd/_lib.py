@@ -53,7 +53,7 @@ class Dropout(C.Structure):
 
 class ColsumItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('wstride', C.c_int),
-                ('woff', C.c_int), ('accumulate', C.c_int), ('_pad', C.c_int)]
+                ('woff', C.c_int), ('accumulate', C.c_int), ('ld', C.c_int)]
 
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, LL
@@ -69,7 +69,7 @@ SIGNATURES = {
     'dp_pack_weight': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
     'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _dr, _vp],
     'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
-                              _vp, _ll, _vp, _dr, _vp],
+                              _vp, _ll, _vp, _dr, _vp, _vp],
     'dp_groupnorm_silu_fwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _i, _vp, _dr,
                                     _vp],
     'dp_groupnorm_silu_bwd_split': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,

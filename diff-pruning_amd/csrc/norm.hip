@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
                                                      float* __restrict__ dx, long long dx_img_stride,
                                                      const float* __restrict__ add1, long long add1_s,
                                                      const float* __restrict__ add2, long long add2_s,
-                                                     float* __restrict__ pws, DpDrop drop) {
+                                                     float* __restrict__ pws, DpDrop drop, float* __restrict__ rows) {
     __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
@@ -268,23 +268,32 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnSrc src, const float* __r
     a *= invM;
     b *= invM;
 
-    // pass 2
-    const int cnt = cpg * HW;
+    // pass 2: one wavefront per channel (as pass 1), so that the per-(image, channel) sum of the OUTPUT -- the bias / time-
+    // embedding-projection gradient rows of the layer below -- falls out of a wave reduction (rows, optional)
     float* dxb = dx + (long long)n * dx_img_stride + (long long)c_base * HW;
     const float* a1b = add1 ? add1 + (long long)n * add1_s + (long long)c_base * HW : nullptr;
     const float* a2b = add2 ? add2 + (long long)n * add2_s + (long long)c_base * HW : nullptr;
-    for (int e = tid; e < cnt; e += 256) {
-        const int cl = e / HW;
+    for (int cl = wave; cl < cpg; cl += 4) {
         const int c = c_base + cl;
-        const float xh = (gn_chan_ptr(src, n, c, HW)[e - cl * HW] - mean) * rstd;
-        const float ga = gamma[c];
-        float d = dzb[(long long)c_base * HW + e];
-        if (drop.thr24) d *= dp_drop1(drop, didx0 + e);
-        if (silu) d *= dp_silu_grad(xh * ga + beta[c]);
-        float v = rstd * (ga * d - a - xh * b);
-        if (a1b) v += a1b[e];
-        if (a2b) v += a2b[e];
-        dxb[e] = v;
+        const float* xp = gn_chan_ptr(src, n, c, HW);
+        const float ga = gamma[c], be = beta[c];
+        float rs = 0.f;
+        for (int i = lane; i < HW; i += 64) {
+            const int e = cl * HW + i;
+            const float xh = (xp[i] - mean) * rstd;
+            float d = dzb[(long long)c_base * HW + e];
+            if (drop.thr24) d *= dp_drop1(drop, didx0 + e);
+            if (silu) d *= dp_silu_grad(xh * ga + be);
+            float v = rstd * (ga * d - a - xh * b);
+            if (a1b) v += a1b[e];
+            if (a2b) v += a2b[e];
+            dxb[e] = v;
+            rs += v;
+        }
+        if (rows) {
+            rs = dp_wave_sum(rs);
+            if (lane == 0) rows[(long long)n * C + c] = rs;
+        }
     }
 }
 
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
                                                           int HW, int G, int silu, float* __restrict__ dx,
                                                           long long dx_img_stride, const float* __restrict__ add1,
                                                           long long add1_s, const float* __restrict__ add2, long long add2_s,
-                                                          float* __restrict__ pws, DpDrop drop) {
+                                                          float* __restrict__ pws, DpDrop drop, float* __restrict__ rows) {
     __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
     const int n = blockIdx.x / G;
     const int g = blockIdx.x - n * G;
@@ -348,25 +357,34 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
     const float invM = 1.0f / (float)(cpg * HW);
     a *= invM;
     b *= invM;
-    const int cnt4 = cpg * HW4;
+    // pass 2: one wavefront per channel; optional per-(image, channel) sums of the output (see gn_bwd_kernel)
     float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
     const float4* dzc = reinterpret_cast<const float4*>(dzb + (long long)c_base * HW);
     const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
     const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
-    for (int e = tid; e < cnt4; e += 256) {
-        const int cl = e / HW4;
+    for (int cl = wave; cl < cpg; cl += 4) {
         const int c = c_base + cl;
-        const float ga = gamma[c];
-        float4 xh;
-        const float4 d = dyv(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4], dzc[e], ga, beta[c], xh, e);
-        float4 v;
-        v.x = rstd * (ga * d.x - a - xh.x * b);
-        v.y = rstd * (ga * d.y - a - xh.y * b);
-        v.z = rstd * (ga * d.z - a - xh.z * b);
-        v.w = rstd * (ga * d.w - a - xh.w * b);
-        if (a1b) { const float4 t = a1b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        if (a2b) { const float4 t = a2b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        dxb[e] = v;
+        const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
+        const float ga = gamma[c], be = beta[c];
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+        for (int i = lane; i < HW4; i += 64) {
+            const int e = cl * HW4 + i;
+            float4 xh;
+            const float4 d = dyv(xp[i], dzc[e], ga, be, xh, e);
+            float4 v;
+            v.x = rstd * (ga * d.x - a - xh.x * b);
+            v.y = rstd * (ga * d.y - a - xh.y * b);
+            v.z = rstd * (ga * d.z - a - xh.z * b);
+            v.w = rstd * (ga * d.w - a - xh.w * b);
+            if (a1b) { const float4 t = a1b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (a2b) { const float4 t = a2b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            dxb[e] = v;
+            r0 += v.x; r1 += v.y; r2 += v.z; r3 += v.w;
+        }
+        if (rows) {
+            const float rs = dp_wave_sum((r0 + r1) + (r2 + r3));
+            if (lane == 0) rows[(long long)n * C + c] = rs;
+        }
     }
 }
 
@@ -375,7 +393,7 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
                                      const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
                                      float* dx, long long dx_img_stride, const float* add1, long long add1_img_stride,
                                      const float* add2, long long add2_img_stride, float* pws, const dp_dropout* drop,
-                                     void* stream) {
+                                     float* rows, void* stream) {
     if (N <= 0 || C <= 0) return 0;
     if (C % G || C / G > GN_MAXCPG) return (int)hipErrorInvalidValue;
     const DpDrop dd = dp_drop_host(drop);
@@ -386,11 +404,11 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     if (vec4)
         DP_LAUNCH(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                           pws, dd);
+                           pws, dd, rows);
     else
         DP_LAUNCH(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                           pws, dd);
+                           pws, dd, rows);
     return DP_LAUNCH_CHECK();
 }
 
@@ -666,18 +684,19 @@ __global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumBatch b) 
     const int wave = threadIdx.x >> 6;
     const int c = ((int)blockIdx.x - b.blk_start[i]) * 64 + lane;
     const int N = it.N, C = it.C, wstride = it.wstride, woff = it.woff;
+    const int ld = it.ld ? it.ld : C;                      // row pitch in (n, c) elements: a column slice of a wider [N][ld] matrix
     const float* __restrict__ ws = it.src;
     float s = 0.f;
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int n = wave;
         for (; n + 12 < N; n += 16) {
-            s0 += ws[((long long)n * C + c) * wstride + woff];
-            s1 += ws[((long long)(n + 4) * C + c) * wstride + woff];
-            s2 += ws[((long long)(n + 8) * C + c) * wstride + woff];
-            s3 += ws[((long long)(n + 12) * C + c) * wstride + woff];
+            s0 += ws[((long long)n * ld + c) * wstride + woff];
+            s1 += ws[((long long)(n + 4) * ld + c) * wstride + woff];
+            s2 += ws[((long long)(n + 8) * ld + c) * wstride + woff];
+            s3 += ws[((long long)(n + 12) * ld + c) * wstride + woff];
         }
-        for (; n < N; n += 4) s0 += ws[((long long)n * C + c) * wstride + woff];
+        for (; n < N; n += 4) s0 += ws[((long long)n * ld + c) * wstride + woff];
         s = (s0 + s1) + (s2 + s3);
     }
     part[wave][lane] = s;

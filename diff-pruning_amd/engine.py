@@ -118,6 +118,10 @@ class UNetEngine:
         # bias / GroupNorm-parameter gradient sums are queued during the backward pass and reduced together at its end
         self.defer_colsum = not os.environ.get('DP_NO_COLSUM_BATCH')
         self._cq = None
+        # the GroupNorm backward kernels also emit the per-(image, channel) sums of their output: the bias and time-embedding
+        # projection gradients of the layer below need exactly those, and a separate row-sum pass would re-read the tensor
+        self.fuse_rows = not os.environ.get('DP_NO_FUSED_ROWS')
+        self._rows_src = None
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -134,11 +138,39 @@ class UNetEngine:
         return ops.dropout_desc(self.dropout.get(site, 0.0), self.drop_seed, site, self.drop_step, self.drop_n_off)
 
     def _colsum(self, ws, N, C, wstride, woff, out):
-        """out[c] += sum_n ws[(n*C + c)*wstride + woff] -- now, or with everything else at the end of backward()."""
+        """out[c] += sum_n ws[(n*C + c)*wstride + woff] -- now, or with everything else at the end of backward().
+        ws may be a column slice [N, C] of a wider row-major matrix (wstride == 1)."""
+        ld = 0
+        if ws.dim() == 2 and wstride == 1 and ws.stride(0) != C:
+            if self._cq is None:
+                ws = ws.contiguous()
+            else:
+                ld = ws.stride(0)
         if self._cq is not None:
-            self._cq.add(ws, N, C, wstride, woff, out, True)
+            self._cq.add(ws, N, C, wstride, woff, out, True, ld)
         else:
             ops.colsum_accum(ws, N, C, wstride, woff, out, True)
+
+    def _rows_of(self, t):
+        """Per-(image, channel) sums of gradient tensor `t` if the GroupNorm backward that produced it (or the wider tensor `t`
+        is the leading channel slice of) also emitted them; else one dp_rowsum_nc pass."""
+        src = self._rows_src
+        if src is not None:
+            full, rows = src
+            if t.data_ptr() == full.data_ptr() and t.shape[0] == full.shape[0] and t.shape[2:] == full.shape[2:] \
+                    and t.stride() == full.stride() and t.shape[1] <= full.shape[1]:
+                return rows if t.shape[1] == full.shape[1] else rows[:, :t.shape[1]]
+        return ops.rowsum_nc(t)
+
+    def _gn_bwd(self, x, x2, gamma, beta, stats, dz, G, silu, **kw):
+        """groupnorm_bwd that remembers the row sums of its output for the next layer's bias / temb gradients."""
+        if self.fuse_rows and hasattr(ops, 'ColsumQueue'):
+            dx, pws, rows = ops.groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, want_rows=True, **kw)
+            self._rows_src = (dx, rows) if rows is not None else None
+        else:
+            dx, pws = ops.groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, **kw)
+            self._rows_src = None
+        return dx, pws
 
     def _begin_backward(self):
         self._cq = ops.ColsumQueue() if (self.defer_colsum and hasattr(ops, 'ColsumQueue')) else None
@@ -203,12 +235,16 @@ class UNetEngine:
         """Accumulate weight / bias gradients of conv `name`; return gradient w.r.t. its (virtual) input."""
         w = self.P[name + '.weight']
 
+        if rows is None and (name + '.bias') in self.P and self._rows_src is not None and self._rows_src[0].data_ptr() == dy.data_ptr():
+            rows = self._rows_of(dy)               # dy came out of a GroupNorm backward that already summed it
+
         def param_grads(rows):
             ops.conv_wgrad(dy, x, x2, self.G[name + '.weight'], spec, alpha=alpha, accumulate=True)
             if (name + '.bias') in self.P:
                 if rows is None:
                     rows = ops.rowsum_nc(dy)
                 if alpha != 1.0:
+                    rows = rows.contiguous()
                     rows = ops.axpby(rows, alpha, torch.empty_like(rows), 0.0)
                 self._colsum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'])
 
@@ -262,14 +298,14 @@ class UNetEngine:
         d = dout
         if out_scale != 1.0:
             d = ops.axpby(dout.contiguous(), 1.0 / out_scale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
-        rows_d = ops.rowsum_nc(d)
+        rows_d = self._rows_of(d)
         dn2 = self._conv_bwd(pre + nm['conv2'], d, n2, None, _SPEC3, hw, rows=rows_d)
-        dh, pws2 = ops.groupnorm_bwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], st2, dn2, G, True,
-                                     drop=drop)
+        dh, pws2 = self._gn_bwd(h, None, P[pre + nm['norm2'] + '.weight'], P[pre + nm['norm2'] + '.bias'], st2, dn2, G, True,
+                                drop=drop)
         self._gn_param_grads(pre + nm['norm2'], pws2)
         del dn2
         # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
-        rows_h = ops.rowsum_nc(dh)
+        rows_h = self._rows_of(dh)
         self._linear_bwd(pre + nm['temb'], rows_h, semb, dx_out=d_semb, dx_accumulate=True)
         dn1 = self._conv_bwd(pre + nm['conv1'], dh, n1, None, _SPEC3, hw, rows=rows_h)
         del dh
@@ -277,8 +313,8 @@ class UNetEngine:
             add1 = self._conv_bwd(pre + nm['shortcut'], d, xa, xb, _SPEC1, hw, rows=rows_d)
         else:
             add1 = d
-        dx, pws1 = ops.groupnorm_bwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], st1, dn1, G,
-                                     True, add1=add1, add2=extra)
+        dx, pws1 = self._gn_bwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], st1, dn1, G,
+                                True, add1=add1, add2=extra)
         self._gn_param_grads(pre + nm['norm1'], pws1)
         return dx
 
@@ -343,8 +379,8 @@ class UNetEngine:
         for dproj, name in ((dq, '.to_q'), (dk, '.to_k'), (dv, '.to_v')):
             self._conv_bwd(pre + name, dproj.view(N, inner, H, W), n, None, _SPEC1, hw, dx_out=dn, dx_accumulate=not first)
             first = False
-        dx, pws = ops.groupnorm_bwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], st, dn, G, False,
-                                    add1=d, add2=extra)
+        dx, pws = self._gn_bwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], st, dn, G, False,
+                               add1=d, add2=extra)
         self._gn_param_grads(pre + '.group_norm', pws)
         return dx
 

@@ -629,8 +629,9 @@ def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None, drop=None):
     return out, stats
 
 
-def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None, drop=None):
-    """Returns (dx [N, C, H, W], pws [N, C, 2]); dgamma = sum_n pws[..., 1], dbeta = sum_n pws[..., 0]."""
+def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None, drop=None, want_rows=False):
+    """Returns (dx [N, C, H, W], pws [N, C, 2]); dgamma = sum_n pws[..., 1], dbeta = sum_n pws[..., 0].
+    want_rows: also return rows [N, C] = sum_hw dx (or None when the split kernels ran) as a third value."""
     s1 = _chk_act(x)
     N, C1, H, W = x.shape
     s2, C2 = 0, 0
@@ -651,14 +652,15 @@ def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=Non
                                                    N, Cc, H * W, G, 1 if silu else 0, _p(out), so, _p(add1), sa1,
                                                    _p(add2), sa2, _p(pws), sl, _p(ws), _dref(drop), _stream()),
                 'dp_groupnorm_silu_bwd_split')
-        return out, pws
+        return (out, pws, None) if want_rows else (out, pws)
+    rows = torch.empty((N, Cc), dtype=_f32, device=x.device) if want_rows else None
     L.check(_lib().dp_groupnorm_silu_bwd(_p(x), _p(x2), C1, s1, s2, _p(gamma), _p(beta), _p(stats), _p(dz), _chk_act(dz),
                                          N, Cc, H * W, G, 1 if silu else 0, _p(out), _chk_act(out),
                                          _p(add1), (_chk_act(add1) if add1 is not None else 0),
                                          _p(add2), (_chk_act(add2) if add2 is not None else 0), _p(pws), _dref(drop),
-                                         _stream()),
+                                         _p(rows), _stream()),
             'dp_groupnorm_silu_bwd')
-    return out, pws
+    return (out, pws, rows) if want_rows else (out, pws)
 
 
 def colsum_accum(ws, N, Cc, wstride, woff, out, accumulate=True):
@@ -674,16 +676,17 @@ class ColsumQueue:
     def __init__(self):
         self.items = []
 
-    def add(self, ws, N, Cc, wstride, woff, out, accumulate=True):
-        self.items.append((ws, N, Cc, wstride, woff, out, accumulate))
+    def add(self, ws, N, Cc, wstride, woff, out, accumulate=True, ld=0):
+        self.items.append((ws, N, Cc, wstride, woff, out, accumulate, ld))
 
     def flush(self):
         n = len(self.items)
         if not n:
             return
         arr = (L.ColsumItem * n)()
-        for a, (ws, N, Cc, wstride, woff, out, acc) in zip(arr, self.items):
+        for a, (ws, N, Cc, wstride, woff, out, acc, ld) in zip(arr, self.items):
             a.src, a.dst, a.N, a.C, a.wstride, a.woff, a.accumulate = ws.data_ptr(), out.data_ptr(), N, Cc, wstride, woff, 1 if acc else 0
+            a.ld = ld
         L.check(_lib().dp_colsum_accum_batch(arr, n, _stream()), 'dp_colsum_accum_batch')
         self.items = []
 

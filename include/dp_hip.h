@@ -131,7 +131,9 @@ int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long lo
                           int N, int C, int HW, int G, int silu,
                           float* dx, long long dx_img_stride,
                           const float* add1, long long add1_img_stride, const float* add2, long long add2_img_stride,
-                          float* pws, const dp_dropout* drop, void* stream);
+                          float* pws, const dp_dropout* drop, float* rows, void* stream);
+/* rows (optional, [N][C]): rows[n*C + c] = sum_hw dx[n][c][hw] -- the bias / time-embedding-projection gradient rows of the
+ * layer that produced x fall out of the same pass (otherwise a separate dp_rowsum_nc re-reads dx). */
 
 /* The same two operations for FEW, LARGE groups (e.g. 256x256 images at batch 4: N*G = 128 groups of 1 MB): the work unit
  * is one of `slices` equal slices of one channel plane, partial statistics go through ws and are combined in a fixed
@@ -152,9 +154,10 @@ int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int c_split, l
 int dp_colsum_accum(const float* ws, int N, int C, int wstride, int woff, float* out, int accumulate, void* stream);
 
 /* The same for n independent items in one launch (per 80 items): dst[c] (+)= sum_n src[(n*C + c)*wstride + woff].  The host
- * queues the bias / GroupNorm-parameter gradient sums of a whole backward pass and flushes them together. */
+ * queues the bias / GroupNorm-parameter gradient sums of a whole backward pass and flushes them together.
+ * With ld != 0 element (n, c) sits at src[(n*ld + c)*wstride + woff] (a column slice of a wider matrix). */
 typedef struct dp_colsum_item {
-    const float* src; float* dst; int N, C, wstride, woff, accumulate, _pad;
+    const float* src; float* dst; int N, C, wstride, woff, accumulate, ld;   /* ld: row pitch in elements, 0 = C */
 } dp_colsum_item;
 int dp_colsum_accum_batch(const dp_colsum_item* items, int n, void* stream);
 

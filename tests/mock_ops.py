@@ -163,7 +163,7 @@ def groupnorm_fwd(x, x2, gamma, beta, G, eps, silu, out=None, drop=None):
     return y, torch.stack([mean, rstd], -1).reshape(N * G, 2)
 
 
-def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None, drop=None):
+def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=None, out=None, drop=None, want_rows=False):
     if drop is not None:
         dz = dz * _mult(dz, drop)
     xc = _cat(x, x2)
@@ -186,7 +186,22 @@ def groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, *, add1=None, add2=Non
         dx = dx + add1
     if add2 is not None:
         dx = dx + add2
+    if want_rows:
+        return dx.contiguous(), torch.stack([s1, s2], -1).contiguous(), dx.sum((2, 3))
     return dx.contiguous(), torch.stack([s1, s2], -1).contiguous()
+
+
+class ColsumQueue:
+    """CPU stand-in of ops.ColsumQueue: applies the sums immediately (a column slice arrives as a strided 2-D view)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, ws, N, Cc, wstride, woff, out, accumulate=True, ld=0):
+        colsum_accum(ws.contiguous() if ld else ws, N, Cc, wstride, woff, out, accumulate)
+
+    def flush(self):
+        pass
 
 
 def colsum_accum(ws, N, C, wstride, woff, out, accumulate=True):

@@ -672,3 +672,21 @@ def test_general_conv_forward_relu(ops, report, shape):
     e2 = relerr(big[:, 3:3 + Cout], ref)
     report['conv_general/%s' % (shape,)] = dict(fwd=e, slice=e2)
     assert max(e, e2) < 2e-5 and float(big[:, :3].abs().max()) == 0
+
+
+@pytest.mark.parametrize('N,C1,C2,H,G', [(3, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8), (4, 256, 0, 16, 32)], ids=str)
+def test_groupnorm_bwd_row_sums(ops, report, N, C1, C2, H, G):
+    """The GroupNorm backward kernels also emit rows[n, c] = sum_hw dx (the next layer's bias / time-embedding-projection
+    gradient rows): equal to a separate row-sum pass over dx up to summation order, and dx itself is unchanged."""
+    xa = rnd(N, C1, H, H, seed=1) + 0.3
+    xb = rnd(N, C2, H, H, seed=2) if C2 else None
+    Cc = C1 + C2
+    gamma, beta = 1 + 0.2 * rnd(Cc, seed=3), 0.1 * rnd(Cc, seed=4)
+    y, stats = ops.groupnorm_fwd(xa, xb, gamma, beta, G, 1e-6, True)
+    dz, add1 = rnd(*y.shape, seed=5), rnd(*y.shape, seed=6)
+    dx0, pws0 = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, True, add1=add1)
+    dx, pws, rows = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, True, add1=add1, want_rows=True)
+    assert torch.equal(dx, dx0) and torch.equal(pws, pws0) and rows.shape == (N, Cc)
+    e = relerr(rows, dx.double().cpu().sum((2, 3)))
+    report['gn_rows/%d_%d_%d_%d' % (N, C1, C2, H)] = e
+    assert e < 1e-5
