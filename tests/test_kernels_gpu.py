@@ -674,7 +674,7 @@ def test_general_conv_forward_relu(ops, report, shape):
     assert max(e, e2) < 2e-5 and float(big[:, :3].abs().max()) == 0
 
 
-@pytest.mark.parametrize('N,C1,C2,H,G', [(3, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8), (4, 256, 0, 16, 32)], ids=str)
+@pytest.mark.parametrize('N,C1,C2,H,G', [(40, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8), (4, 256, 0, 16, 32), (3, 128, 0, 32, 32)], ids=str)
 def test_groupnorm_bwd_row_sums(ops, report, N, C1, C2, H, G):
     """The GroupNorm backward kernels also emit rows[n, c] = sum_hw dx (the next layer's bias / time-embedding-projection
     gradient rows): equal to a separate row-sum pass over dx up to summation order, and dx itself is unchanged."""
@@ -686,7 +686,11 @@ def test_groupnorm_bwd_row_sums(ops, report, N, C1, C2, H, G):
     dz, add1 = rnd(*y.shape, seed=5), rnd(*y.shape, seed=6)
     dx0, pws0 = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, True, add1=add1)
     dx, pws, rows = ops.groupnorm_bwd(xa, xb, gamma, beta, stats, dz, G, True, add1=add1, want_rows=True)
-    assert torch.equal(dx, dx0) and torch.equal(pws, pws0) and rows.shape == (N, Cc)
+    assert torch.equal(dx, dx0) and torch.equal(pws, pws0)
+    if rows is None:                      # few large groups: the split kernels ran (no fused sums; the engine falls back)
+        assert N * G < ops.GN_SPLIT_GROUPS and H * H >= 1024
+        return
+    assert rows.shape == (N, Cc)
     e = relerr(rows, dx.double().cpu().sum((2, 3)))
     report['gn_rows/%d_%d_%d_%d' % (N, C1, C2, H)] = e
     assert e < 1e-5
