@@ -122,6 +122,7 @@ class UNetEngine:
         # projection gradients of the layer below need exactly those, and a separate row-sum pass would re-read the tensor
         self.fuse_rows = not os.environ.get('DP_NO_FUSED_ROWS')
         self._rows_src = None
+        self.segment_hook = None
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -174,6 +175,17 @@ class UNetEngine:
 
     def _begin_backward(self):
         self._cq = ops.ColsumQueue() if (self.defer_colsum and hasattr(ops, 'ColsumQueue')) else None
+
+    def segment_done(self, segment):
+        """backward() reached the end of a segment ('up': output head + up blocks, 'mid', 'down'): all of that segment's
+        parameter gradients are final once the weight-gradient stream is joined and the queued sums are flushed.  The
+        data-parallel finetune step hangs its bucketed gradient all-reduce here (train.FinetuneEngine)."""
+        if self.segment_hook is None:
+            return
+        self._join_side()
+        if self._cq is not None:
+            self._cq.flush()
+        self.segment_hook(segment)
 
     def _end_backward(self):
         """Join the weight-gradient stream, then flush the queued sums (their sources were produced on either stream)."""
@@ -488,6 +500,7 @@ class UNetEngine:
                 order.append(blk[Lr - j])          # local was filled for j = Lr .. 0
         sg = {n_skips - 1 - k: g for k, g in enumerate(order)}     # skips index -> grad view
 
+        self.segment_done('up')
         msf = float(cfg.get('mid_block_scale_factor', 1))
         dx = self.resnet_bwd('mid_block.resnets.1', dx, semb, d_semb)
         if cfg.get('add_attention', True):
@@ -495,6 +508,7 @@ class UNetEngine:
         # mid resnet 0 consumes skips[-1] (the last down output) together with the up path
         idx = n_skips - 1
         dx = self.resnet_bwd('mid_block.resnets.0', dx, semb, d_semb, extra=sg.pop(idx))
+        self.segment_done('mid')
         for i in reversed(range(nb)):
             bt = cfg['down_block_types'][i]
             pre = 'down_blocks.%d' % i
@@ -512,6 +526,7 @@ class UNetEngine:
                 idx -= 1
                 dx = self.resnet_bwd('%s.resnets.%d' % (pre, j), dx, semb, d_semb, extra=sg.pop(idx))
         assert idx == 0 and not sg
+        self.segment_done('down')
         self._conv_bwd('conv_in', dx, sample, None, _SPEC3, None, need_dx=False)
         # time embedding MLP (embeddings.py:200-212)
         d_emb = ops.silu_bwd(emb, d_semb)

@@ -158,6 +158,19 @@ class FinetuneEngine:
             p.data = self.flat_p[off:off + n].view_as(p)
             p.grad = self.flat_g[off:off + n].view_as(p)
             off += n
+        # gradient buckets of the data-parallel step: contiguous ranges of the flat gradient buffer that become final at the three
+        # milestones of the backward pass (output head + up blocks, mid block, down blocks) and at its end (conv_in, time embedding)
+        self._buckets = {'up': [], 'mid': [], 'down': [], 'rest': []}
+        off = 0
+        for name, p in model.named_parameters():
+            seg = ('up' if name.startswith(('up_blocks.', 'conv_norm_out.', 'conv_out.')) else
+                   'mid' if name.startswith('mid_block.') else 'down' if name.startswith('down_blocks.') else 'rest')
+            rs = self._buckets[seg]
+            if rs and rs[-1][1] == off:
+                rs[-1][1] = off + p.numel()
+            else:
+                rs.append([off, off + p.numel()])
+            off += p.numel()
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.ema = self.flat_p.clone() if use_ema else None
@@ -219,9 +232,22 @@ class FinetuneEngine:
         self.flat_g.zero_()                               # optimizer.zero_grad()
         out = eng.forward(noisy, t, save=True)
         loss, dout = ops.mse_fwd_bwd(out, noise, 2.0 / gb, 1.0 / gb)
-        eng.backward(dout)
+        pending = []
         if use_dist:
-            dist.all_reduce(self.flat_g, group=self.group)      # sum of per-shard gradients of the global-mean loss
+            # bucketed all-reduce overlapped with the backward pass: each bucket's collective (RCCL over xGMI) is enqueued as
+            # soon as its gradients are final and runs while the remaining layers' MFMA kernels execute
+            def reduce_segment(seg):
+                for lo, hi in self._buckets[seg]:
+                    pending.append(dist.all_reduce(self.flat_g[lo:hi], group=self.group, async_op=True))
+            eng.segment_hook = reduce_segment
+        try:
+            eng.backward(dout)
+        finally:
+            eng.segment_hook = None
+        if use_dist:
+            reduce_segment('rest')
+            for w in pending:                                   # stream-ordered wait for RCCL (blocks the host for gloo)
+                w.wait()
         partial = ops.sumsq_partials(self.flat_g)
         nc = ops.clip_coef(partial, self.max_grad_norm)
         self.last_grad_norm = nc[0:1]
