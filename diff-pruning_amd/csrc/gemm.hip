@@ -524,7 +524,10 @@ template <int BM, int BN, bool TAILS, bool X4>
 __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(const dp_conv_gemm_params p) {
     // BM = 128: waves 2x2, each 64x64 as interleaved 32x32 sub-tiles (64 apart).  BM = 96 (pruned widths such as 90 or
     // 180 channels lose 30 % of a 128-row tile): waves 1x4, each all 96 rows x 32 columns.
-    static_assert((BM == 128 || BM == 96) && BN == 128, "fast path tiles: 128x128, 96x128");
+    // BN = 64 (X4 only, BM = 128): half-width tiles for launches that would otherwise be ONE round of workgroups (256-channel
+    // layers at 16x16: 1024 tiles = 4 per CU, all ramping up and storing their 64 KB outputs at the same time): twice the
+    // workgroups in two rounds overlap the prologue / epilogue of one round with the K loop of the other.
+    static_assert((BM == 128 || BM == 96) && (BN == 128 || (BN == 64 && BM == 128 && X4)), "fast path tiles: 128x128, 96x128, 128x64");
     constexpr int BK = 16;
     constexpr int WAVES_M = (BM == 128) ? 2 : 1;
     constexpr int TM = BM / 32 / WAVES_M, TN = BN / 32 / (4 / WAVES_M);
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     const unsigned a_row_bytes = (unsigned)p.lda * 4u;
     // B: pixel column bn, rows bk0 + 2*j
     const int bn = tid & (BN - 1);
-    const int bk0 = tid >> 7;
+    const int bk0 = tid / BN;
     const int bpix = n0 + bn;
     const bool bpv = bpix < p.NPIX;
     unsigned b_pix1, b_pix2, vmask = 0;
@@ -610,8 +613,10 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
                 if (dp_gather(g, ho, wo, ky, t - ky * g.kw, off)) vmask |= 1u << t;
             }
     }
-    // X4: lane = (row of the wave's pair, pixel group): pixels n0 + 4*g4 .. +3 of channel rows 8*j + 2*wave + rsub
-    const int g4 = lane & 31, rsub = lane >> 5;
+    // X4: lane = (row of the wave's group, pixel group): pixels n0 + 4*g4 .. +3 of channel rows 4*RPW*j + RPW*wave + rsub
+    constexpr int RPW = 256 / BN;                        // rows one wave-instruction covers (2 for BN = 128, 4 for BN = 64)
+    constexpr int NJ = BK / (4 * RPW);                   // 16-byte loads per lane and K tile (2 / 1)
+    const int g4 = lane & (BN / 4 - 1), rsub = lane / (BN / 4);
     unsigned x_pix1 = 0, x_pix2 = 0, vrow = 0;
     bool fix_l = false, fix_r = false;
     if constexpr (X4) {
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
         const int r = pp - img * HoWo;
         const int ho = r / g.Wo;
         const int wo = r - ho * g.Wo;
-        const unsigned lin = (unsigned)(ho * g.Ws + wo + (2 * wave + rsub) * HsWs);
+        const unsigned lin = (unsigned)(ho * g.Ws + wo + (RPW * wave + rsub) * HsWs);
         x_pix1 = (unsigned)((long long)img * g.x1_img_stride) + lin;
         x_pix2 = (unsigned)((long long)img * g.x2_img_stride) + lin;
         if (gv) {
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             fix_r = wo + 3 + (g.kw - 1 - g.pad_l) >= g.Ws;                    // the last tap column reads column Ws
         }
     }
-    unsigned b_voff[X4 ? 2 : 8];
+    unsigned b_voff[X4 ? (BK * BN / 1024) : 8];
     // (re)build the per-lane offsets for a chunk of `cw` valid channels from source `first`: rows beyond cw are
     // permanently out of range (zeros), so the K loop itself carries no channel test.  Runs only when the source or the
     // width changes (at most 4 times per workgroup).
@@ -641,8 +646,8 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
         if constexpr (X4) {
             const unsigned b = first ? x_pix1 : x_pix2;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                b_voff[j] = (8 * j + 2 * wave + rsub < cw) ? (b + (unsigned)(8 * j * HsWs)) * 4u + IMM_MAX : DP_OOB;
+            for (int j = 0; j < NJ; ++j)
+                b_voff[j] = (4 * RPW * j + RPW * wave + rsub < cw) ? (b + (unsigned)(4 * RPW * j * HsWs)) * 4u + IMM_MAX : DP_OOB;
         } else {
             const unsigned b = first ? b_pix1 : b_pix2;
 #pragma unroll
@@ -679,9 +684,8 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
     float* const ldsA = smem + 4 * (wave * 64);                 // + buf*STAGE + 1024*j   (float4 per lane)
     float* const ldsB = smem + A_SZ + bk0 * 0 + (wave & 1) * 64 + (wave >> 1) * BN;   // row bk0 = wave>>1, cols (wave&1)*64..
 
-    auto dma_tile = [&](int buf) {
+    auto dma_A = [&](int buf) {
         float* As = ldsA + buf * STAGE;
-        float* Bs = ldsB + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (256 * j + 64 * wave >= A_F4) continue;          // BM = 96: the second pass belongs to waves 0 and 1 only
@@ -689,15 +693,18 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)(As + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
         }
+    };
+    auto dma_B = [&](int buf) {
+        float* Bs = ldsB + buf * STAGE;
         const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
         if constexpr (X4) {
             const bool tv = (vrow >> kyc) & 1u;
-            float* B4 = smem + A_SZ + buf * STAGE + 2 * wave * BN;           // this wave's row pair of pass 0
+            float* B4 = smem + A_SZ + buf * STAGE + RPW * wave * BN;         // this wave's row group of pass 0
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 unsigned o = tv ? b_voff[j] : DP_OOB;
                 asm volatile("" : "+v"(o));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(B4 + 8 * j * BN), 16, (int)o, (int)b_soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dp_lds_void*)(B4 + 4 * RPW * j * BN), 16, (int)o, (int)b_soff, 0, 0);
             }
         } else {
             const bool tv = (vmask >> tap) & 1u;
@@ -710,16 +717,23 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             });
         }
     };
+    auto dma_tile = [&](int buf) { dma_A(buf); dma_B(buf); };
     // X4: zero the border element of the tile that has just landed in `buf` (tap column state = the tile's)
     const int kx_last = g.kw - 1, r_over = g.kw - 1 - g.pad_l;
     auto fix_border = [&](int buf) {
         if constexpr (X4) {
-            float* B4 = smem + A_SZ + buf * STAGE + 2 * wave * BN + 4 * lane;
+            float* B4 = smem + A_SZ + buf * STAGE + RPW * wave * BN + 4 * lane;
             if (kx == 0 && g.pad_l == 1) {
-                if (fix_l) { B4[0] = 0.f; B4[8 * BN] = 0.f; }
+                if (fix_l) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) B4[4 * RPW * j * BN] = 0.f;
+                }
             }
             if (kx == kx_last && r_over == 1) {
-                if (fix_r) { B4[3] = 0.f; B4[8 * BN + 3] = 0.f; }
+                if (fix_r) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) B4[4 * RPW * j * BN + 3] = 0.f;
+                }
             }
         }
     };
@@ -764,8 +778,17 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
 #ifndef DP_EXP_NOADV
             if (it + 1 < nIter) advance();
 #endif
-#ifndef DP_EXP_NODMA
-            dma_tile(buf ^ 1);
+            // The prefetch DMA of tile it+1 is issued INSIDE the MFMA sequence (A after k-step DP_DMA_A_KS, B after k-step
+            // DP_DMA_B_KS) instead of in front of it: the co-resident waves of a SIMD run in near lockstep (they share the
+            // matrix pipe round-robin), so a block of DMA issue slots in front of the first MFMA left the pipe idle on all of
+            // them at once.  [measured, round 2: 256->256 @16x16 119.8 -> 121.1, 128->128 @32x32 130.8 -> 134.6 TFLOP/s]
+#ifndef DP_DMA_A_KS
+#define DP_DMA_A_KS 1
+#define DP_DMA_B_KS 4
+#endif
+#if !defined(DP_EXP_NODMA)
+            if (DP_DMA_A_KS < 0) dma_A(buf ^ 1);
+            if (DP_DMA_B_KS < 0) dma_B(buf ^ 1);
 #endif
             const float* Af = fragA + buf * STAGE;
             const float* Bf = fragB + buf * STAGE;
@@ -790,6 +813,10 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if !defined(DP_EXP_NODMA)
+                if (ks == DP_DMA_A_KS) { dma_A(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+                if (ks == DP_DMA_B_KS) { dma_B(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#endif
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fix_border(buf ^ 1);
@@ -818,6 +845,14 @@ static bool conv_fast_x4(const dp_conv_gemm_params& p) {
     if (kh > 8) return false;
     if (p.ntaps == 1 && g.pad_l == 0 && g.pad_t == 0 && g.Ws == g.Wo && g.Hs == g.Ho) return (g.Ho * g.Wo) % 4 == 0;
     return g.Wo % 4 == 0 && g.Ws >= 4 && g.pad_l >= 0 && g.pad_l <= 1 && g.kw - 1 - g.pad_l >= 0 && g.kw - 1 - g.pad_l <= 1;
+}
+
+// 128x64 tiles: same kernel, half-width B tile (see the BN = 64 note in the kernel)
+static bool launch_conv_fast_n64(const dp_conv_gemm_params& p, hipStream_t st) {
+    if (!conv_fast_ok(p) || conv_fast_tails(p) || !conv_fast_x4(p)) return false;
+    dim3 grid((p.NPIX + 63) / 64, (p.M + 127) / 128, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
+    DP_LAUNCH((conv_gemm_fast_kernel<128, 64, false, true>), grid, dim3(256), dp_lds_pad(), st, p);
+    return true;
 }
 
 template <int BM, bool TAILS>
@@ -901,6 +936,9 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
                 e = DP_LAUNCH_CHECK();
                 break;
             }
+            [[fallthrough]];
+        case 4:                                                  // 128x64: fast x4 kernel only, else the 128x128 path
+            if (launch_conv_fast_n64(p, st)) { e = DP_LAUNCH_CHECK(); break; }
             [[fallthrough]];
         case 0: e = launch_conv_gemm<128, 128>(p, st); break;
         case 1: e = launch_conv_gemm<64, 128>(p, st); break;

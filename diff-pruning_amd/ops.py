@@ -65,12 +65,25 @@ def _prefer_tile96(p):
         p.tile = 3 if -(-p.M // 96) * 96 < -(-p.M // 128) * 128 else 0
 
 
+def _conv_x4_ok(p):
+    """Same rule as conv_fast_x4() in csrc/gemm.hip."""
+    g = p.g
+    if (not p.x_guard and g.pad_l > 0) or os.environ.get('DP_NO_X4') or g.kw < 1 or p.ntaps % g.kw or p.ntaps // g.kw > 8:
+        return False
+    if p.ntaps == 1 and g.pad_l == 0 and g.pad_t == 0 and g.Ws == g.Wo and g.Hs == g.Ho:
+        return (g.Ho * g.Wo) % 4 == 0
+    return g.Wo % 4 == 0 and g.Ws >= 4 and 0 <= g.pad_l <= 1 and 0 <= g.kw - 1 - g.pad_l <= 1
+
+
 def _cg_name(p):
-    if p.tile in (0, 3) and _conv_fast_ok(p):
+    if p.tile == 4 and _conv_fast_ok(p) and _conv_x4_ok(p) and p.C % 16 == 0 and not (bool(p.X2) and p.g.c_split % 16):
+        return 'conv_gemm_fast_kernel<128, 64, false, true>'
+    if p.tile in (0, 3, 4) and _conv_fast_ok(p):
         tails = p.tile == 3 or p.C % 16 != 0 or (bool(p.X2) and p.g.c_split % 16 != 0)
-        return 'conv_gemm_fast_kernel<%s, %s>' % ('128, 128' if p.tile == 0 else '96, 128', 'true' if tails else 'false')
+        return 'conv_gemm_fast_kernel<%s, %s, %s>' % ('128, 128' if p.tile != 3 else '96, 128', 'true' if tails else 'false',
+                                                      'true' if _conv_x4_ok(p) else 'false')
     straddle = bool(p.X2) and (p.g.c_split % 16) != 0
-    return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[0 if p.tile == 3 else p.tile], 'true' if p.a_kc else 'false',
+    return 'conv_gemm_kernel<%s, %s, %s>' % (_TILE_NAMES[0 if p.tile in (3, 4) else p.tile], 'true' if p.a_kc else 'false',
                                              'true' if straddle else 'false')
 
 
@@ -154,15 +167,24 @@ def pick_tile(M, N, z=1):
 
 
 CONV_SPLITK_BLOCKS = 1024      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
+_n64 = os.environ.get('DP_CONV_N64', '0')         # default off: measured null (118.7 vs 124.4 TFLOP/s in isolation, 87.4 = 87.4 ms per step)
+CONV_N64_TILES = tuple(int(v) for v in _n64.split(',')) if _n64 not in ('0', '') else None      # [lo, hi) 128x128-tile counts run as 128x64
 
 
 def _conv_ksplit(p, device):
     """Choose split-K for a non-batched conv_gemm whose tile grid would leave most CUs idle (8x8 / 4x4 resolution
     layers, small batches): big tiles keep the MFMA efficiency, the K loop supplies the parallelism."""
     p.ksplit, p.ws = 1, None
+    tiles = -(-p.M // 128) * -(-p.NPIX // 128)
+    # Experiment knob (DP_CONV_N64=lo,hi): launches of fewer than two rounds of 128x128 workgroups run as 128x64 tiles -- twice
+    # the workgroups, so that the ramp / store burst of one round overlaps the K loop of the other.  Measured null: the
+    # narrower tile loses in the K loop what the second round gains (DESIGN.md section 4).
+    if (CONV_N64_TILES and p.tile == 0 and p.batches <= 1 and CONV_N64_TILES[0] <= tiles < CONV_N64_TILES[1]
+            and _conv_fast_ok(p) and _conv_x4_ok(p) and p.C % 16 == 0 and not (bool(p.X2) and p.g.c_split % 16)):
+        p.tile = 4
+        return
     if CONV_SPLITK_BLOCKS <= 0:
         return
-    tiles = -(-p.M // 128) * -(-p.NPIX // 128)
     n_iter = p.ntaps * -(-p.C // 16)
     s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (8 if tiles >= 32 else 2))
     if s >= 2 and p.M >= 64:

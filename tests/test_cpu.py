@@ -119,8 +119,28 @@ def test_kernel_dispatch_heuristics():
     p.tile = 1
     ops._prefer_tile96(p)
     assert p.tile == 1
-    assert ops._cg_name(conv_params(256)) == 'conv_gemm_fast_kernel<128, 128, false>'
-    assert ops._cg_name(conv_params(256, C=90)) == 'conv_gemm_fast_kernel<128, 128, true>'
+    assert ops._cg_name(conv_params(256)) == 'conv_gemm_fast_kernel<128, 128, false, false>'       # x_guard not set: 4-byte loads
+    assert ops._cg_name(conv_params(256, C=90)) == 'conv_gemm_fast_kernel<128, 128, true, false>'
+    p = conv_params(256)
+    p.x_guard = 1
+    assert ops._cg_name(p) == 'conv_gemm_fast_kernel<128, 128, false, true>'
+    # 128x64 tiles for launches below two rounds of 128x128 workgroups (and no split-K then); tails / unguarded inputs keep 128x128
+    p = conv_params(256, C=256, npix=65536)
+    p.x_guard = 1
+    ops._conv_ksplit(p, None)
+    assert p.tile == 0                                                 # the 128x64 experiment is off by default
+    ops.CONV_N64_TILES = (512, 2048)
+    ops._conv_ksplit(p, None)
+    assert p.tile == 4 and p.ksplit == 1 and ops._cg_name(p) == 'conv_gemm_fast_kernel<128, 64, false, true>'
+    p = conv_params(128, npix=262144)
+    p.x_guard = 1
+    ops._conv_ksplit(p, None)
+    assert p.tile == 0 and p.ksplit == 1                               # 2048 tiles: two full rounds already
+    p = conv_params(256, C=90, npix=65536)
+    p.x_guard = 1
+    ops._conv_ksplit(p, None)
+    assert p.tile == 0
+    ops.CONV_N64_TILES = None
 
 
 def test_no_cpu_fallback():
