@@ -1226,32 +1226,42 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
     }
     float* const ldsW = smem + wave * 8 * GRP;      // this wave's first group, operand A of stage 0
 
-    auto dma_tile = [&](int it, int buf) {
+    // The 16 DMA instructions of a K tile are issued in NT_DMA_PER_KS-sized groups BETWEEN the MFMA groups of the current tile
+    // (see the note in conv_gemm_fast_kernel): tile_setup() computes the scalar state, dma_group<q>() issues group q.
+    unsigned t_a_soff = 0, t_b_soff1 = 0, t_b_soff2 = 0;
+    bool t_v = false;
+    auto tile_setup = [&](int it) {
         const int pp0 = p_begin + it * BK;
         const int img = pp0 / HoWo;
         const int r0 = pp0 - img * HoWo;
         const int ho0 = r0 / g.Wo;
         const int wo0 = r0 - ho0 * g.Wo;
-        const unsigned a_soff = (unsigned)((long long)img * p.a_img_stride + r0) * 4u;
-        const unsigned b_soff1 = (unsigned)((long long)img * g.x1_img_stride + ho0 * g.Ws + wo0) * 4u;
-        const unsigned b_soff2 = (unsigned)((long long)img * g.x2_img_stride + ho0 * g.Ws + wo0) * 4u;
-        const bool v = ((unsigned)(ho0 + hc) < (unsigned)g.Hs) && ((unsigned)(wo0 + wc) < (unsigned)g.Ws);
+        t_a_soff = (unsigned)((long long)img * p.a_img_stride + r0) * 4u;
+        t_b_soff1 = (unsigned)((long long)img * g.x1_img_stride + ho0 * g.Ws + wo0) * 4u;
+        t_b_soff2 = (unsigned)((long long)img * g.x2_img_stride + ho0 * g.Ws + wo0) * 4u;
+        t_v = ((unsigned)(ho0 + hc) < (unsigned)g.Hs) && ((unsigned)(wo0 + wc) < (unsigned)g.Ws);
+    };
+    auto dma_one = [&](auto jc, int buf) {                           // instruction jc in 0..15: 0..7 operand A, 8..15 operand B
+        constexpr int jj = decltype(jc)::value;
         float* As = ldsW + buf * STAGE;
-        float* Bs = As + OP_SZ;
-        dp_static_for<0, 8>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
+        if constexpr (jj < 8) {
+            constexpr int j = jj;
             unsigned o = a_voff[j];
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)As, 4, (int)o, (int)a_soff, j * GRP * 4, 0);
-        });
-        dp_static_for<0, 8>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            unsigned o = v ? b_voff[j] : DP_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dp_lds_void*)As, 4, (int)o, (int)t_a_soff, j * GRP * 4, 0);
+        } else {
+            constexpr int j = jj - 8;
+            float* Bs = As + OP_SZ;
+            unsigned o = t_v ? b_voff[j] : DP_OOB;
             asm volatile("" : "+v"(o));
             const bool s1 = !TWO || n0 + 4 * (wave * 8 + j) < C1p;      // scalar: the whole 4-row group is in one source
             __builtin_amdgcn_raw_ptr_buffer_load_lds(s1 ? rB1 : rB2, (dp_lds_void*)Bs, 4, (int)o,
-                                                     (int)(s1 ? b_soff1 : b_soff2), j * GRP * 4, 0);
-        });
+                                                     (int)(s1 ? t_b_soff1 : t_b_soff2), j * GRP * 4, 0);
+        }
+    };
+    auto dma_tile = [&](int it, int buf) {
+        tile_setup(it);
+        dp_static_for<0, 16>([&](auto jc) { dma_one(jc, buf); });
     };
 
     f32x16 acc[TM][TN];
@@ -1275,9 +1285,16 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
         dma_tile(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifndef NT_DMA_SPREAD
+#define NT_DMA_SPREAD 1
+#endif
         for (int it = 0; it < nIter; ++it) {
             const int buf = it & 1;
-            dma_tile(it + 1 < nIter ? it + 1 : it, buf ^ 1);       // last iteration: reloads the current tile (harmless)
+#if NT_DMA_SPREAD
+            tile_setup(it + 1 < nIter ? it + 1 : it);              // last iteration: reloads the current tile (harmless)
+#else
+            dma_tile(it + 1 < nIter ? it + 1 : it, buf ^ 1);
+#endif
             const int bo = buf * STAGE;
             float a[2][TM], b[2][TN];
 #pragma unroll
@@ -1301,6 +1318,16 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if NT_DMA_SPREAD
+                dp_static_for<0, 2>([&](auto qc) {                   // two of the 16 prefetch loads after every MFMA group
+                    constexpr int q = decltype(qc)::value;
+                    dp_static_for<0, 8>([&](auto kc) {
+                        constexpr int kk = decltype(kc)::value;
+                        if (ks == kk) dma_one(std::integral_constant<int, 2 * kk + q>{}, buf ^ 1);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
