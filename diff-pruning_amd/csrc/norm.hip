@@ -357,33 +357,52 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
     const float invM = 1.0f / (float)(cpg * HW);
     a *= invM;
     b *= invM;
-    // pass 2: one wavefront per channel; optional per-(image, channel) sums of the output (see gn_bwd_kernel)
+    // pass 2: one wavefront per channel PAIR (cl, cl + 4): both channels' loads are in flight together (a single channel per
+    // iteration left one 16-byte load per lane outstanding: 88 instead of 69 us per launch); the per-(image, channel) sums of
+    // the output (rows, optional; see gn_bwd_kernel) fall out of a wave reduction
     float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
     const float4* dzc = reinterpret_cast<const float4*>(dzb + (long long)c_base * HW);
     const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
     const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
-    for (int cl = wave; cl < cpg; cl += 4) {
-        const int c = c_base + cl;
-        const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
-        const float ga = gamma[c], be = beta[c];
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    auto finish = [&](float4 xv, float4 dv, float4 t1, float4 t2, float ga, float be, long long e) {
+        float4 xh;
+        const float4 d = dyv(xv, dv, ga, be, xh, e);
+        float4 v;
+        v.x = rstd * (ga * d.x - a - xh.x * b) + t1.x + t2.x;
+        v.y = rstd * (ga * d.y - a - xh.y * b) + t1.y + t2.y;
+        v.z = rstd * (ga * d.z - a - xh.z * b) + t1.z + t2.z;
+        v.w = rstd * (ga * d.w - a - xh.w * b) + t1.w + t2.w;
+        return v;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cl = wave; cl < cpg; cl += 8) {
+        const int cB = cl + 4 < cpg ? cl + 4 : cl;                    // second channel of the pair (== cl when there is none)
+        const bool two = cl + 4 < cpg;
+        const float4* xpA = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW));
+        const float4* xpB = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cB, HW));
+        const float gaA = gamma[c_base + cl], beA = beta[c_base + cl], gaB = gamma[c_base + cB], beB = beta[c_base + cB];
+        float rA = 0.f, rB = 0.f;
         for (int i = lane; i < HW4; i += 64) {
-            const int e = cl * HW4 + i;
-            float4 xh;
-            const float4 d = dyv(xp[i], dzc[e], ga, be, xh, e);
-            float4 v;
-            v.x = rstd * (ga * d.x - a - xh.x * b);
-            v.y = rstd * (ga * d.y - a - xh.y * b);
-            v.z = rstd * (ga * d.z - a - xh.z * b);
-            v.w = rstd * (ga * d.w - a - xh.w * b);
-            if (a1b) { const float4 t = a1b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            if (a2b) { const float4 t = a2b[e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            dxb[e] = v;
-            r0 += v.x; r1 += v.y; r2 += v.z; r3 += v.w;
+            const int eA = cl * HW4 + i, eB = cB * HW4 + i;
+            const float4 xa = xpA[i], da = dzc[eA], xb = xpB[i], db = dzc[eB];
+            const float4 pa = a1b ? a1b[eA] : zero4, qa = a2b ? a2b[eA] : zero4;
+            const float4 pb = a1b ? a1b[eB] : zero4, qb = a2b ? a2b[eB] : zero4;
+            const float4 va = finish(xa, da, pa, qa, gaA, beA, eA);
+            dxb[eA] = va;
+            rA += (va.x + va.y) + (va.z + va.w);
+            if (two) {
+                const float4 vb = finish(xb, db, pb, qb, gaB, beB, eB);
+                dxb[eB] = vb;
+                rB += (vb.x + vb.y) + (vb.z + vb.w);
+            }
         }
         if (rows) {
-            const float rs = dp_wave_sum((r0 + r1) + (r2 + r3));
-            if (lane == 0) rows[(long long)n * C + c] = rs;
+            rA = dp_wave_sum(rA);
+            rB = dp_wave_sum(rB);
+            if (lane == 0) {
+                rows[(long long)n * C + c_base + cl] = rA;
+                if (two) rows[(long long)n * C + c_base + cB] = rB;
+            }
         }
     }
 }

@@ -327,6 +327,11 @@ WGRAD_MIN_PIX = int(os.environ.get('DP_WGRAD_MIN_PIX', '128'))      # fewest pix
 
 
 def _workspace(n, device):
+    # During hipGraph capture nothing is cached: the buffer comes from the graph's private pool (stream-ordered reuse inside
+    # the capture is the allocator's job), and a cached tensor would outlive its graph -- torch hands the same capture stream
+    # to the next capture, which would then be given memory of a pool that has been released.
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(n, 1), dtype=_f32, device=device)
     # one scratch buffer per (device, stream): concurrent streams must not share split-K partials
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
     t = _ws_cache.get(key)

@@ -19,6 +19,10 @@ from . import ops
 from .engine import UNetEngine
 
 
+GRAPH_AUTO_PIXELS = 16384       # taylor_sweep(use_graph=None) under DP_GRAPH=auto: shards up to this many pixels ...
+GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay a captured hipGraph
+
+
 def flatten_grads(model):
     """Point every parameter's .grad at a slice of one zero-initialised flat fp32 buffer; returns the buffer."""
     params = [p for p in model.parameters()]
@@ -167,6 +171,13 @@ class HipSweepStep:
         self.eng.prepare_packs()
         ops._workspace(1 << 26, self.clean.device)          # split-K workspace must exist before capture
         self._t = torch.zeros(self.B, dtype=torch.long, device=self.clean.device)
+        # one eager pass before the capture (code objects loaded, workspaces and allocator pools warm) that leaves the
+        # accumulated gradients untouched: with the early-exit state set to "stopped" the loss kernel emits dOut = 0 and
+        # every += epilogue adds an exact zero
+        real_state = self.stop_state
+        self.stop_state = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float32, device=self.clean.device)
+        self._step(self._t)
+        self.stop_state = real_state
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -190,7 +201,7 @@ def _f32_lt_prod(loss, loss_max, thr):
 
 
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
-                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=False, micro_batch=None,
+                 step_fn=None, flat_grads=None, reduce_grads=True, use_graph=None, micro_batch=None,
                  accumulate_breaking_step=True, device_exit=True, poll_every=8):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
 
@@ -202,7 +213,12 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     torch.distributed is initialised, single process otherwise).  `step_fn(k) -> local loss tensor` lets the
     multi-process CPU tests drive the same control flow with a different per-step engine.
     device_exit / poll_every: keep the Diff-Pruning early-exit state on the device and read the stop flag every
-    `poll_every` timesteps (False: read the loss on the host after every step, as the reference does)."""
+    `poll_every` timesteps (False: read the loss on the host after every step, as the reference does).
+    use_graph: replay the timestep from a captured hipGraph (bit-identical; works with the on-device early exit).  Measured
+    slower than eager launches at every batch size on this stack -- C1-size model, batch 4, 200 timesteps: 24-26 ms per step
+    replayed vs 14.7 eager (tools/bench_c1_long.py); batch 256: +3 % -- the ~750-node graph launch costs more host time than
+    the ctypes launches it replaces.  None = False unless DP_GRAPH=auto (shards of <= GRAPH_AUTO_PIXELS pixels swept for
+    >= GRAPH_AUTO_STEPS timesteps).  Kept for runtimes where graph launch is cheap."""
     import torch.distributed as dist
     use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     B_local = clean_images.shape[0]
@@ -215,27 +231,40 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         B_global = B_local
     if flat_grads is None and step_fn is None:
         flat_grads = flatten_grads(model)
-    if step_fn is None:
+    two_phase = thr is not None and not accumulate_breaking_step
+    own_step = step_fn is None
+    if use_graph is None:
+        use_graph = (os.environ.get('DP_GRAPH') == 'auto' and own_step and not two_phase and micro_batch is None
+                     and clean_images.device.type == 'cuda' and num_steps >= GRAPH_AUTO_STEPS
+                     and B_local * clean_images.shape[2] * clean_images.shape[3] <= GRAPH_AUTO_PIXELS)
+    stop_state = losses_dev = None
+    if own_step:
         step_fn = HipSweepStep(model, scheduler, clean_images, noise, B_global * per_img, loss_kind, B_global)
         step_fn.micro = micro_batch
         if use_graph:
+            if thr is not None and device_exit and not two_phase:
+                # the captured loss kernel reads the early-exit state: it has to exist before the capture
+                stop_state = torch.zeros(3, dtype=torch.float32, device=clean_images.device)
+                losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=clean_images.device)
+                step_fn.stop_state = stop_state
             step_fn.capture()
     losses = []
     pending = []
     loss_max = 0.0
     steps = 0
-    two_phase = thr is not None and not accumulate_breaking_step
     if two_phase and use_graph:
         raise ValueError('use_graph replays forward + backward as one unit: not available with accumulate_breaking_step=False')
-    on_device = (thr is not None and device_exit and not use_graph and isinstance(step_fn, HipSweepStep)
-                 and hasattr(ops, 'early_exit_update') and clean_images.device.type == 'cuda')
+    on_device = (thr is not None and device_exit and (not use_graph or stop_state is not None)
+                 and isinstance(step_fn, HipSweepStep) and hasattr(ops, 'early_exit_update')
+                 and clean_images.device.type == 'cuda')
     if on_device:
         # The early-exit state lives on the device: no host read of the loss per step.  Timesteps enqueued after the stop are
         # exact no-ops (dOut = 0), the host looks at the flag every `poll_every` steps, and the scalar-loss all-reduce of the
         # data-parallel path is stream-ordered (RCCL), so nothing blocks the host between polls.
         dev = clean_images.device
-        state = torch.zeros(3, dtype=torch.float32, device=dev)
-        losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=dev)
+        state = stop_state if stop_state is not None else torch.zeros(3, dtype=torch.float32, device=dev)
+        if losses_dev is None:
+            losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=dev)
         step_fn.stop_state = state
         k = 0
         while k < num_steps:
