@@ -374,7 +374,10 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
         if a96 < 0.9 * a128:
             tile, bm, bn = 3, 96, 96
     tiles = -(-Cout // bm) * -(-Cin // bn) * taps
-    splits = max(1, min(WGRAD_BLOCKS // tiles, P // WGRAD_MIN_PIX if P >= 2 * WGRAD_MIN_PIX else 1))     # floor: never spill into a 2nd round
+    # 1x1 weight gradients have 4-8 output tiles and an enormous K: half a round of workgroups with twice the K range each
+    # beats a full round whose partial sums are twice the traffic (256->256 @16x16 B=256: 108 -> 98 us, tools/bench_wgrad1x1.py)
+    blocks = WGRAD_BLOCKS if taps > 1 else WGRAD_BLOCKS // 2
+    splits = max(1, min(blocks // tiles, P // WGRAD_MIN_PIX if P >= 2 * WGRAD_MIN_PIX else 1))     # floor: never spill into a 2nd round
     if max_splits is not None:
         splits = max(1, min(splits, max_splits))
     pps = -(-P // splits)
