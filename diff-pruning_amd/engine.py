@@ -122,7 +122,15 @@ class UNetEngine:
         # projection gradients of the layer below need exactly those, and a separate row-sum pass would re-read the tensor
         self.fuse_rows = not os.environ.get('DP_NO_FUSED_ROWS')
         self._rows_src = None
+        self._temb_rows = None
         self.segment_hook = None
+        # Time-embedding projections batched over the network (Diffusers UNet only): the 22 `time_emb_proj` Linear layers all read
+        # the same silu(emb), and their input gradient is only needed once the whole backward pass is over -- so forward is ONE
+        # GEMM against the concatenated weights ([sum C, 512]; every ResnetBlock2D takes its column slice as the conv epilogue's
+        # per-(image, channel) addend), and backward is two GEMMs at the end (d silu(emb) = R_all W_all, dW_all = R_all^T silu(emb))
+        # over the concatenated row sums instead of 22 x (dgrad + wgrad + split-K reduce) latency-bound launches.
+        self.temb_batch = not os.environ.get('DP_NO_TEMB_BATCH')
+        self._temb = None
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -193,6 +201,29 @@ class UNetEngine:
         if self._cq is not None:
             self._cq.flush()
             self._cq = None
+
+    def _resnet_prefixes(self):
+        cfg = self.cfg
+        Lr, nb = cfg['layers_per_block'], len(cfg['block_out_channels'])
+        out = ['down_blocks.%d.resnets.%d' % (i, j) for i in range(nb) for j in range(Lr)]
+        out += ['mid_block.resnets.0', 'mid_block.resnets.1']
+        out += ['up_blocks.%d.resnets.%d' % (i, j) for i in range(nb) for j in range(Lr + 1)]
+        return out
+
+    def _temb_pack(self):
+        """(prefixes, {prefix: (offset, C)}, W_all [sum C, tdim], b_all [sum C]) -- cached with the packed conv operands."""
+        hit = self.packs._c.get(('__temb_all__', 0))
+        if hit is not None:
+            return hit
+        names = self._resnet_prefixes()
+        ws = [self.P[n + '.time_emb_proj.weight'] for n in names]
+        offs, o = {}, 0
+        for n, w in zip(names, ws):
+            offs[n] = (o, w.shape[0])
+            o += w.shape[0]
+        val = (names, offs, torch.cat(ws, 0).contiguous(), torch.cat([self.P[n + '.time_emb_proj.bias'] for n in names], 0).contiguous())
+        self.packs._c[('__temb_all__', 0)] = val
+        return val
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
@@ -283,7 +314,11 @@ class UNetEngine:
         eps = cfg['norm_eps'] if eps is None else eps
         nm = names
         n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], G, eps, True)
-        tproj = self._linear(pre + nm['temb'], semb)
+        if self._temb is not None:
+            o, c = self._temb[1][pre]
+            tproj = self._temb[2][:, o:o + c]          # column slice of the batched projection (row stride = sum C)
+        else:
+            tproj = self._linear(pre + nm['temb'], semb)
         h = self._conv(pre + nm['conv1'], n1, None, _SPEC3, tadd=tproj)
         # resnet.py:622-630: norm2 -> SiLU -> dropout -> conv2; the dropout is fused into the GroupNorm kernel's store
         drop = self._drop(pre + nm['dropout']) if 'dropout' in nm else None
@@ -318,7 +353,10 @@ class UNetEngine:
         del dn2
         # time-embedding projection: d tproj[n, c] = sum_hw dh  (also conv1's bias-gradient rows)
         rows_h = self._rows_of(dh)
-        self._linear_bwd(pre + nm['temb'], rows_h, semb, dx_out=d_semb, dx_accumulate=True)
+        if self._temb_rows is not None:
+            self._temb_rows[pre] = rows_h              # batched at the end of backward()
+        else:
+            self._linear_bwd(pre + nm['temb'], rows_h, semb, dx_out=d_semb, dx_accumulate=True)
         dn1 = self._conv_bwd(pre + nm['conv1'], dh, n1, None, _SPEC3, hw, rows=rows_h)
         del dh
         if has_sc:
@@ -412,6 +450,10 @@ class UNetEngine:
         a1 = ops.silu_fwd(h1)
         emb = self._linear('time_embedding.linear_2', a1)
         semb = ops.silu_fwd(emb)
+        self._temb = None
+        if self.temb_batch and 'down_blocks.0.resnets.0.time_emb_proj.weight' in P:
+            names, offs, W_all, b_all = self._temb_pack()
+            self._temb = (names, offs, ops.linear_forward(semb, W_all, b_all), W_all)
         x = self._conv('conv_in', sample, None, _SPEC3)
         skips = [x]
         for i, bt in enumerate(cfg['down_block_types']):
@@ -453,7 +495,9 @@ class UNetEngine:
         out = self._conv('conv_out', no, None, _SPEC3)
         if ctx is not None:
             ctx['_head'] = (sample, t_emb, h1, a1, emb, semb, xo, no, sto, n_skips)
+            ctx['_temb'] = None if self._temb is None else (self._temb[0], self._temb[1], self._temb[3])
             self.ctx = ctx
+        self._temb = None
         return out
 
     def backward(self, dout):
@@ -465,6 +509,8 @@ class UNetEngine:
         nb = len(boc)
         G = cfg['norm_num_groups']
         sample, t_emb, h1, a1, emb, semb, xo, no, sto, n_skips = ctx.pop('_head')
+        temb = ctx.pop('_temb', None)
+        self._temb_rows = {} if temb is not None else None
         self._begin_backward()
         d_semb = torch.zeros_like(semb)
         hw = tuple(xo.shape[2:])
@@ -528,6 +574,20 @@ class UNetEngine:
         assert idx == 0 and not sg
         self.segment_done('down')
         self._conv_bwd('conv_in', dx, sample, None, _SPEC3, None, need_dx=False)
+        if temb is not None:
+            # all time_emb_proj layers at once: rows of every ResnetBlock2D side by side, two GEMMs, gradients scattered back
+            names, offs, W_all = temb
+            rows = self._temb_rows
+            self._temb_rows = None
+            R_all = torch.cat([rows[n] for n in names], 1)
+            d_semb = ops.linear_dgrad(R_all, W_all)
+            dW_all = torch.empty_like(W_all)
+            ops.linear_wgrad(R_all, semb, dW_all, accumulate=False)
+            for n in names:
+                o, c = offs[n]
+                gw = self.G[n + '.time_emb_proj.weight']
+                ops.axpby(dW_all[o:o + c].view(-1), 1.0, gw.view(-1), 1.0)
+                self._colsum(rows[n], rows[n].shape[0], c, 1, 0, self.G[n + '.time_emb_proj.bias'])
         # time embedding MLP (embeddings.py:200-212)
         d_emb = ops.silu_bwd(emb, d_semb)
         d_a1 = self._linear_bwd('time_embedding.linear_2', d_emb, a1)
