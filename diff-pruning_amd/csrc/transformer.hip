@@ -9,13 +9,17 @@
 // contiguous 256-byte run of tokens, the channel loop is 4x shorter and carries two independent load streams per lane
 // (one thread per token with 3 serial passes over up to 960 channels was latency bound: 31 % of an LDM step).
 // Variance in one pass around the token's first channel as the shift (stable: the shifted mean is small).
+// TOK tokens x (256 / TOK) channel groups per workgroup: 64 x 4 for large token counts; 16 x 16 when 64-token workgroups would
+// leave the chip mostly idle (LDM importance pass: 6 latents x 1024 tokens = 96 workgroups on 256 CUs; 161 us for 28 MB).
+template <int TOK>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long x_img_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int N,
                                                      int C, int T, float eps, float* __restrict__ y, long long y_img_stride,
                                                      float* __restrict__ stats) {
-    __shared__ float r1[4][64], r2[4][64];
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const long long tok = (long long)blockIdx.x * 64 + tl;
+    constexpr int CG = 256 / TOK;
+    __shared__ float r1[CG][TOK], r2[CG][TOK];
+    const int tl = threadIdx.x % TOK, cg = threadIdx.x / TOK;
+    const long long tok = (long long)blockIdx.x * TOK + tl;
     const bool valid = tok < (long long)N * T;
     const long long tk = valid ? tok : 0;
     const int n = (int)(tk / T);
@@ -24,8 +28,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float k = xp[0];
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     int c = cg;
-    for (; c + 4 < C; c += 8) {
-        const float v0 = xp[(long long)c * T] - k, v1 = xp[(long long)(c + 4) * T] - k;
+    for (; c + CG < C; c += 2 * CG) {
+        const float v0 = xp[(long long)c * T] - k, v1 = xp[(long long)(c + CG) * T] - k;
         s0 += v0; q0 += v0 * v0;
         s1 += v1; q1 += v1 * v1;
     }
@@ -33,8 +37,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     r1[cg][tl] = s0 + s1;
     r2[cg][tl] = q0 + q1;
     __syncthreads();
-    const float ms = ((r1[0][tl] + r1[1][tl]) + (r1[2][tl] + r1[3][tl])) / (float)C;
-    const float var = fmaxf(((r2[0][tl] + r2[1][tl]) + (r2[2][tl] + r2[3][tl])) / (float)C - ms * ms, 0.f);
+    float rs = 0.f, rq = 0.f;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) { rs += r1[j][tl]; rq += r2[j][tl]; }            // fixed order
+    const float ms = rs / (float)C;
+    const float var = fmaxf(rq / (float)C - ms * ms, 0.f);
     const float mean = k + ms;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (!valid) return;
@@ -43,27 +50,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         stats[tok * 2 + 1] = rstd;
     }
     float* yp = y + (long long)n * y_img_stride + t;
-    for (c = cg; c < C; c += 4) yp[(long long)c * T] = (xp[(long long)c * T] - mean) * rstd * gamma[c] + beta[c];
+    for (c = cg; c < C; c += CG) yp[(long long)c * T] = (xp[(long long)c * T] - mean) * rstd * gamma[c] + beta[c];
 }
 
 extern "C" int dp_layernorm_fwd(const float* x, long long x_img_stride, const float* gamma, const float* beta, int N, int C,
                                 int T, float eps, float* y, long long y_img_stride, float* stats, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    DP_LAUNCH(ln_fwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
-                       x_img_stride, gamma, beta, N, C, T, eps, y, y_img_stride, stats);
+    if (ntok >= 64 * 1024)
+        DP_LAUNCH(ln_fwd_kernel<64>, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
+                  x_img_stride, gamma, beta, N, C, T, eps, y, y_img_stride, stats);
+    else
+        DP_LAUNCH(ln_fwd_kernel<16>, dim3((unsigned)((ntok + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x,
+                  x_img_stride, gamma, beta, N, C, T, eps, y, y_img_stride, stats);
     return DP_LAUNCH_CHECK();
 }
 
 // dx = rstd * (gamma*dy - mean_c(gamma*dy) - xhat * mean_c(gamma*dy*xhat))  (+ add)      (same 64 x 4 decomposition)
+template <int TOK>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long long x_img_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
                                                      const float* __restrict__ dy, long long dy_img_stride, int N, int C,
                                                      int T, float* __restrict__ dx, long long dx_img_stride,
                                                      const float* __restrict__ add, long long add_img_stride) {
-    __shared__ float r1[4][64], r2[4][64];
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const long long tok = (long long)blockIdx.x * 64 + tl;
+    constexpr int CG = 256 / TOK;
+    __shared__ float r1[CG][TOK], r2[CG][TOK];
+    const int tl = threadIdx.x % TOK, cg = threadIdx.x / TOK;
+    const long long tok = (long long)blockIdx.x * TOK + tl;
     const bool valid = tok < (long long)N * T;
     const long long tk = valid ? tok : 0;
     const int n = (int)(tk / T);
@@ -73,9 +86,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     const float* dp = dy + (long long)n * dy_img_stride + t;
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     int c = cg;
-    for (; c + 4 < C; c += 8) {
-        const float g0 = gamma[c] * dp[(long long)c * T], g1 = gamma[c + 4] * dp[(long long)(c + 4) * T];
-        const float h0 = (xp[(long long)c * T] - mean) * rstd, h1 = (xp[(long long)(c + 4) * T] - mean) * rstd;
+    for (; c + CG < C; c += 2 * CG) {
+        const float g0 = gamma[c] * dp[(long long)c * T], g1 = gamma[c + CG] * dp[(long long)(c + CG) * T];
+        const float h0 = (xp[(long long)c * T] - mean) * rstd, h1 = (xp[(long long)(c + CG) * T] - mean) * rstd;
         a0 += g0; b0 += g0 * h0;
         a1 += g1; b1 += g1 * h1;
     }
@@ -86,12 +99,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     r1[cg][tl] = a0 + a1;
     r2[cg][tl] = b0 + b1;
     __syncthreads();
-    const float a = ((r1[0][tl] + r1[1][tl]) + (r1[2][tl] + r1[3][tl])) / (float)C;
-    const float b = ((r2[0][tl] + r2[1][tl]) + (r2[2][tl] + r2[3][tl])) / (float)C;
+    float ra = 0.f, rb = 0.f;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) { ra += r1[j][tl]; rb += r2[j][tl]; }            // fixed order
+    const float a = ra / (float)C;
+    const float b = rb / (float)C;
     if (!valid) return;
     float* op = dx + (long long)n * dx_img_stride + t;
     const float* ap = add ? add + (long long)n * add_img_stride + t : nullptr;
-    for (c = cg; c < C; c += 4) {
+    for (c = cg; c < C; c += CG) {
         const float xh = (xp[(long long)c * T] - mean) * rstd;
         float v = rstd * (gamma[c] * dp[(long long)c * T] - a - xh * b);
         if (ap) v += ap[(long long)c * T];
@@ -129,8 +145,12 @@ extern "C" int dp_layernorm_bwd(const float* x, long long x_img_stride, const fl
                                 long long dx_img_stride, const float* add, long long add_img_stride, float* pws, void* stream) {
     const long long ntok = (long long)N * T;
     if (ntok <= 0) return 0;
-    DP_LAUNCH(ln_bwd_kernel, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
-                       x_img_stride, gamma, stats, dy, dy_img_stride, N, C, T, dx, dx_img_stride, add, add_img_stride);
+    if (ntok >= 64 * 1024)
+        DP_LAUNCH(ln_bwd_kernel<64>, dim3((unsigned)((ntok + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
+                  x_img_stride, gamma, stats, dy, dy_img_stride, N, C, T, dx, dx_img_stride, add, add_img_stride);
+    else
+        DP_LAUNCH(ln_bwd_kernel<16>, dim3((unsigned)((ntok + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x,
+                  x_img_stride, gamma, stats, dy, dy_img_stride, N, C, T, dx, dx_img_stride, add, add_img_stride);
     int e = DP_LAUNCH_CHECK();
     if (e) return e;
     const long long nrows = (long long)N * C;

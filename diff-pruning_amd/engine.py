@@ -131,6 +131,10 @@ class UNetEngine:
         # over the concatenated row sums instead of 22 x (dgrad + wgrad + split-K reduce) latency-bound launches.
         self.temb_batch = not os.environ.get('DP_NO_TEMB_BATCH')
         self._temb = None
+        # Attention q / k / v projections as ONE 1x1 convolution over the concatenated weights (single-head blocks): the
+        # normalised input is read once instead of three times, and the three input gradients that used to accumulate into one
+        # buffer (3 x read + 2 x read-modify-write) are one K = 3C contraction.  q, k, v are channel slices of the result.
+        self.fuse_qkv = not os.environ.get('DP_NO_FUSED_QKV')
 
     # ------------------------------------------------------------------------------------------
     def bind(self, params, grads=None):
@@ -224,6 +228,20 @@ class UNetEngine:
         val = (names, offs, torch.cat(ws, 0).contiguous(), torch.cat([self.P[n + '.time_emb_proj.bias'] for n in names], 0).contiguous())
         self.packs._c[('__temb_all__', 0)] = val
         return val
+
+    def _qkv_pack(self, pre):
+        """Packed operands of cat(to_q, to_k, to_v): (fwd pack, ld, bias, dgrad pack, ld, (cq, ck, cv)); cached with the packs."""
+        key = (pre + '.__qkv__', 0)
+        hit = self.packs._c.get(key)
+        if hit is None:
+            ws = [self.P[pre + n + '.weight'] for n in ('.to_q', '.to_k', '.to_v')]
+            w = torch.cat(ws, 0).contiguous()
+            b = torch.cat([self.P[pre + n + '.bias'] for n in ('.to_q', '.to_k', '.to_v')], 0).contiguous()
+            wp, ld = ops.pack_weight(w, 0)
+            wd, ldd = ops.pack_weight(w, 1)
+            hit = (wp, ld, b, wd, ldd, tuple(x.shape[0] for x in ws))
+            self.packs._c[key] = hit
+        return hit
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
@@ -380,32 +398,39 @@ class UNetEngine:
         N, C, H, W = x.shape
         T = H * W
         n, st = ops.groupnorm_fwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], G, eps, False)
-        q = self._conv(pre + '.to_q', n, None, _SPEC1)
-        k = self._conv(pre + '.to_k', n, None, _SPEC1)
-        v = self._conv(pre + '.to_v', n, None, _SPEC1)
+        fused = self.fuse_qkv and heads == 1 and hasattr(ops, 'empty_act') and (pre + '.to_q.bias') in P
+        if fused:
+            wp, ld, b_cat, _, _, (cq, ck, cv) = self._qkv_pack(pre)
+            qkv = ops.conv_forward(n, None, wp, ld, cq + ck + cv, _SPEC1, bias=b_cat)
+            q, k, v = qkv[:, :cq], qkv[:, cq:cq + ck], qkv[:, cq + ck:]
+        else:
+            q = self._conv(pre + '.to_q', n, None, _SPEC1)
+            k = self._conv(pre + '.to_k', n, None, _SPEC1)
+            v = self._conv(pre + '.to_v', n, None, _SPEC1)
         inner = q.shape[1]
         # heads: channel-major tokens make head_to_batch_dim (attention_processor.py:283-305) a view: head h owns the
         # contiguous channel rows [h*d, (h+1)*d) of every image -> batch index n*heads + h
         Z, d = N * heads, inner // heads
         s = ops.bmm_tn(q.view(Z, d, T), k.view(Z, d, T), alpha=scale)
         p = ops.softmax_fwd(s, out=s)
-        o = ops.bmm_nt(v.view(Z, d, T), p)
+        vd = v.shape[1] // heads                      # the value width may differ from the query / key width after pruning
+        o = ops.bmm_nt(v.view(Z, vd, T), p)
         drop = self._drop(pre + '.to_out.1')
         if drop is None:
-            out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
+            out = self._conv(pre + '.to_out.0', o.view(N, vd * heads, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)
         else:
             # attention_processor.py:455-466: to_out[0] -> to_out[1] (dropout) -> + residual -> / rescale_output_factor
-            out = self._conv(pre + '.to_out.0', o.view(N, inner, H, W), None, _SPEC1)
+            out = self._conv(pre + '.to_out.0', o.view(N, vd * heads, H, W), None, _SPEC1)
             ops.dropout_apply(out, drop, out=out)
             ops.copy_strided(x, out, accumulate=True)
             if rescale != 1.0:
                 ops.axpby(out, 1.0 / rescale, out, 0.0)
         if save is not None:
-            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads, drop)
+            save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads, drop, fused)
         return out
 
     def attn_bwd(self, pre, dout, extra=None):
-        x, st, n, q, k, v, p, o, scale, rescale, heads, drop = self.ctx.pop(pre)
+        x, st, n, q, k, v, p, o, scale, rescale, heads, drop, fused = self.ctx.pop(pre)
         P, cfg = self.P, self.cfg
         G = cfg['norm_num_groups']
         N, C, H, W = x.shape
@@ -416,19 +441,33 @@ class UNetEngine:
         if rescale != 1.0:
             d = ops.axpby(dout.contiguous(), 1.0 / rescale, torch.empty_like(dout, memory_format=torch.contiguous_format), 0.0)
         dproj = d if drop is None else ops.dropout_apply(d.contiguous(), drop)
-        do = self._conv_bwd(pre + '.to_out.0', dproj, o.view(N, inner, H, W), None, _SPEC1, hw)
+        do = self._conv_bwd(pre + '.to_out.0', dproj, o.view(N, -1, H, W), None, _SPEC1, hw)
         Z, dh = N * heads, inner // heads
-        do3 = do.view(Z, dh, T)
-        dv = ops.bmm_nn(do3, p)
-        dp = ops.bmm_tn(do3, v.view(Z, dh, T))
-        ds = ops.softmax_bwd(p, dp, scale, out=dp)
-        dq = ops.bmm_nt(k.view(Z, dh, T), ds)
-        dk = ops.bmm_nn(q.view(Z, dh, T), ds)
-        dn = torch.empty_like(n)
-        first = True
-        for dproj, name in ((dq, '.to_q'), (dk, '.to_k'), (dv, '.to_v')):
-            self._conv_bwd(pre + name, dproj.view(N, inner, H, W), n, None, _SPEC1, hw, dx_out=dn, dx_accumulate=not first)
-            first = False
+        do3 = do.view(Z, do.shape[1] // heads, T)
+        if fused:
+            # dq | dk | dv written straight into channel slices of one buffer; one K = 3C input-gradient contraction
+            _, _, _, wd, ldd, (cq, ck, cv) = self._qkv_pack(pre)
+            d_qkv = ops.empty_act((N, cq + ck + cv, H, W), x.device)
+            sl = (d_qkv[:, :cq], d_qkv[:, cq:cq + ck], d_qkv[:, cq + ck:])
+            ops.bmm_nn(do3, p, out=sl[2].view(N, cv, T))
+            dp = ops.bmm_tn(do3, v.view(N, cv, T))
+            ds = ops.softmax_bwd(p, dp, scale, out=dp)
+            ops.bmm_nt(k.view(N, ck, T), ds, out=sl[0].view(N, cq, T))
+            ops.bmm_nn(q.view(N, cq, T), ds, out=sl[1].view(N, ck, T))
+            for dproj, name in zip(sl, ('.to_q', '.to_k', '.to_v')):
+                self._conv_bwd(pre + name, dproj, n, None, _SPEC1, hw, need_dx=False)       # weight / bias gradients only
+            dn = ops.conv_dgrad(d_qkv, wd, ldd, n.shape[1], _SPEC1, hw)
+        else:
+            dv = ops.bmm_nn(do3, p)
+            dp = ops.bmm_tn(do3, v.view(Z, dh, T))
+            ds = ops.softmax_bwd(p, dp, scale, out=dp)
+            dq = ops.bmm_nt(k.view(Z, dh, T), ds)
+            dk = ops.bmm_nn(q.view(Z, dh, T), ds)
+            dn = torch.empty_like(n)
+            first = True
+            for dproj, name in ((dq, '.to_q'), (dk, '.to_k'), (dv, '.to_v')):
+                self._conv_bwd(pre + name, dproj.view(N, inner, H, W), n, None, _SPEC1, hw, dx_out=dn, dx_accumulate=not first)
+                first = False
         dx, pws = self._gn_bwd(x, None, P[pre + '.group_norm.weight'], P[pre + '.group_norm.bias'], st, dn, G, False,
                                add1=d, add2=extra)
         self._gn_param_grads(pre + '.group_norm', pws)

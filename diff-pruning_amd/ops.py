@@ -166,7 +166,7 @@ def pick_tile(M, N, z=1):
     return best
 
 
-CONV_SPLITK_BLOCKS = 1024      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
+CONV_SPLITK_BLOCKS = int(os.environ.get('DP_CONV_SPLITK_BLOCKS', '512'))      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
 _n64 = os.environ.get('DP_CONV_N64', '0')         # default off: measured null (118.7 vs 124.4 TFLOP/s in isolation, 87.4 = 87.4 ms per step)
 CONV_N64_TILES = tuple(int(v) for v in _n64.split(',')) if _n64 not in ('0', '') else None      # [lo, hi) 128x128-tile counts run as 128x64
 
@@ -186,7 +186,9 @@ def _conv_ksplit(p, device):
     if CONV_SPLITK_BLOCKS <= 0:
         return
     n_iter = p.ntaps * -(-p.C // 16)
-    s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (8 if tiles >= 32 else 2))
+    # K tiles per slice: at least 16 for grids that already hold a workgroup per second CU (a 1x1 conv at 8x8, 16 K tiles, ran
+    # 38 us split in two against 26 us unsplit), 8 from 32 tiles on, 2 for the tiniest grids  [tools/bench_conv_small.py]
+    s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (16 if tiles >= 128 else 8 if tiles >= 32 else 2))
     if s >= 2 and p.M >= 64:
         if p.tile != 3:
             p.tile = 0 if p.M > 64 else 1
@@ -461,23 +463,29 @@ def _bgeom(T, c_split):
     return _geom(1, T, 1, T, 1, T, 1, 1, 1, 0, 0, 0, c_split, 0, 0)
 
 
+def _bs(t):
+    """Batch stride of a [Z, R, S] operand whose matrices are contiguous (a channel slice of a wider [N, C, T] tensor is fine)."""
+    assert t.dim() == 3 and t.stride(2) == 1 and (t.stride(1) == t.shape[2] or t.shape[1] == 1), 'matrices must be contiguous'
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2]
+
+
 def bmm_tn(a, b, alpha=1.0, out=None, accumulate=False):
     """out[z, m, n] = alpha * sum_k a[z, k, m] * b[z, k, n]      (QK^T: a=Q, b=K;  dP: a=dO, b=V)"""
     Z, K, M = a.shape
     _, K2, Nn = b.shape
-    assert K2 == K and a.is_contiguous() and b.is_contiguous() and M % 4 == 0
+    assert K2 == K and M % 4 == 0
     if out is None:
         assert not accumulate
         out = torch.empty((Z, M, Nn), dtype=_f32, device=a.device)
     p = L.ConvGemmParams()
-    p.A, p.a_bs, p.lda, p.a_kc = _p(a), K * M, M, 0
-    p.X1, p.X2, p.x_bs = _p(b), None, K * Nn
+    p.A, p.a_bs, p.lda, p.a_kc = _p(a), _bs(a), M, 0
+    p.X1, p.X2, p.x_bs = _p(b), None, _bs(b)
     p.x_guard = 1                                    # one tap, no padding: nothing is read in front of b
     p.a_bytes, p.x1_bytes, p.x2_bytes = K * M * 4, K * Nn * 4, 0
     p.g = _bgeom(Nn, K)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
-    p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
+    p.out, p.o_img_stride, p.o_bs = _p(out), 0, _bs(out)
     p.alpha, p.post_scale, p.accumulate = alpha, 1.0, 1 if accumulate else 0
     if Z == 1:
         _conv_ksplit(p, a.device)
@@ -489,18 +497,19 @@ def bmm_nn(a, b, alpha=1.0, out=None, accumulate=False):
     """out[z, m, n] = alpha * sum_k a[z, m, k] * b[z, k, n]      (dV: a=dO, b=P;  dK: a=Q, b=dS)"""
     Z, M, K = a.shape
     _, K2, Nn = b.shape
-    assert K2 == K and a.is_contiguous() and b.is_contiguous()
+    assert K2 == K
     if out is None:
         assert not accumulate
         out = torch.empty((Z, M, Nn), dtype=_f32, device=a.device)
     p = L.ConvGemmParams()
-    p.A, p.a_bs, p.lda, p.a_kc = _p(a), M * K, K, 1
-    p.X1, p.X2, p.x_bs = _p(b), None, K * Nn
+    p.A, p.a_bs, p.lda, p.a_kc = _p(a), _bs(a), K, 1
+    p.X1, p.X2, p.x_bs = _p(b), None, _bs(b)
+    p.x_guard = 1
     p.a_bytes, p.x1_bytes, p.x2_bytes = M * K * 4, K * Nn * 4, 0
     p.g = _bgeom(Nn, K)
     p.M, p.C, p.NPIX, p.ntaps, p.batches = M, K, Nn, 1, Z
     p.tile = pick_tile(M, Nn, Z)
-    p.out, p.o_img_stride, p.o_bs = _p(out), 0, M * Nn
+    p.out, p.o_img_stride, p.o_bs = _p(out), 0, _bs(out)
     p.alpha, p.post_scale, p.accumulate = alpha, 1.0, 1 if accumulate else 0
     if Z == 1:
         _conv_ksplit(p, a.device)
@@ -512,18 +521,18 @@ def bmm_nt(a, b, alpha=1.0, out=None, col_bias=None):
     """out[z, m, n] = alpha * sum_k a[z, m, k] * b[z, n, k] (+ col_bias[n])      (P.V: a=V, b=P;  dQ: a=K, b=dS)"""
     Z, M, K = a.shape
     _, Nn, K2 = b.shape
-    assert K2 == K and a.is_contiguous() and b.is_contiguous()
+    assert K2 == K
     if out is None:
         out = torch.empty((Z, M, Nn), dtype=_f32, device=a.device)
     p = L.NtGemmParams()
-    p.A, p.a_bs, p.a_img_stride = _p(a), M * K, 0
-    p.X1, p.X2, p.x_bs = _p(b), None, Nn * K
+    p.A, p.a_bs, p.a_img_stride = _p(a), _bs(a), 0
+    p.X1, p.X2, p.x_bs = _p(b), None, _bs(b)
     p.a_bytes, p.x1_bytes, p.x2_bytes = M * K * 4, Nn * K * 4, 0
     p.g = _bgeom(K, Nn)
     p.M, p.C, p.NCOLS, p.ntaps, p.P = M, Nn, Nn, 1, K
     p.batches, p.splits, p.p_per_split, p.batched = Z, 1, 0, 1
     p.tile = pick_tile(M, Nn, Z)
-    p.out, p.o_bs, p.ldo, p.accumulate = _p(out), M * Nn, Nn, 0
+    p.out, p.o_bs, p.ldo, p.accumulate = _p(out), _bs(out), Nn, 0
     p.alpha, p.col_bias = alpha, _p(col_bias)
     L.check(_run(lambda: _lib().dp_nt_gemm(C.byref(p), _stream()), _nt_name(p), 2.0 * Z * M * Nn * K), 'dp_nt_gemm(bmm_nt)')
     return out

@@ -114,12 +114,26 @@ def bmm_tn(a, b, alpha=1.0, out=None):
     return r
 
 
-def bmm_nn(a, b, alpha=1.0, out=None):
-    return alpha * torch.bmm(a, b)
+def bmm_nn(a, b, alpha=1.0, out=None, accumulate=False):
+    r = alpha * torch.bmm(a, b)
+    if out is not None:
+        out.copy_(out + r if accumulate else r)
+        return out
+    return r
 
 
-def bmm_nt(a, b, alpha=1.0, out=None):
-    return alpha * torch.bmm(a, b.transpose(1, 2))
+def bmm_nt(a, b, alpha=1.0, out=None, col_bias=None):
+    r = alpha * torch.bmm(a, b.transpose(1, 2))
+    if col_bias is not None:
+        r = r + col_bias
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def empty_act(shape, device):
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
 
 
 class _Drop:

@@ -545,6 +545,26 @@ def test_wgrad_xcd_order_is_a_pure_relabelling(ops, report, monkeypatch):
     assert bad == 0
 
 
+@pytest.mark.parametrize('shape', [(2, 128, 3, 32), (3, 37, 4, 20), (1, 16, 1, 5), (5, 50, 2, 16)], ids=str)
+def test_conv_few_output_channels_direct_kernel(ops, report, monkeypatch, shape):
+    """conv_out-shaped layers (<= 4 output channels, 3x3 'same'): the direct stencil kernel against fp64 F.conv2d and against
+    the matrix path it replaces (ragged tiles, channel tails, ReLU epilogue)."""
+    N, C, M, H = shape
+    x = rnd(N, C, H, H, seed=1)
+    w = rnd(M, C, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * C))
+    b = rnd(M, seed=3)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    ref = ref_conv(x, w, b, 1, 1, 0, False)
+    y = ops.conv_forward(x, None, wp, ld, M, spec, bias=b)
+    yr = ops.conv_forward(x, None, wp, ld, M, spec, bias=b, relu=True)
+    monkeypatch.setenv('DP_NO_FEW_OUT', '1')
+    ym = ops.conv_forward(x, None, wp, ld, M, spec, bias=b)
+    e, em, er = relerr(y, ref), relerr(y, ym.double().cpu()), relerr(yr, ref.clamp_min(0))
+    report['conv_few_out/%s' % (shape,)] = dict(fwd=e, vs_matrix_path=em, relu=er)
+    assert max(e, em, er) < 2e-5
+
+
 def test_conv_fast_x4_loads_equal_dword_loads(ops, report, monkeypatch):
     """The 16-byte B-tile loads of the fast convolution kernel (4 pixels per lane, border element zeroed in LDS) put exactly the
     values of the 4-byte path into LDS: forward, dgrad and the attention products are bit-identical with and without them."""

@@ -1,20 +1,41 @@
 #!/usr/bin/env python3
-"""cProfile of the prune tail (scoring + mask selection + slicing) on the CIFAR UNet."""
-import cProfile, importlib, os, pstats, sys, time
+"""cProfile of the sweep's tail (scoring + mask selection + slicing, sweep.prune_model) on the CIFAR UNet."""
+import cProfile
+import importlib
+import os
+import pstats
+import sys
+import time
+
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
-import golden_common as gc
-unet = importlib.import_module('diff-pruning_amd.unet'); sweep = importlib.import_module('diff-pruning_amd.sweep')
-diffusion = importlib.import_module('diff-pruning_amd.diffusion')
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import golden_common as gc  # noqa: E402
+
+unet = importlib.import_module('diff-pruning_amd.unet')
+sweep = importlib.import_module('diff-pruning_amd.sweep')
+dev = torch.device('cuda')
+
+
 def fresh():
-    m = unet.UNet2DModel(**gc.CIFAR_CFG); gc.det_init_(m, 0); m = m.cuda().eval()
-    c = torch.from_numpy(gc.det_clean((4, 3, 32, 32), 1)).cuda(); n = torch.from_numpy(gc.det_noise((4, 3, 32, 32), 2)).cuda()
-    sweep.taylor_sweep(m, diffusion.DDPMScheduler(), c, n, num_steps=2)
+    model = unet.UNet2DModel(**gc.CIFAR_CFG)
+    gc.det_init_(model, 0)
+    model = model.to(dev).eval()
+    flat = sweep.flatten_grads(model)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    for p in model.parameters():
+        p.grad.copy_(torch.randn(p.shape, generator=g).to(dev))
     torch.cuda.synchronize()
-    return m
-m = fresh(); t = time.perf_counter(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); print('warm-up tail ms', (time.perf_counter() - t) * 1e3)
-m = fresh(); t = time.perf_counter(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); print('tail ms', (time.perf_counter() - t) * 1e3)
+    return model
+
+
 m = fresh()
-pr = cProfile.Profile(); pr.enable(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+t0 = time.perf_counter(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); print('first call %.1f ms' % ((time.perf_counter() - t0) * 1e3))
+m = fresh()
+t0 = time.perf_counter(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); print('second call %.1f ms' % ((time.perf_counter() - t0) * 1e3))
+m = fresh()
+pr = cProfile.Profile()
+pr.enable(); sweep.prune_model(m, 0.3); torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
