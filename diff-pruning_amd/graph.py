@@ -81,6 +81,7 @@ class _GraphBase:
                 order.append(n)
 
         stack, visited = [root], set()
+        relinked = set()
         while stack:
             f = stack.pop()
             if f.uid in visited:
@@ -88,6 +89,11 @@ class _GraphBase:
             create(f)
             for inp in f.inputs:
                 create(inp)
+                if inp.uid not in relinked:
+                    relinked.add(inp.uid)
+                    inp.outputs = []
+                if f not in inp.outputs:             # Node.add_output at the time the CONSUMER is expanded
+                    inp.outputs.append(f)            # (dependency.py:796-797): consumers in trace order
                 stack.append(inp)
             visited.add(f.uid)
         return order
@@ -245,17 +251,32 @@ class ChannelView:
         return self._out(name)
 
     def out_channels(self, node):
-        if node.kind in ('conv', 'linear', 'gn', 'ln'):
+        if node.kind in ('conv', 'linear', 'gn', 'ln', 'bn', 'dw'):
             return self._out(node.name)
         if node.kind == 'cat':
             return sum(self.out_channels(i) for i in node.inputs)
+        if node.kind == 'const':
+            return node.part
         if node.kind == 'slice':
-            return self.out_channels(node.inputs[0]) // node.part[1]
+            return slice_range(self, node)[1]
+        if node.kind in ('flatten', 'unflatten'):
+            c = self.out_channels(node.inputs[0])
+            return None if c is None else (c * node.part if node.kind == 'flatten' else c // node.part)
         for i in node.inputs:           # element-wise: same as (any) input
             c = self.out_channels(i)
             if c is not None:
                 return c
         return None
+
+
+def slice_range(chan, node):
+    """(first channel, channel count) of a `slice` node inside its input tensor.  Symbolic graphs: part = (index, number of
+    equal parts).  Traced graphs: part = (index, trace.SplitInfo) with the live sizes of every output of that split."""
+    j, parts = node.part
+    if isinstance(parts, int):
+        d = chan.out_channels(node.inputs[0]) // parts
+        return j * d, d
+    return parts.range(j)
 
 
 class Member:
@@ -271,75 +292,133 @@ class Member:
         return 'Member(%s, %s, %d idxs)' % (self.name, self.kind, len(self.idxs))
 
 
-def coupled_members(graph, chan, root_name, idxs):
-    """dependency.py:433-496.  Propagate the out-channel set `idxs` of layer `root_name` through the graph;
-    returns an ordered list of Members (root first).  Index sets reaching the same (layer, kind) are merged
+def _fns(node):
+    """(in-channel pruning fn, out-channel pruning fn) of a node.  Layers with a weight matrix have two different ones;
+    everything else prunes 'its channels' with ONE function (function.py: prune_in_channels = prune_out_channels for the
+    norms and the depthwise convolution, ops.py dummy pruners for element-wise / concat / split / reshape)."""
+    return ('in', 'out') if node.kind in ('conv', 'linear') else ('p', 'p')
+
+
+def _to_input(chan, node, k, ii):
+    """Indices `ii` on the output of `node`, expressed on the output of its k-th input."""
+    if node.kind == 'cat':
+        off = sum(chan.out_channels(i) for i in node.inputs[:k])
+        n_in = chan.out_channels(node.inputs[k])
+        return [i - off for i in ii if off <= i < off + n_in]
+    if node.kind == 'slice':
+        off = slice_range(chan, node)[0]
+        return [i + off for i in ii]
+    if node.kind == 'flatten':
+        return sorted({i // node.part for i in ii})
+    if node.kind == 'unflatten':
+        return [i * node.part + k2 for i in ii for k2 in range(node.part)]
+    return ii
+
+
+def _to_output(chan, node, c, ii):
+    """Indices `ii` on the output of `node`, expressed on the output (or, for a layer, the input channels) of consumer c."""
+    if c.kind == 'cat':
+        off = 0
+        for inp in c.inputs:
+            if inp is node:
+                break
+            off += chan.out_channels(inp)
+        return [i + off for i in ii]
+    if c.kind == 'slice':
+        off, d = slice_range(chan, c)
+        return [i - off for i in ii if off <= i < off + d]
+    if c.kind == 'flatten':
+        return [i * c.part + k for i in ii for k in range(c.part)]
+    if c.kind == 'unflatten':
+        return sorted({i // c.part for i in ii})
+    return ii
+
+
+def coupled_members(graph, chan, root_name, idxs, aux=None):
+    """dependency.py:433-496.  Propagate the out-channel set `idxs` of layer `root_name` through the graph; returns an
+    ordered list of Members (root first), index sets reaching the same (layer, pruning fn) merged
     (Group.add_and_merge, dependency.py:492-494).
 
-    A channel set S living on the output tensor of node n implies
-      producer side: conv/linear -> member (n, 'out', S), stop;  Group/LayerNorm -> member (n, 'gn'|'ln', S) and S on its input;
-                     element-wise -> S on every input;  cat -> S split over the inputs by their channel offsets;
-      consumer side: conv/linear -> member (c, 'in', S), stop;  GroupNorm / element-wise -> S on c's output;
-                     cat -> S shifted by the input's offset on c's output."""
+    The order is the reference's: a (node, fn, idxs) operation is APPENDED when it is discovered and EXPANDED in LIFO
+    order; expanding lists the node's dependencies inputs first, then outputs (dependency.py:603-627), of which a layer
+    triggers only one side (out-channel pruning -> its consumers' in-channels; in-channel pruning -> its producers'
+    out-channels) and every other node both.  A dependency is skipped when its index set is empty or when its target was
+    already expanded and the identical operation is already in the group (dependency.py:476-479).  Members are summed in
+    this order by the importance criteria, so the order is part of bit-exactness.
+
+    Index maps (_helpers.py:17-79): cat <-> input k shifts by the input's channel offset; slice (one output of a
+    split / chunk) <-> its source shifts by the slice's offset; flatten / unflatten map channel c <-> features
+    [c*s, (c+1)*s).  BatchNorm ('bn') and depthwise convolutions ('dw', member kind 'out') pass indices through like
+    GroupNorm.  `aux`, when given, receives (slice node, number of its channels in the group) for the traced splits whose
+    sizes the caller must shrink after pruning."""
     root = graph.layers[root_name]
-    members, order = {}, []
+    root_fn = _fns(root)[1]
+    sliced = {}
 
-    def add(name, kind, ii):
-        key = (name, kind)
-        if key not in members:
-            members[key] = set()
-            order.append(key)
-        members[key].update(ii)
+    # A slice is looked THROUGH, in both directions: the reference has one split node per torch.split, living in the
+    # coordinates of the tensor that is split, whose dependencies lead straight to the consumers of its outputs; the
+    # per-output slice nodes of this graph are finer than that and must not add a level to the LIFO expansion order.
+    def out_deps(node, c, ii):
+        jj = _to_output(chan, node, c, ii)
+        if c.kind == 'slice':
+            if not jj:
+                return []
+            sliced.setdefault(c.uid, (c, set()))[1].update(jj)
+            return [d for c2 in c.outputs for d in out_deps(c, c2, jj)]
+        return [(c, _fns(c)[0], jj)]
 
-    seen = {}
-    stack = [(root, list(idxs))]
+    def in_deps(node, k, inp, ii):
+        jj = _to_input(chan, node, k, ii)
+        if inp.kind == 'slice':
+            if not jj:
+                return []
+            sliced.setdefault(inp.uid, (inp, set()))[1].update(jj)
+            return in_deps(inp, 0, inp.inputs[0], jj)
+        return [(inp, _fns(inp)[1], jj)]
+
+    entries = [(root, root_fn, list(idxs))]
+    present = {(root.uid, root_fn): {tuple(idxs)}}
+    visited = set()
+    stack = [entries[0]]
     while stack:
-        node, ii = stack.pop()
-        s = seen.setdefault(node.uid, set())
-        ii = [i for i in ii if i not in s]
-        if not ii:
-            continue
-        s.update(ii)
-        # ---- producer side
-        if node.kind in ('conv', 'linear'):
-            add(node.name, 'out', ii)
-        elif node.kind in ('gn', 'ln'):
-            add(node.name, node.kind, ii)
-            for inp in node.inputs:
-                stack.append((inp, ii))
-        elif node.kind == 'slice':
-            d = chan.out_channels(node)
-            stack.append((node.inputs[0], [i + node.part[0] * d for i in ii]))
-        elif node.kind == 'cat':
-            off = 0
-            for inp in node.inputs:
-                n_in = chan.out_channels(inp)
-                sub = [i - off for i in ii if off <= i < off + n_in]
-                if sub:
-                    stack.append((inp, sub))
-                off += n_in
-        else:
-            for inp in node.inputs:
-                stack.append((inp, ii))
-        # ---- consumer side
-        for c in node.outputs:
-            if c.kind in ('conv', 'linear'):
-                add(c.name, 'in', ii)
-            elif c.kind == 'cat':
-                off = 0
-                for inp in c.inputs:
-                    if inp is node:
-                        break
-                    off += chan.out_channels(inp)
-                stack.append((c, [i + off for i in ii]))
-            elif c.kind == 'slice':
-                d = chan.out_channels(c)
-                sub = [i - c.part[0] * d for i in ii if c.part[0] * d <= i < (c.part[0] + 1) * d]
-                if sub:
-                    stack.append((c, sub))
-            else:
-                stack.append((c, ii))
-    return [Member(n, k, sorted(members[(n, k)])) for (n, k) in order]
+        node, fn, ii = stack.pop()
+        visited.add(node.uid)
+        in_fn, out_fn = _fns(node)
+        deps = []
+        if fn == in_fn:
+            for k, inp in enumerate(node.inputs):
+                deps.extend(in_deps(node, k, inp, ii))
+        if fn == out_fn:
+            for c in node.outputs:
+                deps.extend(out_deps(node, c, ii))
+        for target, tfn, jj in deps:
+            if not jj:
+                continue
+            key = (target.uid, tfn)
+            tj = tuple(jj)
+            have = present.setdefault(key, set())
+            if target.uid in visited and tj in have:
+                continue
+            have.add(tj)
+            e = (target, tfn, jj)
+            entries.append(e)
+            stack.append(e)
+    merged, order = {}, []
+    for node, fn, ii in entries:
+        key = (node.uid, fn)
+        if key not in merged:
+            merged[key] = (node, fn, set())
+            order.append(key)
+        merged[key][2].update(ii)
+    out = []
+    for key in order:
+        node, fn, ii = merged[key]
+        if node.name is not None:
+            kind = fn if node.kind in ('conv', 'linear') else ('out' if node.kind == 'dw' else node.kind)
+            out.append(Member(node.name, kind, sorted(ii)))
+    if aux is not None:
+        aux.extend((n, len(ii)) for n, ii in sliced.values() if not isinstance(n.part[1], int))
+    return out
 
 
 def all_groups(graph, chan_fn, ignored=('conv_out',)):
@@ -347,7 +426,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
     `chan_fn()` returns a fresh ChannelView (channel counts change while the caller prunes between yields)."""
     visited = set()
     for node in graph.order:
-        if node.kind not in ('conv', 'linear'):
+        if node.kind not in ('conv', 'linear', 'dw'):
             continue
         if node.name in ignored or node.name in visited:
             continue
@@ -356,7 +435,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
         members = coupled_members(graph, chan, node.name, list(range(n_out)))
         prunable = True
         for m in members:
-            if m.kind in ('out', 'gn', 'ln'):        # members pruned through an out-channel pruning function
+            if m.kind in ('out', 'gn', 'ln', 'bn'):  # members pruned through an out-channel pruning function
                 visited.add(m.name)
                 if m.name in ignored:
                     prunable = False

@@ -108,7 +108,33 @@ def prune_layernorm_out_channels(layer, idxs):
         _slice_param(layer, 'bias', 0, keep)
     return layer
 
+def prune_batchnorm_out_channels(layer, idxs):
+    """function.py BatchnormPruner: slice the running statistics and (if affine) weight / bias."""
+    keep = _keep(layer.num_features, idxs, layer.running_mean.device if layer.running_mean is not None else layer.weight.device)
+    layer.num_features = layer.num_features - len(set(idxs))
+    if layer.track_running_stats:
+        layer.running_mean = layer.running_mean.data.index_select(0, keep)
+        layer.running_var = layer.running_var.data.index_select(0, keep)
+    if layer.affine:
+        _slice_param(layer, 'weight', 0, keep)
+        _slice_param(layer, 'bias', 0, keep)
+    return layer
+
+
+def prune_depthwise_conv_out_channels(layer, idxs):
+    """function.py DepthwiseConvPruner: one filter per channel, so in_channels, out_channels and groups shrink together."""
+    keep = _keep(layer.out_channels, idxs, layer.weight.device)
+    n = layer.out_channels - len(set(idxs))
+    layer.out_channels = layer.in_channels = layer.groups = n
+    _slice_param(layer, 'weight', 0, keep)
+    _slice_param(layer, 'bias', 0, keep)
+    return layer
+
+
 function = SimpleNamespace(
+    prune_batchnorm_out_channels=prune_batchnorm_out_channels, prune_batchnorm_in_channels=prune_batchnorm_out_channels,
+    prune_depthwise_conv_out_channels=prune_depthwise_conv_out_channels,
+    prune_depthwise_conv_in_channels=prune_depthwise_conv_out_channels,
     prune_conv_out_channels=prune_conv_out_channels, prune_conv_in_channels=prune_conv_in_channels,
     prune_linear_out_channels=prune_linear_out_channels, prune_linear_in_channels=prune_linear_in_channels,
     prune_groupnorm_out_channels=prune_groupnorm_out_channels, prune_groupnorm_in_channels=prune_groupnorm_in_channels,
@@ -120,6 +146,10 @@ def _handler_for(layer, kind):
         return prune_layernorm_out_channels
     if kind == 'gn':
         return prune_groupnorm_out_channels
+    if kind == 'bn':
+        return prune_batchnorm_out_channels
+    if isinstance(layer, nn.modules.conv._ConvNd) and layer.groups > 1:
+        return prune_depthwise_conv_out_channels
     if isinstance(layer, nn.Linear):
         return prune_linear_out_channels if kind == 'out' else prune_linear_in_channels
     return prune_conv_out_channels if kind == 'out' else prune_conv_in_channels
@@ -132,6 +162,8 @@ def _out_channels(layer):
         return layer.num_channels
     if isinstance(layer, nn.LayerNorm):
         return layer.normalized_shape[-1]
+    if isinstance(layer, nn.modules.batchnorm._BatchNorm):
+        return layer.num_features
     return layer.out_channels
 
 
@@ -142,6 +174,8 @@ def _in_channels(layer):
         return layer.num_channels
     if isinstance(layer, nn.LayerNorm):
         return layer.normalized_shape[-1]
+    if isinstance(layer, nn.modules.batchnorm._BatchNorm):
+        return layer.num_features
     return layer.in_channels
 
 
@@ -164,9 +198,10 @@ class Dependency:
 class Group:
     """Iterates as (dep, idxs), root first (dependency.py:143-191)."""
 
-    def __init__(self, items, dg=None):
+    def __init__(self, items, dg=None, aux=()):
         self._items = items
         self._DG = dg
+        self._aux = list(aux)       # traced graphs: (slice node, channels of it in this group), see graph.coupled_members
 
     def __iter__(self):
         return iter(self._items)
@@ -184,6 +219,10 @@ class Group:
             raise NotImplementedError('re-indexing an enumerated group: ask the graph for get_pruning_group(module, fn, idxs)')
         for dep, ix in self._items:
             dep(ix)
+        for node, n in self._aux:                  # the outputs of a torch.split shrink with the tensor that is split
+            j, info = node.part
+            info.sizes[j] -= n
+        self._aux = []
         if record_history and self._DG is not None and self._items:
             root, ridx = self._items[0]
             self._DG._pruning_history.append([root.target.name, root.kind != 'in', [int(i) for i in ridx]])
@@ -274,7 +313,7 @@ class TaylorImportance(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
-            if kind is None or kind == 'ln':          # LayerNorm members carry no term (importance.py:383-418)
+            if kind is None or kind in ('ln', 'bn'):  # LayerNorm / BatchNorm members carry no term (importance.py:383-418)
                 continue
             layer = dep.target.module
             if kind == 'gn' and (not layer.affine or not self.groupnorm_term):
@@ -341,7 +380,7 @@ class _GradCriterion(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
-            if kind is None or kind == 'ln':
+            if kind is None or kind in ('ln', 'bn'):
                 continue
             layer = dep.target.module
             if kind == 'gn' and (not layer.affine or not self.gn_modes):
@@ -453,15 +492,32 @@ def linear_scheduler(ch_sparsity, steps):
 
 
 class DependencyGraph:
-    """Group enumeration for UNet2DModel (see graph.py)."""
+    """Group enumeration (dependency.py:259-527).  For the two model families of this package the op graph is written
+    down from the model configuration (graph.py); any other module is traced through autograd with `example_inputs`
+    (trace.py), as `tp.DependencyGraph().build_dependency(model, example_inputs=...)` does."""
 
-    def __init__(self, model):
+    def __init__(self, model=None, example_inputs=None, forward_fn=None, output_transform=None):
+        self._pruning_history = []
+        if model is not None:
+            self.build_dependency(model, example_inputs, forward_fn, output_transform)
+
+    def build_dependency(self, model, example_inputs=None, forward_fn=None, output_transform=None):
+        """dependency.py:295-383.  Returns self."""
         self.model = model
-        cfg = dict(model.config)
-        self.graph = LdmGraph(cfg) if 'model_channels' in cfg else UNetGraph(cfg)
+        cfg = getattr(model, 'config', None)
+        cfg = dict(cfg) if cfg is not None and hasattr(cfg, 'keys') else {}
+        if 'model_channels' in cfg:
+            self.graph = LdmGraph(cfg)
+        elif 'block_out_channels' in cfg and 'down_block_types' in cfg:
+            self.graph = UNetGraph(cfg)
+        else:
+            if example_inputs is None:
+                raise ValueError('example_inputs are needed to trace %s' % type(model).__name__)
+            from .trace import TracedGraph
+            self.graph = TracedGraph(model, example_inputs, forward_fn, output_transform)
         self.name2module = dict(model.named_modules())
         self.module2name = {m: n for n, m in self.name2module.items()}
-        self._pruning_history = []
+        return self
 
     def pruning_history(self):
         """dependency.py:278-279: [[root module name, is_out_channel_pruning, idxs], ...] in application order."""
@@ -479,14 +535,15 @@ class DependencyGraph:
 
     def _chan(self):
         n2m = self.name2module
-        return ChannelView(lambda name: n2m[name].weight.shape[0])
+        return ChannelView(lambda name: _out_channels(n2m[name]))
 
-    def _group(self, members):
-        return Group([(Dependency(self.name2module[m.name], m.name, m.kind), list(m.idxs)) for m in members], self)
+    def _group(self, members, aux=()):
+        return Group([(Dependency(self.name2module[m.name], m.name, m.kind), list(m.idxs)) for m in members], self, aux)
 
     def get_pruning_group(self, module, pruning_fn, idxs):
         name = self.module2name[module]
-        return self._group(coupled_members(self.graph, self._chan(), name, list(idxs)))
+        aux = []
+        return self._group(coupled_members(self.graph, self._chan(), name, list(idxs), aux), aux)
 
     def get_all_groups(self, ignored_layers=(), root_module_types=(nn.Conv2d, nn.Linear)):
         ignored = tuple(self.module2name[m] for m in ignored_layers if m in self.module2name)
@@ -495,7 +552,7 @@ class DependencyGraph:
 
     def check_pruning_group(self, group):
         for dep, idxs in group:
-            n = _out_channels(dep.target.module) if dep.kind in ('out', 'gn', 'ln') else _in_channels(dep.target.module)
+            n = _out_channels(dep.target.module) if dep.kind in ('out', 'gn', 'ln', 'bn') else _in_channels(dep.target.module)
             if n <= len(idxs):
                 return False
         return True
@@ -517,14 +574,14 @@ class MetaPruner:
         self.ch_sparsity, self.max_ch_sparsity = ch_sparsity, max_ch_sparsity
         self.round_to, self.root_module_types = round_to, root_module_types
         self.channel_groups = dict(channel_groups) if channel_groups else {}
-        self.DG = DependencyGraph(model)
+        self.DG = DependencyGraph(model, example_inputs)
         self.ignored_layers = []
         for layer in (ignored_layers or []):
             self.ignored_layers.extend(list(layer.modules()))
         self.iterative_steps, self.current_step = iterative_steps, 0
         self.layer_init_out_ch, self.layer_init_in_ch = {}, {}
         for m in model.modules():
-            if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
+            if isinstance(m, (nn.modules.conv._ConvNd, nn.Linear, nn.GroupNorm, nn.LayerNorm, nn.modules.batchnorm._BatchNorm)):
                 self.layer_init_out_ch[m] = _out_channels(m)
                 self.layer_init_in_ch[m] = _in_channels(m)
         self.per_step_ch_sparsity = iterative_sparsity_scheduler(ch_sparsity, iterative_steps)
@@ -563,7 +620,7 @@ class MetaPruner:
     def _check_sparsity(self, group):
         for dep, _ in group:
             m = dep.target.module
-            if dep.kind in ('out', 'gn', 'ln'):
+            if dep.kind in ('out', 'gn', 'ln', 'bn'):
                 n = _out_channels(m)
                 if n < self.layer_init_out_ch[m] * (1 - self.max_ch_sparsity) or n == 1:
                     return False

@@ -88,6 +88,12 @@ def kind_of(dep):
         return 'in'
     if h == f.prune_groupnorm_out_channels:
         return 'gn'
+    if h in (f.prune_batchnorm_out_channels, f.prune_batchnorm_in_channels):
+        return 'bn'
+    if h in (f.prune_layernorm_out_channels, f.prune_layernorm_in_channels):
+        return 'ln'
+    if h in (f.prune_depthwise_conv_out_channels, f.prune_depthwise_conv_in_channels):
+        return 'out'
     return 'other'
 
 
@@ -637,6 +643,34 @@ def do_dropout():
     json.dump(dict(p=0.1, seed=seed, step=step, sites=n_sites, loss=float(loss), fwd_out=gc.f32_to_b64(out.detach().numpy()),
                    grad_stats=grad_stats(model)), open(os.path.join(HERE, 'tiny_dropout.json'), 'w'))
     print('dropout ok: sites', n_sites, 'loss', float(loss))
+
+
+def do_traced():
+    """Row f2: the reference's DependencyGraph (autograd trace) and MagnitudePruner on the toy networks of toy_nets.py:
+    group tables in visiting order, then a whole pruning pass (ratio 0.5, deterministic index scores) with its
+    pruning history, the parameter shapes afterwards and the output shapes of the pruned network."""
+    import toy_nets
+    res = {}
+    for name in toy_nets.NETS:
+        model, inputs, ignored = toy_nets.build(name)
+        names = name_of(model)
+        pruner = tp.pruner.MagnitudePruner(model, inputs, importance=toy_nets.IndexScore(), iterative_steps=1,
+                                           ch_sparsity=0.5, ignored_layers=ignored)
+        table = [dict(ch_groups=int(pruner.get_channel_groups(g)), members=dump_group(g, names))
+                 for g in pruner.DG.get_all_groups(ignored_layers=pruner.ignored_layers,
+                                                   root_module_types=pruner.root_module_types)]
+        pruned = []
+        for g in pruner.step(interactive=True):
+            pruned.append(dump_group(g, names))
+            g.prune()
+        with torch.no_grad():
+            out = model(*inputs)
+        outs = [list(o.shape) for o in (out if isinstance(out, tuple) else (out,))]
+        hist = [[n, bool(o), sorted(int(i) for i in ix)] for n, o, ix in pruner.DG.pruning_history()]
+        res[name] = dict(groups=table, pruned_groups=pruned, history=hist, out_shapes=outs,
+                         shapes={k: list(v.shape) for k, v in model.state_dict().items()})
+        print('traced', name, len(table), 'groups,', len(pruned), 'pruned, params', sum(p.numel() for p in model.parameters()))
+    json.dump(res, open(os.path.join(HERE, 'traced_groups.json'), 'w'))
 
 
 if __name__ == '__main__':

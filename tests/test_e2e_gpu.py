@@ -1036,3 +1036,47 @@ def test_compare_directories_ssim_and_fid_paths(report, tmp_path):
     report['e2e/ssim_fid_paths'] = dict(ssim=s, ssim_ref=s_ref, mse=m, mse_ref=m_ref, fid_self=f_self, fid_ab=f_ab, fid_npz=f_npz)
     assert abs(s - s_ref) < 1e-5 and abs(m - m_ref) < 1e-6 * max(m_ref, 1e-9) + 1e-9
     assert abs(f_self) < 1e-3 and f_ab > 0 and abs(f_ab - f_npz) < 1e-6 * max(f_ab, 1.0)
+
+
+@pytest.mark.parametrize('name', ['res_cat', 'plain_cnn', 'token_mixer'])
+def test_traced_model_taylor_prune_on_device(report, name):
+    """Row f2: the device criterion on a network that is NOT one of the two UNet families.  A plain-PyTorch toy network
+    (tests/golden/toy_nets.py) lives on the GPU, its gradients come from torch autograd, the groups from the autograd
+    tracer (trace.py) and the scores from the HIP kernels (dp_wg_reduce / dp_gather_add): every group's score equals the
+    vendored criterion's formula (importance.py:383-428: sum over same-sized members of sum((w*g)^2) resp. |w*g| for
+    GroupNorm; BatchNorm / LayerNorm members add nothing) and the pruned network still runs."""
+    import toy_nets
+    pruning = pkg('pruning')
+    model, inputs, ignored = toy_nets.build(name)
+    model = model.cuda()
+    inputs = tuple(t.cuda() for t in inputs)
+    out = model(*inputs)
+    out.square().mean().backward()
+    pr = pruning.MetaPruner(model, inputs, importance=pruning.TaylorImportance(), iterative_steps=1, ch_sparsity=0.3,
+                            ignored_layers=ignored)
+    worst, n_groups = 0.0, 0
+    for g in pr.step(interactive=True):
+        root, ch_groups, score, idxs = pr.records[-1]
+        all_g = next(gg for gg in pr.DG.get_all_groups(pr.ignored_layers) if gg[0][0].target.name == root)
+        n0 = len(all_g[0][1])
+        want = torch.zeros(n0, dtype=torch.float64)
+        for dep, ix in all_g:
+            m = dep.target.module
+            if len(ix) != n0 or dep.kind in ('ln', 'bn'):
+                continue
+            wg = (m.weight.data.double() * m.weight.grad.data.double()).cpu()
+            if dep.kind == 'out':
+                want += wg[ix].flatten(1).square().sum(1)
+            elif dep.kind == 'in':
+                want += wg.transpose(0, 1).flatten(1)[ix].square().sum(1)
+            elif dep.kind == 'gn':
+                want += wg[ix].abs()
+        err = float((score.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        worst = max(worst, err)
+        assert err < 1e-5, (root, err)
+        g.prune()
+        n_groups += 1
+    with torch.no_grad():
+        y = model(*inputs)
+    assert torch.isfinite(y).all() and n_groups >= 3
+    report['traced/%s' % name] = dict(groups=n_groups, score_rel_err=worst, params_after=sum(p.numel() for p in model.parameters()))
