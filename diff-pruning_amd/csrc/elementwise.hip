@@ -297,6 +297,53 @@ extern "C" int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// nearest x2 upsampling, materialised (F.interpolate(scale_factor=2.0, mode="nearest"), resnet.py:155): one thread per 4
+// consecutive output pixels (= 2 source pixels) when W is even, per output pixel otherwise.  The upsample convolution then
+// is a plain stride-1 convolution and runs on the LDS-DMA kernels; the gather form stays for foreign callers.
+// ---------------------------------------------------------------------------------------------
+__global__ void upsample2x_kernel(const float* __restrict__ x, long long x_img_stride, int N, int C, int H, int W,
+                                  float* __restrict__ y, long long y_img_stride, int vec) {
+    const int Wo = 2 * W, Ho = 2 * H;
+    if (vec) {
+        const int W4 = Wo / 4;
+        const long long per = (long long)C * Ho * W4;
+        const long long total = (long long)N * per;
+        GS_LOOP(i, total) {
+            const long long n = i / per;
+            const long long r = i - n * per;
+            const int w4 = (int)(r % W4);
+            const long long ch = r / W4;            // c*Ho + ho
+            const int ho = (int)(ch % Ho);
+            const long long c = ch / Ho;
+            const float2 s = *reinterpret_cast<const float2*>(x + n * x_img_stride + (c * H + (ho >> 1)) * (long long)W + 2 * w4);
+            *reinterpret_cast<float4*>(y + n * y_img_stride + ch * Wo + 4 * w4) = make_float4(s.x, s.x, s.y, s.y);
+        }
+    } else {
+        const long long per = (long long)C * Ho * Wo;
+        const long long total = (long long)N * per;
+        GS_LOOP(i, total) {
+            const long long n = i / per;
+            const long long r = i - n * per;
+            const int wo = (int)(r % Wo);
+            const long long ch = r / Wo;
+            const int ho = (int)(ch % Ho);
+            const long long c = ch / Ho;
+            y[n * y_img_stride + r] = x[n * x_img_stride + (c * H + (ho >> 1)) * (long long)W + (wo >> 1)];
+        }
+    }
+}
+extern "C" int dp_upsample2x(const float* x, long long x_img_stride, int N, int C, int H, int W, float* y,
+                             long long y_img_stride, void* stream) {
+    const int vec = (W % 2 == 0) && (x_img_stride % 2 == 0) && (y_img_stride % 4 == 0) && ((uintptr_t)x % 8 == 0) &&
+                    ((uintptr_t)y % 16 == 0);
+    const long long total = (long long)N * C * (2 * H) * (vec ? W / 2 : 2 * W);
+    if (total <= 0) return 0;
+    DP_LAUNCH(upsample2x_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_img_stride, N, C, H, W, y,
+                       y_img_stride, vec);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // DDIM update (scheduling_ddim.py:324-370)
 // ---------------------------------------------------------------------------------------------
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ vn,

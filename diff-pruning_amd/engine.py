@@ -20,6 +20,7 @@ from . import ops
 _SPEC3 = ops.ConvSpec(3, 1, 1, 0)
 _SPEC1 = ops.ConvSpec(1, 1, 0, 0)
 _SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
+UPS_COPY = not os.environ.get('DP_NO_UPS_COPY')
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
 RES_DIFFUSERS = dict(norm1='.norm1', conv1='.conv1', temb='.time_emb_proj', norm2='.norm2', conv2='.conv2',
@@ -524,8 +525,10 @@ class UNetEngine:
                 if bt == 'AttnUpBlock2D':
                     x = self.attn_fwd('%s.attentions.%d' % (pre, j), x, self.attn_scale(rev[i]), 1.0, ctx, self.attn_heads(rev[i]))
             if i != nb - 1:
-                xin = x
-                x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC_UP)
+                # the x2-upsampled tensor is materialised (4x a low-resolution activation, HBM-bound) so that the convolution
+                # and its weight gradient are plain stride-1 launches on the LDS-DMA kernels (see ops.upsample2x)
+                xin = ops.upsample2x(x) if UPS_COPY else x
+                x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC3 if UPS_COPY else _SPEC_UP)
                 if ctx is not None:
                     ctx[pre + '.up'] = xin
         G, eps = cfg['norm_num_groups'], cfg['norm_eps']
@@ -563,8 +566,11 @@ class UNetEngine:
             pre = 'up_blocks.%d' % i
             if i != nb - 1:
                 xin = ctx.pop(pre + '.up')
-                dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC_UP,
-                                     (2 * xin.shape[2], 2 * xin.shape[3]))
+                if UPS_COPY:
+                    dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC3, (xin.shape[2], xin.shape[3]))
+                else:
+                    dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC_UP,
+                                         (2 * xin.shape[2], 2 * xin.shape[3]))
                 dx = ops.downsum2x2(dxv)
                 del dxv
             local = []

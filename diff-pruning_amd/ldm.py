@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import engine as engine_mod
 from .engine import UNetEngine, RES_LDM, _SPEC1, _SPEC3, _SPEC_UP, _PinnedWeights
 
 _SPEC_DOWN = ops.ConvSpec(3, 2, 1, 0)
@@ -316,8 +317,8 @@ class LdmEngine(UNetEngine):
                 elif it[0] == 'st':
                     h = self.st_fwd(pre, h, ctx2d, it[1], ctx)
                 else:
-                    hin = h
-                    h = self._conv(pre + '.conv', hin, None, _SPEC_UP)
+                    hin = ops.upsample2x(h) if engine_mod.UPS_COPY else h          # see UNetEngine.forward
+                    h = self._conv(pre + '.conv', hin, None, _SPEC3 if engine_mod.UPS_COPY else _SPEC_UP)
                     if ctx is not None:
                         ctx[pre] = hin
         ho = h
@@ -347,7 +348,10 @@ class LdmEngine(UNetEngine):
                 pre = 'output_blocks.%d.%d' % (bi, li)
                 if it[0] == 'up':
                     hin = ctx.pop(pre)
-                    dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC_UP, (2 * hin.shape[2], 2 * hin.shape[3]))
+                    if engine_mod.UPS_COPY:
+                        dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC3, (hin.shape[2], hin.shape[3]))
+                    else:
+                        dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC_UP, (2 * hin.shape[2], 2 * hin.shape[3]))
                     dx = ops.downsum2x2(dxv)
                 elif it[0] == 'st':
                     dx = self.st_bwd(pre, dx)

@@ -848,6 +848,15 @@ def downsum2x2(dy, out=None):
     return out
 
 
+def upsample2x(x):
+    """Nearest x2 upsampling into a fresh (guarded) activation."""
+    sx = _chk_act(x)
+    N, Cc, H, W = x.shape
+    out = empty_act((N, Cc, 2 * H, 2 * W), x.device)
+    L.check(_lib().dp_upsample2x(_p(x), sx, N, Cc, H, W, _p(out), _chk_act(out), _stream()), 'dp_upsample2x')
+    return out
+
+
 def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
     """Taylor-importance channel reduction of one member.  w/g: [R, C, T...] contiguous (or 1-D for mode 3)."""
     assert w.is_contiguous() and g.is_contiguous() and w.shape == g.shape

@@ -202,6 +202,11 @@ int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* 
 /* dx[n][c][h][w] = sum of the 2x2 block of dy (backward of nearest x2 upsampling, resnet.py:155) */
 int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H, int W, float* dx, long long dx_img_stride, void* stream);
 
+/* y[n][c][2h+i][2w+j] = x[n][c][h][w]: nearest x2 upsampling, materialised (F.interpolate(scale_factor=2.0,
+ * mode="nearest") in Upsample2D, diffusers/models/resnet.py:155; openaimodel.py Upsample).  The conv that follows is then a
+ * plain stride-1 conv (dp_conv_gemm with ups = 0) instead of the gather form (ups = 1). */
+int dp_upsample2x(const float* x, long long x_img_stride, int N, int C, int H, int W, float* y, long long y_img_stride, void* stream);
+
 /* Taylor-importance reductions  (ddpm_exp/torch_pruning/importance.py:375-434).
  * Weight viewed as [R][C][T]; dim = 0: out[r] = sum_{c,t} f(w*g); dim = 1: out[c] = sum_{r,t} f(w*g);
  * mode 0: f = (w g)^2 (vendored), mode 1: f = |w g| (sum_abs), mode 2: signed sum then |.| (abs_sum),

@@ -670,6 +670,26 @@ def do_traced():
         res[name] = dict(groups=table, pruned_groups=pruned, history=hist, out_shapes=outs,
                          shapes={k: list(v.shape) for k, v in model.state_dict().items()})
         print('traced', name, len(table), 'groups,', len(pruned), 'pruned, params', sum(p.numel() for p in model.parameters()))
+    # Pin of the tracer itself, only possible here: THIS repository's tracer applied to the REFERENCE's Diffusers
+    # UNet2DModel modules must enumerate exactly the groups the reference's DependencyGraph enumerates on them.
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    own_trace = importlib.import_module('diff-pruning_amd.trace')
+    own_graph = importlib.import_module('diff-pruning_amd.graph')
+    own_pruning = importlib.import_module('diff-pruning_amd.pruning')
+    pinned = {}
+    for cfgname, cfg, H in (('tiny', gc.TINY_CFG, 16), ('cifar', gc.CIFAR_CFG, 32)):
+        model = build_ref_unet(cfg, 0)
+        ref = [t['members'] for t in group_table(model, H)]
+        tg = own_trace.TracedGraph(model, {'sample': torch.randn(1, 3, H, H), 'timestep': torch.ones((1,)).long()})
+        n2m = dict(model.named_modules())
+        chan = own_graph.ChannelView(lambda name: own_pruning._out_channels(n2m[name]))
+        mine = [[[m.name, m.kind, compress(m.idxs)] for m in members]
+                for _, members in own_graph.all_groups(tg, lambda: chan, ('conv_out',))]
+        assert mine == ref, cfgname
+        pinned[cfgname] = len(mine)
+    res['_own_tracer_on_reference_unet2d_groups_equal'] = pinned
+    print('own tracer on the reference UNet2DModel: groups equal', pinned)
     json.dump(res, open(os.path.join(HERE, 'traced_groups.json'), 'w'))
 
 

@@ -29,7 +29,7 @@ class PlainCNN(nn.Module):
 
 
 class ResCat(nn.Module):
-    """GroupNorm residual block, a skip concatenation, and a chunk whose halves feed different convolutions."""
+    """GroupNorm residual block, a skip concatenation, and a split whose parts feed different convolutions."""
 
     def __init__(self, swap=False):
         super().__init__()
@@ -55,7 +55,7 @@ class ResCat(nn.Module):
         d = self.mid(F.relu(self.down(skip)))
         u = self.up(F.interpolate(d, scale_factor=2.0, mode='nearest'))
         f = self.fuse(torch.cat([u, skip], dim=1))
-        a, b = f.chunk(2, dim=1)
+        a, b = f.split([self.left.in_channels, self.right.in_channels], dim=1)     # sizes follow the pruned layers
         if self.swap:       # the reference numbers the outputs of a split in TRACE order (dependency.py:825-853), which is
             return self.head(self.left(a) + self.right(b))      # the reverse of the chunk order here: see test_cpu
         return self.head(self.right(b) + self.left(a))

@@ -290,6 +290,10 @@ def downsum2x2(dy, out=None):
     return F.avg_pool2d(dy, 2) * 4
 
 
+def upsample2x(x):
+    return F.interpolate(x, scale_factor=2.0, mode='nearest')
+
+
 def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
     p = w * g
     if mode == 3:

@@ -714,3 +714,24 @@ def test_groupnorm_bwd_row_sums(ops, report, N, C1, C2, H, G):
     e = relerr(rows, dx.double().cpu().sum((2, 3)))
     report['gn_rows/%d_%d_%d_%d' % (N, C1, C2, H)] = e
     assert e < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 7, 3, 5), (1, 2, 1, 1), (4, 16, 16, 16)], ids=str)
+def test_upsample2x_equals_nearest_interpolate(ops, report, shape):
+    """dp_upsample2x (vector path for even widths, scalar otherwise, channel-slice sources) is F.interpolate(nearest, x2) bit for
+    bit; the materialised-upsample convolution equals the gather-form (ups = 1) convolution it replaces."""
+    N, C, H, W = shape
+    x = rnd(N, C, H, W, seed=1)
+    y = ops.upsample2x(x)
+    assert torch.equal(y.cpu(), F.interpolate(x.cpu(), scale_factor=2.0, mode='nearest'))
+    big = rnd(N, C + 3, H, W, seed=2)
+    ys = ops.upsample2x(big[:, 1:1 + C])
+    assert torch.equal(ys.cpu(), F.interpolate(big[:, 1:1 + C].cpu(), scale_factor=2.0, mode='nearest'))
+    w = rnd(6, C, 3, 3, seed=3, scale=0.2)
+    b = rnd(6, seed=4)
+    wp, ld = ops.pack_weight(w, 0)
+    a = ops.conv_forward(y, None, wp, ld, 6, ops.ConvSpec(3, 1, 1, 0), bias=b)
+    g = ops.conv_forward(x, None, wp, ld, 6, ops.ConvSpec(3, 1, 1, 1), bias=b)
+    e = relerr(a, g.double().cpu())
+    report['upsample2x/%s' % (shape,)] = dict(conv_vs_gather_form=e)
+    assert e < 2e-6
