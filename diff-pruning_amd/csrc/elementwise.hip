@@ -344,6 +344,63 @@ extern "C" int dp_upsample2x(const float* x, long long x_img_stride, int N, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Input gradient of a stride-2 3x3 convolution, assembled from its four parity classes: dx[2i+ph][2j+pw] = q[2ph+pw][i][j]
+// (+ add: the skip-connection gradient that the caller would otherwise add in a second pass).  See ops.conv_dgrad_s2.
+// ---------------------------------------------------------------------------------------------
+__global__ void interleave2x2_kernel(const float* __restrict__ q, long long q_class_stride, long long q_img_stride, int N, int C,
+                                     int Ho, int Wo, const float* __restrict__ add, long long add_img_stride,
+                                     float* __restrict__ dx, long long dx_img_stride, int vec) {
+    const int W = 2 * Wo, H = 2 * Ho;
+    if (vec) {                                   // one thread: 4 consecutive output pixels of one row = 2 + 2 class elements
+        const int W4 = W / 4;
+        const long long per = (long long)C * H * W4;
+        const long long total = (long long)N * per;
+        GS_LOOP(t, total) {
+            const long long n = t / per;
+            const long long r = t - n * per;
+            const int w4 = (int)(r % W4);
+            const long long ch = r / W4;            // c*H + h
+            const int h = (int)(ch % H);
+            const long long c = ch / H;
+            const float* qb = q + (long long)(2 * (h & 1)) * q_class_stride + n * q_img_stride + (c * Ho + (h >> 1)) * (long long)Wo + 2 * w4;
+            const float2 a = *reinterpret_cast<const float2*>(qb);
+            const float2 b = *reinterpret_cast<const float2*>(qb + q_class_stride);
+            float4 o = make_float4(a.x, b.x, a.y, b.y);
+            const long long oi = ch * W + 4 * w4;
+            if (add) {
+                const float4 s = *reinterpret_cast<const float4*>(add + n * add_img_stride + oi);
+                o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+            }
+            *reinterpret_cast<float4*>(dx + n * dx_img_stride + oi) = o;
+        }
+    } else {
+        const long long per = (long long)C * H * W;
+        const long long total = (long long)N * per;
+        GS_LOOP(t, total) {
+            const long long n = t / per;
+            const long long r = t - n * per;
+            const int w = (int)(r % W);
+            const long long ch = r / W;
+            const int h = (int)(ch % H);
+            const long long c = ch / H;
+            float v = q[(long long)(2 * (h & 1) + (w & 1)) * q_class_stride + n * q_img_stride + (c * Ho + (h >> 1)) * (long long)Wo + (w >> 1)];
+            if (add) v += add[n * add_img_stride + r];
+            dx[n * dx_img_stride + r] = v;
+        }
+    }
+}
+extern "C" int dp_interleave2x2(const float* q, long long q_class_stride, long long q_img_stride, int N, int C, int Ho, int Wo,
+                                const float* add, long long add_img_stride, float* dx, long long dx_img_stride, void* stream) {
+    const int vec = (Wo % 2 == 0) && (q_class_stride % 2 == 0) && (q_img_stride % 2 == 0) && (dx_img_stride % 4 == 0) &&
+                    (add_img_stride % 4 == 0) && ((uintptr_t)q % 8 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)add % 16 == 0);
+    const long long total = (long long)N * C * (2 * Ho) * (vec ? Wo / 2 : 2 * Wo);
+    if (total <= 0) return 0;
+    DP_LAUNCH(interleave2x2_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, q, q_class_stride, q_img_stride, N,
+                       C, Ho, Wo, add, add_img_stride, dx, dx_img_stride, vec);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // DDIM update (scheduling_ddim.py:324-370)
 // ---------------------------------------------------------------------------------------------
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ vn,

@@ -21,6 +21,7 @@ _SPEC3 = ops.ConvSpec(3, 1, 1, 0)
 _SPEC1 = ops.ConvSpec(1, 1, 0, 0)
 _SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
 UPS_COPY = not os.environ.get('DP_NO_UPS_COPY')
+S2_PARITY = not os.environ.get('DP_NO_S2_PARITY')
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
 RES_DIFFUSERS = dict(norm1='.norm1', conv1='.conv1', temb='.time_emb_proj', norm2='.norm2', conv2='.conv2',
@@ -68,7 +69,10 @@ class _Packs:
         hit = self._c.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1], hit[2]
-        buf, ld = ops.pack_weight(w, mode)
+        if isinstance(mode, tuple):               # ('s2', ph, pw, pad): one parity class of a stride-2 dgrad (ops.conv_dgrad_s2)
+            buf, ld = ops.pack_weight_s2(w, mode[1], mode[2], mode[3])
+        else:
+            buf, ld = ops.pack_weight(w, mode)
         self._c[key] = (tag, buf, ld)
         return buf, ld
 
@@ -293,8 +297,8 @@ class UNetEngine:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def _conv_bwd(self, name, dy, x, x2, spec, in_hw, *, need_dx=True, rows=None, dx_out=None, dx_accumulate=False,
-                  alpha=1.0):
-        """Accumulate weight / bias gradients of conv `name`; return gradient w.r.t. its (virtual) input."""
+                  alpha=1.0, dx_add=None):
+        """Accumulate weight / bias gradients of conv `name`; return gradient w.r.t. its (virtual) input (+ dx_add)."""
         w = self.P[name + '.weight']
 
         if rows is None and (name + '.bias') in self.P and self._rows_src is not None and self._rows_src[0].data_ptr() == dy.data_ptr():
@@ -318,8 +322,15 @@ class UNetEngine:
                 param_grads(rows)
         if not need_dx:
             return None
+        if (S2_PARITY and spec.stride == 2 and spec.k == 3 and not spec.ups and spec.pad in (0, 1) and alpha == 1.0
+                and dx_out is None and in_hw[0] == 2 * dy.shape[2] and in_hw[1] == 2 * dy.shape[3]):
+            packs = [self.packs.get(name, w, ('s2', ph, pw, spec.pad)) for ph in (0, 1) for pw in (0, 1)]
+            return ops.conv_dgrad_s2(dy, packs, w.shape[1], spec, in_hw, add=dx_add)
         wd, ldd = self.packs.get(name, w, 1)
-        return ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
+        dx = ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
+        if dx_add is not None:
+            ops.copy_strided(dx_add, dx, accumulate=True)
+        return dx
 
     def _gn_param_grads(self, name, pws):
         N, C = pws.shape[0], pws.shape[1]
@@ -606,10 +617,8 @@ class UNetEngine:
             if i != nb - 1:
                 # dx is the full gradient of the downsampler output (skips[idx]); its input is skips[idx-1]
                 xin, spec = ctx.pop(pre + '.down')
-                dxd = self._conv_bwd(pre + '.downsamplers.0.conv', dx, xin, None, spec, tuple(xin.shape[2:]))
                 idx -= 1
-                ops.copy_strided(sg.pop(idx), dxd, accumulate=True)
-                dx = dxd
+                dx = self._conv_bwd(pre + '.downsamplers.0.conv', dx, xin, None, spec, tuple(xin.shape[2:]), dx_add=sg.pop(idx))
             for j in reversed(range(Lr)):
                 # dx = full gradient of skips[idx] (output of resnet j / its attention)
                 if bt == 'AttnDownBlock2D':

@@ -375,9 +375,7 @@ class LdmEngine(UNetEngine):
                     dx = self.resnet_bwd(pre, dx, semb, d_semb, extra=extra)
                 elif it[0] == 'down':
                     hin = ctx.pop(pre)
-                    dxd = self._conv_bwd(pre + '.op', dx, hin, None, _SPEC_DOWN, tuple(hin.shape[2:]))
-                    ops.copy_strided(extra, dxd, accumulate=True)
-                    dx = dxd
+                    dx = self._conv_bwd(pre + '.op', dx, hin, None, _SPEC_DOWN, tuple(hin.shape[2:]), dx_add=extra)
                 else:
                     self._conv_bwd(pre, dx, x, None, _SPEC3, None, need_dx=False)
         assert not sg

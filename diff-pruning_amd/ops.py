@@ -323,6 +323,61 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     return out
 
 
+def _s2_taps(parity, pad):
+    """Stride-2, k = 3: which kernel taps reach input positions of this parity, and the top / left padding of the small
+    stride-1 convolution over dy that computes them.  dX[2i+p] = sum_k dy[(2i + p + pad - k) / 2] w[k] over the k with
+    (p + pad - k) even: k in {0, 2} (rows i+e-1, i+e of dy, e = (p+pad)/2) or k = 1 (row i)."""
+    if (parity + pad) % 2 == 0:
+        return [0, 2], 1 - (parity + pad) // 2
+    return [1], 0
+
+
+def pack_weight_s2(w, ph, pw, pad):
+    """dgrad operand of parity class (ph, pw) of a stride-2 3x3 convolution: the taps of that class in natural order; the
+    tap flip of pack_weight(mode 1) then puts k = 2 on the earlier dy row / column, as the formula above wants."""
+    kh, _ = _s2_taps(ph, pad)
+    kw, _ = _s2_taps(pw, pad)
+    sh = slice(0, 3, 2) if len(kh) == 2 else slice(1, 2)          # views, not index tensors: no host -> device copies
+    sw = slice(0, 3, 2) if len(kw) == 2 else slice(1, 2)
+    return pack_weight(w[:, :, sh, sw].contiguous(), 1)
+
+
+def conv_dgrad_s2(dy, packs, Cin, spec, in_hw, add=None):
+    """Input gradient of a stride-2 3x3 convolution (pad 0 = the reference's asymmetric (0,1,0,1) pad, or symmetric pad 1) as
+    four stride-1 convolutions over dy, one per parity class of the input position (4 + 2 + 2 + 1 = 9 taps per 2x2 block of
+    input pixels: the algorithmic work; the zero-inserted form of conv_dgrad spends 36), interleaved by dp_interleave2x2, which
+    also adds `add` (the skip-connection gradient).  packs: [pack_weight_s2(w, ph, pw, spec.pad) for ph in (0,1) for pw in (0,1)]."""
+    sd = _chk_act(dy)
+    N, Cout, Ho, Wo = dy.shape
+    H, W = in_hw
+    assert spec.k == 3 and spec.stride == 2 and H == 2 * Ho and W == 2 * Wo
+    q = empty_act((4, N, Cin, Ho, Wo), dy.device)
+    for ph in (0, 1):
+        th, pad_h = _s2_taps(ph, spec.pad)
+        for pw in (0, 1):
+            tw, pad_w = _s2_taps(pw, spec.pad)
+            wd, ldd = packs[2 * ph + pw]
+            out = q[2 * ph + pw]
+            p = L.ConvGemmParams()
+            p.A, p.a_bs, p.lda, p.a_kc = _p(wd), 0, ldd, 0
+            p.X1, p.X2, p.x_bs = _p(dy), None, 0
+            p.x_guard = 1 if _guarded(dy) else 0
+            p.a_bytes, p.x1_bytes, p.x2_bytes = wd.numel() * 4, _extent_bytes(dy), 0
+            p.g = _geom(Ho, Wo, Ho, Wo, Ho, Wo, len(tw), 1, 1, pad_h, pad_w, 0, Cout, sd, 0)
+            p.M, p.C, p.NPIX, p.ntaps, p.batches = Cin, Cout, N * Ho * Wo, len(th) * len(tw), 1
+            p.tile = pick_tile(Cin, N * Ho * Wo)
+            _prefer_tile96(p)
+            p.out, p.o_img_stride, p.o_bs = _p(out), Cin * Ho * Wo, 0
+            p.alpha, p.post_scale = 1.0, 1.0
+            _conv_ksplit(p, dy.device)
+            L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
+                         4.0 * (dy.numel() + wd.numel() + out.numel())), 'dp_conv_gemm(dgrad, stride-2 parity class)')
+    dx = empty_act((N, Cin, H, W), dy.device)
+    L.check(_lib().dp_interleave2x2(_p(q), q.stride(0), q.stride(1), N, Cin, Ho, Wo, _p(add),
+                                    _chk_act(add) if add is not None else 0, _p(dx), _chk_act(dx), _stream()), 'dp_interleave2x2')
+    return dx
+
+
 _ws_cache = {}
 WGRAD_BLOCKS = 1024          # target workgroups per wgrad launch (256 CUs x 4 resident workgroups)
 WGRAD_MIN_PIX = int(os.environ.get('DP_WGRAD_MIN_PIX', '128'))      # fewest pixels per split-K slice of a weight gradient

@@ -207,6 +207,14 @@ int dp_downsum2x2(const float* dy, long long dy_img_stride, int N, int C, int H,
  * plain stride-1 conv (dp_conv_gemm with ups = 0) instead of the gather form (ups = 1). */
 int dp_upsample2x(const float* x, long long x_img_stride, int N, int C, int H, int W, float* y, long long y_img_stride, void* stream);
 
+/* dx[n][c][2i+ph][2j+pw] = q[(2ph+pw)*q_class_stride + n*q_img_stride + (c*Ho+i)*Wo + j] (+ add[n][c][2i+ph][2j+pw]).
+ * Assembles the input gradient of a stride-2 3x3 convolution (Downsample2D, diffusers/models/resnet.py:218; openaimodel.py
+ * Downsample) from its four parity classes, each of which is a small stride-1 convolution over dy with the 4 / 2 / 2 / 1 taps
+ * that can reach that parity (dp_conv_gemm): 9/4 taps per input pixel instead of the 9 of the zero-inserted form.
+ * `add` (optional) is the skip-connection gradient the caller adds to dx (ConvolutionBackward + AddBackward in autograd). */
+int dp_interleave2x2(const float* q, long long q_class_stride, long long q_img_stride, int N, int C, int Ho, int Wo,
+                     const float* add, long long add_img_stride, float* dx, long long dx_img_stride, void* stream);
+
 /* Taylor-importance reductions  (ddpm_exp/torch_pruning/importance.py:375-434).
  * Weight viewed as [R][C][T]; dim = 0: out[r] = sum_{c,t} f(w*g); dim = 1: out[c] = sum_{r,t} f(w*g);
  * mode 0: f = (w g)^2 (vendored), mode 1: f = |w g| (sum_abs), mode 2: signed sum then |.| (abs_sum),

@@ -78,6 +78,15 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     return dx.contiguous()
 
 
+def pack_weight_s2(w, ph, pw, pad):
+    return w, 1
+
+
+def conv_dgrad_s2(dy, packs, Cin, spec, in_hw, add=None):
+    dx = conv_dgrad(dy, packs[0][0], packs[0][1], Cin, spec, in_hw)
+    return dx if add is None else dx + add
+
+
 def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=None):
     xin = _prep(_cat(x, x2), spec)
     k = spec.k

@@ -735,3 +735,30 @@ def test_upsample2x_equals_nearest_interpolate(ops, report, shape):
     e = relerr(a, g.double().cpu())
     report['upsample2x/%s' % (shape,)] = dict(conv_vs_gather_form=e)
     assert e < 2e-6
+
+
+@pytest.mark.parametrize('case', [(2, 24, 40, 8, 0), (3, 37, 19, 6, 1), (2, 128, 128, 16, 0), (1, 5, 7, 2, 1), (2, 64, 96, 3, 0)], ids=str)
+def test_stride2_dgrad_by_parity_classes(ops, report, case):
+    """Input gradient of the stride-2 3x3 downsample convolution (asymmetric (0,1,0,1) pad of Diffusers, symmetric pad 1 of the
+    LDM UNet) as four stride-1 convolutions + dp_interleave2x2 (with the fused skip-gradient add, also from a channel slice):
+    against fp64 autograd and against the zero-inserted single-launch form; odd widths take the scalar interleave path."""
+    N, Cin, Cout, Ho, pad = case
+    H = 2 * Ho
+    x = rnd(N, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    dy = rnd(N, Cout, Ho, Ho, seed=3)
+    spec = ops.ConvSpec(3, 2, pad, 0)
+    xr = x.double().cpu().requires_grad_(True)
+    xin = F.pad(xr, (0, 1, 0, 1)) if pad == 0 else xr
+    y = F.conv2d(xin, w.double().cpu(), None, stride=2, padding=pad)
+    assert y.shape[2] == Ho
+    y.backward(dy.double().cpu())
+    packs = [ops.pack_weight_s2(w, ph, pw, pad) for ph in (0, 1) for pw in (0, 1)]
+    dx = ops.conv_dgrad_s2(dy, packs, Cin, spec, (H, H))
+    wd, ldd = ops.pack_weight(w, 1)
+    dz = ops.conv_dgrad(dy, wd, ldd, Cin, spec, (H, H))
+    big = rnd(N, Cin + 5, H, H, seed=4)
+    dxa = ops.conv_dgrad_s2(dy, packs, Cin, spec, (H, H), add=big[:, 2:2 + Cin])
+    e, ez, ea = relerr(dx, xr.grad), relerr(dx, dz.double().cpu()), relerr(dxa, xr.grad + big[:, 2:2 + Cin].double().cpu())
+    report['dgrad_s2/%s' % (case,)] = dict(vs_fp64=e, vs_zero_inserted=ez, with_add=ea)
+    assert max(e, ez, ea) < 2e-5
