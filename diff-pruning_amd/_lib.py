@@ -92,6 +92,9 @@ SIGNATURES = {
     'dp_downsum2x2': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],
     'dp_upsample2x': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],
     'dp_interleave2x2': [_vp, _ll, _ll, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp],
+    'dp_deinterleave2x2': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _ll, _vp],
+    'dp_ups_weff': [_vp, _ll, _vp, _vp],
+    'dp_ups_wfold': [_vp, _ll, _vp, _i, _vp],
     'dp_wg_reduce': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     'dp_gather_add': [_vp, _vp, _i, _vp, _vp],
     'dp_sumsq_partials': [_vp, _ll, _vp, _i, _vp],

@@ -389,6 +389,113 @@ __global__ void interleave2x2_kernel(const float* __restrict__ q, long long q_cl
         }
     }
 }
+// q[2ph+pw][n][c][i][j] = y[n][c][2i+ph][2j+pw]: the inverse of interleave2x2 (the four parity classes of an output gradient).
+__global__ void deinterleave2x2_kernel(const float* __restrict__ y, long long y_img_stride, int N, int C, int Ho, int Wo,
+                                       float* __restrict__ q, long long q_class_stride, long long q_img_stride, int vec) {
+    const int W = 2 * Wo, H = 2 * Ho;
+    if (vec) {
+        const int W4 = W / 4;
+        const long long per = (long long)C * H * W4;
+        const long long total = (long long)N * per;
+        GS_LOOP(t, total) {
+            const long long n = t / per;
+            const long long r = t - n * per;
+            const int w4 = (int)(r % W4);
+            const long long ch = r / W4;
+            const int h = (int)(ch % H);
+            const long long c = ch / H;
+            const float4 v = *reinterpret_cast<const float4*>(y + n * y_img_stride + ch * W + 4 * w4);
+            float* qb = q + (long long)(2 * (h & 1)) * q_class_stride + n * q_img_stride + (c * Ho + (h >> 1)) * (long long)Wo + 2 * w4;
+            *reinterpret_cast<float2*>(qb) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2*>(qb + q_class_stride) = make_float2(v.y, v.w);
+        }
+    } else {
+        const long long per = (long long)C * H * W;
+        const long long total = (long long)N * per;
+        GS_LOOP(t, total) {
+            const long long n = t / per;
+            const long long r = t - n * per;
+            const int w = (int)(r % W);
+            const long long ch = r / W;
+            const int h = (int)(ch % H);
+            const long long c = ch / H;
+            q[(long long)(2 * (h & 1) + (w & 1)) * q_class_stride + n * q_img_stride + (c * Ho + (h >> 1)) * (long long)Wo + (w >> 1)] =
+                y[n * y_img_stride + r];
+        }
+    }
+}
+extern "C" int dp_deinterleave2x2(const float* y, long long y_img_stride, int N, int C, int Ho, int Wo, float* q,
+                                  long long q_class_stride, long long q_img_stride, void* stream) {
+    const int vec = (Wo % 2 == 0) && (q_class_stride % 2 == 0) && (q_img_stride % 2 == 0) && (y_img_stride % 4 == 0) &&
+                    ((uintptr_t)q % 8 == 0) && ((uintptr_t)y % 16 == 0);
+    const long long total = (long long)N * C * (2 * Ho) * (vec ? Wo / 2 : 2 * Wo);
+    if (total <= 0) return 0;
+    DP_LAUNCH(deinterleave2x2_kernel, dim3(dp_grid(total)), dim3(256), 0, (hipStream_t)stream, y, y_img_stride, N, C, Ho, Wo, q,
+                       q_class_stride, q_img_stride, vec);
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nearest-x2 upsampling followed by a 3x3 'same' convolution == four 2x2 convolutions on the LOW-resolution input, one per
+// parity class (ph, pw) of the output position: output row 2i+ph reads upsampled rows 2i+ph+ky-1, i.e. source rows
+//   ph = 0:  i-1 (ky = 0),  i (ky = 1, 2)        ph = 1:  i (ky = 0, 1),  i+1 (ky = 2)
+// so the class kernel has 2 taps per dimension whose weights are SUMS of the 3x3 taps that land on the same source pixel
+// (top / left padding 1 - ph / 1 - pw).  16 multiply-adds per low-resolution pixel and channel pair instead of 36.
+//   weff[2ph+pw][m][ty][tx] = sum_{ky in S(ph,ty)} sum_{kx in S(pw,tx)} w[m][ky][kx],  S(0,0) = {0}, S(0,1) = {1,2},
+//                                                                                    S(1,0) = {0,1}, S(1,1) = {2}
+// and the weight gradient folds back with the transposed map:  gw[m][ky][kx] (+)= sum_classes gweff[class][m][ty(ph,ky)][tx(pw,kx)].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dp_ups_t(int parity, int k) { return parity == 0 ? (k == 0 ? 0 : 1) : (k == 2 ? 1 : 0); }
+
+__global__ void ups_weff_kernel(const float* __restrict__ w, long long M, float* __restrict__ weff) {
+    GS_LOOP(m, M) {
+        float k[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) k[t] = w[m * 9 + t];
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int ph = cls >> 1, pw = cls & 1;
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) e[dp_ups_t(ph, ky) * 2 + dp_ups_t(pw, kx)] += k[ky * 3 + kx];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) weff[((long long)cls * M + m) * 4 + t] = e[t];
+        }
+    }
+}
+extern "C" int dp_ups_weff(const float* w, long long M, float* weff, void* stream) {
+    if (M <= 0) return 0;
+    DP_LAUNCH(ups_weff_kernel, dim3(dp_grid(M)), dim3(256), 0, (hipStream_t)stream, w, M, weff);
+    return DP_LAUNCH_CHECK();
+}
+
+__global__ void ups_wfold_kernel(const float* __restrict__ gweff, long long M, float* __restrict__ gw, int accumulate) {
+    GS_LOOP(m, M) {
+        float e[4][4];
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) e[cls][t] = gweff[((long long)cls * M + m) * 4 + t];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float s = 0.f;
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) s += e[cls][dp_ups_t(cls >> 1, ky) * 2 + dp_ups_t(cls & 1, kx)];
+                float* o = gw + m * 9 + ky * 3 + kx;
+                *o = accumulate ? *o + s : s;
+            }
+    }
+}
+extern "C" int dp_ups_wfold(const float* gweff, long long M, float* gw, int accumulate, void* stream) {
+    if (M <= 0) return 0;
+    DP_LAUNCH(ups_wfold_kernel, dim3(dp_grid(M)), dim3(256), 0, (hipStream_t)stream, gweff, M, gw, accumulate);
+    return DP_LAUNCH_CHECK();
+}
+
 extern "C" int dp_interleave2x2(const float* q, long long q_class_stride, long long q_img_stride, int N, int C, int Ho, int Wo,
                                 const float* add, long long add_img_stride, float* dx, long long dx_img_stride, void* stream) {
     const int vec = (Wo % 2 == 0) && (q_class_stride % 2 == 0) && (q_img_stride % 2 == 0) && (dx_img_stride % 4 == 0) &&

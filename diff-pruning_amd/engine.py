@@ -21,6 +21,8 @@ _SPEC3 = ops.ConvSpec(3, 1, 1, 0)
 _SPEC1 = ops.ConvSpec(1, 1, 0, 0)
 _SPEC_UP = ops.ConvSpec(3, 1, 1, 1)
 UPS_COPY = not os.environ.get('DP_NO_UPS_COPY')
+UPS_SUBPIXEL = not os.environ.get('DP_NO_UPS_SUBPIXEL')      # upsample convolutions as four 2x2 convolutions at low resolution
+_UPS_SPECS = ops.UPS_CLASS_SPECS
 S2_PARITY = not os.environ.get('DP_NO_S2_PARITY')
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
@@ -69,12 +71,26 @@ class _Packs:
         hit = self._c.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1], hit[2]
-        if isinstance(mode, tuple):               # ('s2', ph, pw, pad): one parity class of a stride-2 dgrad (ops.conv_dgrad_s2)
+        if isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
+            weff = self.get_weff(name, w)
+            buf, ld = ops.pack_weight(weff[mode[1]], mode[2])
+        elif isinstance(mode, tuple):             # ('s2', ph, pw, pad): one parity class of a stride-2 dgrad (ops.conv_dgrad_s2)
             buf, ld = ops.pack_weight_s2(w, mode[1], mode[2], mode[3])
         else:
             buf, ld = ops.pack_weight(w, mode)
         self._c[key] = (tag, buf, ld)
         return buf, ld
+
+    def get_weff(self, name, w):
+        """[4, Cout, Cin, 2, 2] class kernels of the upsample convolution `name` (ops.ups_weff), cached like the packs."""
+        key = (name, 'weff')
+        tag = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        weff = ops.ups_weff(w)
+        self._c[key] = (tag, weff, 0)
+        return weff
 
     def clear(self):
         self._c.clear()
@@ -332,6 +348,50 @@ class UNetEngine:
             ops.copy_strided(dx_add, dx, accumulate=True)
         return dx
 
+    # ---- Upsample2D: nearest x2 + conv3x3 (resnet.py:131-166) as four 2x2 convolutions on the low-resolution input --------
+    # One per parity class of the output position, with class kernels that are sums of the 3x3 taps reading the same source
+    # pixel (csrc/elementwise.hip, dp_ups_weff): the same function with 16 instead of 36 multiply-adds per low-resolution
+    # pixel and channel pair, in the forward pass, the input gradient and the weight gradient alike.
+    def _ups_conv_fwd(self, name, x):
+        w = self.P[name + '.weight']
+        N, _, H, W = x.shape
+        q = ops.empty_act((4, N, w.shape[0], H, W), x.device)
+        for c, spec in enumerate(_UPS_SPECS):
+            wp, ld = self.packs.get(name, w, ('up', c, 0))
+            ops.conv_forward(x, None, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), out=q[c])
+        return ops.interleave2x2(q)
+
+    def _ups_conv_bwd(self, name, dy, x):
+        """Accumulate the weight / bias gradients of the upsample convolution `name`; return the gradient w.r.t. its
+        low-resolution input x (what Upsample2D's autograd returns after the 2x2 sum of UpsampleNearest2DBackward)."""
+        w = self.P[name + '.weight']
+        dyq = ops.deinterleave2x2(dy)
+        rows = None
+        if (name + '.bias') in self.P and self._rows_src is not None and self._rows_src[0].data_ptr() == dy.data_ptr():
+            rows = self._rows_of(dy)
+
+        def param_grads(rows):
+            gweff = torch.empty((4,) + tuple(w.shape[:2]) + (2, 2), dtype=torch.float32, device=dy.device)
+            for c, spec in enumerate(_UPS_SPECS):
+                ops.conv_wgrad(dyq[c], x, None, gweff[c], spec, accumulate=False)
+            ops.ups_wfold(gweff, self.G[name + '.weight'], accumulate=True)
+            if (name + '.bias') in self.P:
+                if rows is None:
+                    rows = ops.rowsum_nc(dy)
+                self._colsum(rows, rows.shape[0], rows.shape[1], 1, 0, self.G[name + '.bias'])
+
+        side = self._side_stream(dyq, dy, x, rows)
+        if side is None:
+            param_grads(rows)
+        else:
+            with torch.cuda.stream(side):
+                param_grads(rows)
+        dx = None
+        for c, spec in enumerate(_UPS_SPECS):
+            wd, ldd = self.packs.get(name, w, ('up', c, 1))
+            dx = ops.conv_dgrad(dyq[c], wd, ldd, w.shape[1], spec, tuple(x.shape[2:]), out=dx, accumulate=c > 0)
+        return dx
+
     def _gn_param_grads(self, name, pws):
         N, C = pws.shape[0], pws.shape[1]
         self._colsum(pws, N, C, 2, 1, self.G[name + '.weight'])
@@ -538,8 +598,12 @@ class UNetEngine:
             if i != nb - 1:
                 # the x2-upsampled tensor is materialised (4x a low-resolution activation, HBM-bound) so that the convolution
                 # and its weight gradient are plain stride-1 launches on the LDS-DMA kernels (see ops.upsample2x)
-                xin = ops.upsample2x(x) if UPS_COPY else x
-                x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC3 if UPS_COPY else _SPEC_UP)
+                if UPS_SUBPIXEL:
+                    xin = x
+                    x = self._ups_conv_fwd(pre + '.upsamplers.0.conv', xin)
+                else:
+                    xin = ops.upsample2x(x) if UPS_COPY else x
+                    x = self._conv(pre + '.upsamplers.0.conv', xin, None, _SPEC3 if UPS_COPY else _SPEC_UP)
                 if ctx is not None:
                     ctx[pre + '.up'] = xin
         G, eps = cfg['norm_num_groups'], cfg['norm_eps']
@@ -577,12 +641,16 @@ class UNetEngine:
             pre = 'up_blocks.%d' % i
             if i != nb - 1:
                 xin = ctx.pop(pre + '.up')
-                if UPS_COPY:
+                if UPS_SUBPIXEL:
+                    dx = self._ups_conv_bwd(pre + '.upsamplers.0.conv', dx, xin)
+                    dxv = None
+                elif UPS_COPY:
                     dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC3, (xin.shape[2], xin.shape[3]))
                 else:
                     dxv = self._conv_bwd(pre + '.upsamplers.0.conv', dx, xin, None, _SPEC_UP,
                                          (2 * xin.shape[2], 2 * xin.shape[3]))
-                dx = ops.downsum2x2(dxv)
+                if dxv is not None:
+                    dx = ops.downsum2x2(dxv)
                 del dxv
             local = []
             for j in reversed(range(Lr + 1)):

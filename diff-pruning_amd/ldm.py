@@ -317,8 +317,12 @@ class LdmEngine(UNetEngine):
                 elif it[0] == 'st':
                     h = self.st_fwd(pre, h, ctx2d, it[1], ctx)
                 else:
-                    hin = ops.upsample2x(h) if engine_mod.UPS_COPY else h          # see UNetEngine.forward
-                    h = self._conv(pre + '.conv', hin, None, _SPEC3 if engine_mod.UPS_COPY else _SPEC_UP)
+                    if engine_mod.UPS_SUBPIXEL:                                    # see UNetEngine._ups_conv_fwd
+                        hin = h
+                        h = self._ups_conv_fwd(pre + '.conv', hin)
+                    else:
+                        hin = ops.upsample2x(h) if engine_mod.UPS_COPY else h
+                        h = self._conv(pre + '.conv', hin, None, _SPEC3 if engine_mod.UPS_COPY else _SPEC_UP)
                     if ctx is not None:
                         ctx[pre] = hin
         ho = h
@@ -348,11 +352,14 @@ class LdmEngine(UNetEngine):
                 pre = 'output_blocks.%d.%d' % (bi, li)
                 if it[0] == 'up':
                     hin = ctx.pop(pre)
-                    if engine_mod.UPS_COPY:
-                        dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC3, (hin.shape[2], hin.shape[3]))
+                    if engine_mod.UPS_SUBPIXEL:
+                        dx = self._ups_conv_bwd(pre + '.conv', dx, hin)
                     else:
-                        dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC_UP, (2 * hin.shape[2], 2 * hin.shape[3]))
-                    dx = ops.downsum2x2(dxv)
+                        if engine_mod.UPS_COPY:
+                            dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC3, (hin.shape[2], hin.shape[3]))
+                        else:
+                            dxv = self._conv_bwd(pre + '.conv', dx, hin, None, _SPEC_UP, (2 * hin.shape[2], 2 * hin.shape[3]))
+                        dx = ops.downsum2x2(dxv)
                 elif it[0] == 'st':
                     dx = self.st_bwd(pre, dx)
                 else:

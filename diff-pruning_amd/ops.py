@@ -224,13 +224,22 @@ class ConvSpec:
     """Forward geometry of one convolution (kernel k x k, stride, top/left padding, fused nearest x2 upsample).
     General form (forward only; the FID Inception network's 1x7 / 7x1 / 5x5 / valid stride-2 convolutions):
     ConvSpec.general(kh, kw, stride, pad_h, pad_w) -- symmetric zero padding, output floor((H + 2 pad - k) / stride) + 1."""
-    __slots__ = ('k', 'stride', 'pad', 'ups', 'kh', 'kw', 'pad_h', 'pad_w', 'sym')
+    __slots__ = ('k', 'stride', 'pad', 'ups', 'kh', 'kw', 'pad_h', 'pad_w', 'sym', 'keep')
 
     def __init__(self, k=3, stride=1, pad=1, ups=0):
         self.k, self.stride, self.pad, self.ups = k, stride, pad, ups
         self.kh = self.kw = k
         self.pad_h = self.pad_w = pad
         self.sym = False
+        self.keep = False
+
+    @classmethod
+    def same(cls, kh, kw, pad_t, pad_l):
+        """Stride-1 convolution whose output has the size of its input, zero padding pad_t / pad_l on top / left and whatever
+        is missing on the other side (the parity-class kernels of the upsample convolution: 2x2 taps, pads 1 or 0)."""
+        s = cls(kh, 1, pad_t, 0)
+        s.kh, s.kw, s.pad_h, s.pad_w, s.keep = kh, kw, pad_t, pad_l, True
+        return s
 
     @classmethod
     def general(cls, kh, kw, stride=1, pad_h=0, pad_w=0):
@@ -240,6 +249,8 @@ class ConvSpec:
 
     def out_hw(self, Hs, Ws):
         Hv, Wv = Hs << self.ups, Ws << self.ups
+        if self.keep:
+            return Hv, Wv
         if self.sym:
             return (Hv + 2 * self.pad_h - self.kh) // self.stride + 1, (Wv + 2 * self.pad_w - self.kw) // self.stride + 1
         if self.stride == 1:
@@ -309,9 +320,8 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.x_guard = 1 if _guarded(dy) else 0
     p.a_bytes, p.x1_bytes, p.x2_bytes = wd.numel() * 4, _extent_bytes(dy), 0
     # dX[h] = sum_ky' dY[(h + ky' - (k-1-pad)) / stride] Wflip[ky']
-    padp = spec.k - 1 - spec.pad
-    p.g = _geom(Hv, Wv, Ho, Wo, Ho, Wo, spec.k, 1, spec.stride, padp, padp, 0, Cout, sd, 0)
-    p.M, p.C, p.NPIX, p.ntaps, p.batches = Cin, Cout, N * Hv * Wv, spec.k * spec.k, 1
+    p.g = _geom(Hv, Wv, Ho, Wo, Ho, Wo, spec.kw, 1, spec.stride, spec.kh - 1 - spec.pad_h, spec.kw - 1 - spec.pad_w, 0, Cout, sd, 0)
+    p.M, p.C, p.NPIX, p.ntaps, p.batches = Cin, Cout, N * Hv * Wv, spec.kh * spec.kw, 1
     p.tile = pick_tile(Cin, N * Hv * Wv)
     _prefer_tile96(p)
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
@@ -372,10 +382,46 @@ def conv_dgrad_s2(dy, packs, Cin, spec, in_hw, add=None):
             _conv_ksplit(p, dy.device)
             L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
                          4.0 * (dy.numel() + wd.numel() + out.numel())), 'dp_conv_gemm(dgrad, stride-2 parity class)')
-    dx = empty_act((N, Cin, H, W), dy.device)
-    L.check(_lib().dp_interleave2x2(_p(q), q.stride(0), q.stride(1), N, Cin, Ho, Wo, _p(add),
-                                    _chk_act(add) if add is not None else 0, _p(dx), _chk_act(dx), _stream()), 'dp_interleave2x2')
-    return dx
+    return interleave2x2(q, add)
+
+
+def interleave2x2(q, add=None):
+    """y[n, c, 2i+ph, 2j+pw] = q[2ph+pw, n, c, i, j] (+ add)."""
+    _, N, Cc, Ho, Wo = q.shape
+    assert q[0, 0].is_contiguous()
+    y = empty_act((N, Cc, 2 * Ho, 2 * Wo), q.device)
+    L.check(_lib().dp_interleave2x2(_p(q), q.stride(0), q.stride(1), N, Cc, Ho, Wo, _p(add),
+                                    _chk_act(add) if add is not None else 0, _p(y), _chk_act(y), _stream()), 'dp_interleave2x2')
+    return y
+
+
+def deinterleave2x2(y):
+    """q[2ph+pw, n, c, i, j] = y[n, c, 2i+ph, 2j+pw]: the four parity classes as guarded activations."""
+    sy = _chk_act(y)
+    N, Cc, H, W = y.shape
+    assert H % 2 == 0 and W % 2 == 0
+    q = empty_act((4, N, Cc, H // 2, W // 2), y.device)
+    L.check(_lib().dp_deinterleave2x2(_p(y), sy, N, Cc, H // 2, W // 2, _p(q), q.stride(0), q.stride(1), _stream()),
+            'dp_deinterleave2x2')
+    return q
+
+
+UPS_CLASS_SPECS = tuple(ConvSpec.same(2, 2, 1 - ph, 1 - pw) for ph in (0, 1) for pw in (0, 1))
+
+
+def ups_weff(w):
+    """[4, Cout, Cin, 2, 2] class kernels of `upsample x2 -> conv3x3(w)` (see dp_ups_weff)."""
+    assert w.dim() == 4 and w.shape[2:] == (3, 3) and w.is_contiguous()
+    weff = torch.empty((4, w.shape[0], w.shape[1], 2, 2), dtype=_f32, device=w.device)
+    L.check(_lib().dp_ups_weff(_p(w), w.shape[0] * w.shape[1], _p(weff), _stream()), 'dp_ups_weff')
+    return weff
+
+
+def ups_wfold(gweff, gw, accumulate=True):
+    """gw[Cout, Cin, 3, 3] (+)= fold of the class weight gradients gweff[4, Cout, Cin, 2, 2]."""
+    assert gweff.is_contiguous() and gw.is_contiguous() and gweff.shape[1:3] == gw.shape[:2]
+    L.check(_lib().dp_ups_wfold(_p(gweff), gw.shape[0] * gw.shape[1], _p(gw), 1 if accumulate else 0, _stream()), 'dp_ups_wfold')
+    return gw
 
 
 _ws_cache = {}
@@ -409,18 +455,19 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
         s2 = _chk_act(x2)
         C2 = x2.shape[1]
     Cin = C1 + C2
-    taps = spec.k * spec.k
+    taps = spec.kh * spec.kw
     assert gw.is_contiguous() and gw.numel() == Cout * Cin * taps
     ncols = Cin * taps
     P = N * Ho * Wo
+    square = spec.kh == spec.kw and spec.pad_h == spec.pad_w and not spec.keep
     few_in = x2 is None and taps > 1 and Cin * taps <= 64
     few_out = (x2 is None and taps > 1 and Cout * taps <= 64 and spec.stride == 1 and not spec.ups
                and 2 * spec.pad == spec.k - 1)
-    if WGRAD_MERGE_TAPS and (few_in or few_out):
+    if WGRAD_MERGE_TAPS and square and (few_in or few_out):
         return _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in)
     # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension
     # (N*Ho*Wo, up to 262144) supplies the parallelism; partial sums are reduced in a fixed order (deterministic).
-    geom = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.k, spec.stride, 1, spec.pad, spec.pad, spec.ups,
+    geom = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.kw, spec.stride, 1, spec.pad_h, spec.pad_w, spec.ups,
                  C1 if x2 is not None else Cin, s1, s2)
     tile = 0 if Cout > 64 else 1
     bm, bn, _ = _TILES[tile]

@@ -215,6 +215,18 @@ int dp_upsample2x(const float* x, long long x_img_stride, int N, int C, int H, i
 int dp_interleave2x2(const float* q, long long q_class_stride, long long q_img_stride, int N, int C, int Ho, int Wo,
                      const float* add, long long add_img_stride, float* dx, long long dx_img_stride, void* stream);
 
+/* q[(2ph+pw)*q_class_stride + n*q_img_stride + (c*Ho+i)*Wo + j] = y[n][c][2i+ph][2j+pw]: inverse of dp_interleave2x2. */
+int dp_deinterleave2x2(const float* y, long long y_img_stride, int N, int C, int Ho, int Wo, float* q,
+                       long long q_class_stride, long long q_img_stride, void* stream);
+
+/* Upsample2D = F.interpolate(nearest, x2) + Conv2d(3x3, pad 1) (diffusers/models/resnet.py:131-166; openaimodel.py Upsample)
+ * as four 2x2 convolutions on the low-resolution input, one per parity class (ph, pw) of the output position, top / left
+ * padding (1 - ph, 1 - pw); mathematically the same function with 16 instead of 36 multiply-adds per low-resolution pixel.
+ * dp_ups_weff: weff[4][M][2][2] from w[M][3][3] (M = Cout*Cin), sums of the taps that read the same source pixel;
+ * dp_ups_wfold: gw[M][3][3] (+)= the transposed map applied to the class weight gradients gweff[4][M][2][2]. */
+int dp_ups_weff(const float* w, long long M, float* weff, void* stream);
+int dp_ups_wfold(const float* gweff, long long M, float* gw, int accumulate, void* stream);
+
 /* Taylor-importance reductions  (ddpm_exp/torch_pruning/importance.py:375-434).
  * Weight viewed as [R][C][T]; dim = 0: out[r] = sum_{c,t} f(w*g); dim = 1: out[c] = sum_{r,t} f(w*g);
  * mode 0: f = (w g)^2 (vendored), mode 1: f = |w g| (sum_abs), mode 2: signed sum then |.| (abs_sum),

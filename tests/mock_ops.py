@@ -37,7 +37,13 @@ def _cat(x, x2):
     return x if x2 is None else torch.cat([x, x2], 1)
 
 
+def _keep_pad(spec):
+    return (spec.pad_w, spec.kw - 1 - spec.pad_w, spec.pad_h, spec.kh - 1 - spec.pad_h)
+
+
 def _prep(x, spec):
+    if getattr(spec, 'keep', False):
+        return F.pad(x, _keep_pad(spec))
     if spec.ups:
         x = F.interpolate(x, scale_factor=2.0, mode='nearest')
     if spec.stride == 2 and spec.pad == 0:
@@ -48,7 +54,7 @@ def _prep(x, spec):
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
                  accumulate=False):
     w = wp if wp.dim() == 4 else wp.view(wp.shape[0], wp.shape[1], 1, 1)
-    y = alpha * F.conv2d(_prep(_cat(x, x2), spec), w, None, stride=spec.stride, padding=spec.pad)
+    y = alpha * F.conv2d(_prep(_cat(x, x2), spec), w, None, stride=spec.stride, padding=0 if getattr(spec, 'keep', False) else spec.pad)
     if bias is not None:
         y = y + bias[None, :, None, None]
     if tadd is not None:
@@ -66,6 +72,14 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     w = wd if wd.dim() == 4 else wd.view(wd.shape[0], wd.shape[1], 1, 1)
     N = dy.shape[0]
     Hv, Wv = in_hw
+    if getattr(spec, 'keep', False):
+        l, r, t, b = _keep_pad(spec)
+        dxp = torch.nn.grad.conv2d_input((N, Cin, Hv + t + b, Wv + l + r), w, dy.contiguous(), stride=1, padding=0)
+        dx = alpha * dxp[:, :, t:t + Hv, l:l + Wv]
+        if out is not None:
+            out.copy_(out + dx if accumulate else dx)
+            return out
+        return dx.contiguous()
     asym = spec.stride == 2 and spec.pad == 0
     shape = (N, Cin, Hv + (1 if asym else 0), Wv + (1 if asym else 0))
     dx = torch.nn.grad.conv2d_input(shape, w, dy.contiguous(), stride=spec.stride, padding=spec.pad)
@@ -89,9 +103,8 @@ def conv_dgrad_s2(dy, packs, Cin, spec, in_hw, add=None):
 
 def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=None):
     xin = _prep(_cat(x, x2), spec)
-    k = spec.k
-    g = torch.nn.grad.conv2d_weight(xin, (dy.shape[1], xin.shape[1], k, k), dy.contiguous(), stride=spec.stride,
-                                    padding=spec.pad)
+    g = torch.nn.grad.conv2d_weight(xin, (dy.shape[1], xin.shape[1], spec.kh, spec.kw), dy.contiguous(), stride=spec.stride,
+                                    padding=0 if getattr(spec, 'keep', False) else spec.pad)
     g = alpha * g.reshape(gw.shape)
     gw.copy_(gw + g if accumulate else g)
     return gw
@@ -301,6 +314,44 @@ def downsum2x2(dy, out=None):
 
 def upsample2x(x):
     return F.interpolate(x, scale_factor=2.0, mode='nearest')
+
+
+def interleave2x2(q, add=None):
+    _, N, C, Ho, Wo = q.shape
+    y = q.new_zeros(N, C, 2 * Ho, 2 * Wo)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            y[:, :, ph::2, pw::2] = q[2 * ph + pw]
+    return y if add is None else y + add
+
+
+def deinterleave2x2(y):
+    return torch.stack([y[:, :, ph::2, pw::2] for ph in (0, 1) for pw in (0, 1)]).contiguous()
+
+
+def _ups_t(parity, k):
+    return (0 if k == 0 else 1) if parity == 0 else (1 if k == 2 else 0)
+
+
+def ups_weff(w):
+    weff = w.new_zeros(4, w.shape[0], w.shape[1], 2, 2)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            for ky in range(3):
+                for kx in range(3):
+                    weff[2 * ph + pw, :, :, _ups_t(ph, ky), _ups_t(pw, kx)] += w[:, :, ky, kx]
+    return weff
+
+
+def ups_wfold(gweff, gw, accumulate=True):
+    g = torch.zeros_like(gw)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            for ky in range(3):
+                for kx in range(3):
+                    g[:, :, ky, kx] += gweff[2 * ph + pw, :, :, _ups_t(ph, ky), _ups_t(pw, kx)]
+    gw.copy_(gw + g if accumulate else g)
+    return gw
 
 
 def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):

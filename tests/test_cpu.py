@@ -1306,3 +1306,41 @@ def test_ssim_oracle_properties():
     assert torch.allclose(M.ssim(x, x), torch.ones(3, dtype=torch.float64))
     assert torch.allclose(M.ssim(x, y), M.ssim(y, x))
     assert (M.ssim(x, y) > M.ssim(x, z)).all() and (M.ssim(x, z) > 0).all()
+
+
+def test_upsample_conv_as_four_low_resolution_convs(mocked, monkeypatch):
+    """Upsample2D (nearest x2 + conv3x3, resnet.py:131-166) computed by the engine as four 2x2 convolutions on the low-
+    resolution input (UNetEngine._ups_conv_fwd / _ups_conv_bwd): the composition -- class kernels, paddings, interleave, the
+    accumulated input gradient and the folded weight gradient -- against autograd of the plain formulation, in fp64."""
+    import torch.nn.functional as F
+    engine = pkg('engine')
+    monkeypatch.setattr(mocked, 'empty_act', lambda shape, device: torch.empty(tuple(shape), dtype=torch.float64))
+    torch.manual_seed(0)
+    N, Ci, Co, H, W = 2, 5, 7, 4, 6
+    x = torch.randn(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(Co, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode='nearest'), w, b, padding=1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    eng = engine.UNetEngine({})
+    eng.overlap_wgrad = False
+    gw0, gb0 = torch.randn_like(w), torch.randn_like(b)
+    eng.P = {'u.weight': w.detach(), 'u.bias': b.detach()}
+    eng.G = {'u.weight': gw0.clone(), 'u.bias': gb0.clone()}
+    eng._begin_backward()
+    got = eng._ups_conv_fwd('u', x.detach())
+    dx = eng._ups_conv_bwd('u', dy, x.detach())
+    eng._end_backward()
+    assert got.shape == y.shape and float((got - y.detach()).abs().max()) < 1e-12
+    assert float((dx - x.grad).abs().max()) < 1e-12
+    # accumulates, like every parameter gradient (the class gradients pass through the engine's fp32 buffer: 1e-7 relative)
+    assert float((eng.G['u.weight'] - (gw0 + w.grad)).abs().max()) < 3e-6 * float(w.grad.abs().max())
+    assert float((eng.G['u.bias'] - (gb0 + b.grad)).abs().max()) < 1e-11
+    # the class kernels are the sums of the taps that read the same source pixel; the fold is the transposed map
+    weff = mocked.ups_weff(w.detach())
+    assert torch.allclose(weff.sum((0, 3, 4)) / 4, w.detach().sum((2, 3)), atol=1e-12)
+    g = torch.randn(4, Co, Ci, 2, 2, dtype=torch.float64)
+    lhs = (weff * g).sum()
+    rhs = (w.detach() * mocked.ups_wfold(g, torch.zeros_like(w.detach()), accumulate=False)).sum()
+    assert abs(float(lhs - rhs)) < 1e-9

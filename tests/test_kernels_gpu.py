@@ -762,3 +762,53 @@ def test_stride2_dgrad_by_parity_classes(ops, report, case):
     e, ez, ea = relerr(dx, xr.grad), relerr(dx, dz.double().cpu()), relerr(dxa, xr.grad + big[:, 2:2 + Cin].double().cpu())
     report['dgrad_s2/%s' % (case,)] = dict(vs_fp64=e, vs_zero_inserted=ez, with_add=ea)
     assert max(e, ez, ea) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12, 4, 4), (3, 37, 50, 5, 3), (2, 128, 96, 8, 8), (1, 3, 5, 1, 1)], ids=str)
+def test_upsample_conv_subpixel_primitives_and_composite(ops, report, shape):
+    """Upsample2D as four 2x2 convolutions at low resolution: dp_ups_weff / dp_ups_wfold against their definition,
+    dp_deinterleave2x2 as the inverse of dp_interleave2x2, the class convolutions (ConvSpec.same: 2x2 taps, top / left padding
+    1 or 0) in forward, input-gradient and weight-gradient form, and the composite against fp64 autograd of
+    interpolate(nearest x2) + conv2d(3x3, pad 1) and against the single-launch gather form it replaces."""
+    N, Ci, Co, H, W = shape
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=3)
+    dy = rnd(N, Co, 2 * H, 2 * W, seed=4)
+    xr, wr = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode='nearest'), wr, b.double().cpu(), padding=1)
+    yr.backward(dy.double().cpu())
+
+    def t(parity, k):
+        return (0 if k == 0 else 1) if parity == 0 else (1 if k == 2 else 0)
+
+    weff = ops.ups_weff(w)
+    want = torch.zeros(4, Co, Ci, 2, 2, dtype=torch.float64)
+    for ph in (0, 1):
+        for pw in (0, 1):
+            for ky in range(3):
+                for kx in range(3):
+                    want[2 * ph + pw, :, :, t(ph, ky), t(pw, kx)] += w.double().cpu()[:, :, ky, kx]
+    e_weff = relerr(weff, want)
+    q = ops.deinterleave2x2(dy)
+    assert all(torch.equal(q[2 * ph + pw].cpu(), dy.cpu()[:, :, ph::2, pw::2]) for ph in (0, 1) for pw in (0, 1))
+    assert torch.equal(ops.interleave2x2(q).cpu(), dy.cpu())
+    # composite
+    qy = ops.empty_act((4, N, Co, H, W), x.device)
+    dx = None
+    gweff = torch.empty(4, Co, Ci, 2, 2, device=x.device)
+    for c, spec in enumerate(ops.UPS_CLASS_SPECS):
+        wp, ld = ops.pack_weight(weff[c], 0)
+        ops.conv_forward(x, None, wp, ld, Co, spec, bias=b, out=qy[c])
+        wd, ldd = ops.pack_weight(weff[c], 1)
+        dx = ops.conv_dgrad(q[c], wd, ldd, Ci, spec, (H, W), out=dx, accumulate=c > 0)
+        ops.conv_wgrad(q[c], x, None, gweff[c], spec, accumulate=False)
+    y = ops.interleave2x2(qy)
+    gw0 = rnd(Co, Ci, 3, 3, seed=5)
+    gw = ops.ups_wfold(gweff, gw0.clone(), accumulate=True)
+    wp9, ld9 = ops.pack_weight(w, 0)
+    y_gather = ops.conv_forward(x, None, wp9, ld9, Co, ops.ConvSpec(3, 1, 1, 1), bias=b)
+    e = dict(weff=e_weff, fwd=relerr(y, yr.detach()), fwd_vs_gather_form=relerr(y, y_gather.double().cpu()),
+             dgrad=relerr(dx, xr.grad), wgrad=relerr(gw, gw0.double().cpu() + wr.grad))
+    report['ups_subpixel/%s' % (shape,)] = e
+    assert max(e.values()) < 2e-5, e
