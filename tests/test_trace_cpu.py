@@ -208,3 +208,35 @@ def test_trace_leaves_the_module_as_it_found_it():
     assert not inputs[0].requires_grad
     assert all(torch.equal(v, sd[k]) for k, v in model.state_dict().items())       # eval() during the trace: BN statistics untouched
     assert not model.conv1._forward_hooks
+
+
+def test_trace_entry_points_dict_inputs_forward_fn_and_output_transform():
+    """The call forms of build_dependency (dependency.py:295-312, 660-682): dict example inputs, a custom forward_fn, an
+    output_transform that selects what to trace from, dataclass-like outputs -- all give the graph of the plain call."""
+    pruning, trace = pkg('pruning'), pkg('trace')
+    model, inputs, ignored = toy_nets.build('time_cond_unet')
+    want = [[(d.target.name, d.kind, len(i)) for d, i in g] for g in pruning.DependencyGraph(model, inputs).get_all_groups(ignored)]
+    as_dict = pruning.DependencyGraph().build_dependency(model, example_inputs={'x': inputs[0], 't': inputs[1]})
+    assert [[(d.target.name, d.kind, len(i)) for d, i in g] for g in as_dict.get_all_groups(ignored)] == want
+    via_fn = pruning.DependencyGraph().build_dependency(model, example_inputs=inputs, forward_fn=lambda m, ex: m(ex[0], t=ex[1]))
+    assert [[(d.target.name, d.kind, len(i)) for d, i in g] for g in via_fn.get_all_groups(ignored)] == want
+
+    class Out:
+        def __init__(self, a, b):
+            self.sample, self.aux = a, b
+
+    wrapped = pruning.DependencyGraph().build_dependency(
+        model, example_inputs=inputs, forward_fn=lambda m, ex: Out(*m(*ex)))
+    assert [[(d.target.name, d.kind, len(i)) for d, i in g] for g in wrapped.get_all_groups(ignored)] == want
+    # tracing from the first output only: out_b is never reached, so it is not a layer of the graph and `merge` couples with out_a alone
+    first = pruning.DependencyGraph().build_dependency(model, example_inputs=inputs, output_transform=lambda o: o[0])
+    assert 'out_b' not in first.graph.layers and 'out_a' in first.graph.layers
+    g = first.get_pruning_group(model.merge, None, [1, 2])
+    assert [(d.target.name, d.kind) for d, _ in g] == [('merge', 'out'), ('out_a', 'in')]
+    # a module without parameters that require grad anywhere still traces (requires_grad is switched on for the trace only)
+    frozen, inputs2, _ = toy_nets.build('plain_cnn')
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    assert len(list(pruning.DependencyGraph(frozen, inputs2).get_all_groups([frozen.fc2]))) == 3
+    assert not any(p.requires_grad for p in frozen.parameters())
+    assert trace.TracedGraph(frozen, inputs2).layers.keys() == {'conv1', 'bn1', 'conv2', 'bn2', 'fc1', 'fc2'}
