@@ -123,7 +123,7 @@ class TracedGraph(_GraphBase):
             self.out.append(self._walk(o.grad_fn, created))
         if not self.out:
             raise RuntimeError('no model output carries a grad_fn: nothing to trace (are all parameters frozen?)')
-        del self._fn2module                                     # drop the autograd graph
+        del self._fn2module, self._fn2node, self._slice_nodes, outs      # drop the autograd graph (and the activations it saved)
 
     # ---- forward pass with hooks (dependency.py:636-676) ---------------------------------------------
     def _run(self, model, example_inputs, forward_fn, output_transform):
