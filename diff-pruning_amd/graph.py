@@ -376,8 +376,20 @@ def coupled_members(graph, chan, root_name, idxs, aux=None):
             return in_deps(inp, 0, inp.inputs[0], jj)
         return [(inp, _fns(inp)[1], jj)]
 
-    entries = [(root, root_fn, list(idxs))]
-    present = {(root.uid, root_fn): {tuple(idxs)}}
+    idxs = list(idxs)
+    entries = [(root, root_fn, idxs)]
+    # Element-wise edges hand the SAME list object on, so most of the operations of a big group (hundreds of dependencies x
+    # hundreds of indices) are repeats: the hashable form of a list is computed once per object (the memo keeps the object alive,
+    # so its id cannot be recycled), and a list that was already merged into a member is not merged again.
+    frozen = {}
+
+    def key_of(jj):
+        hit = frozen.get(id(jj))
+        if hit is None:
+            hit = frozen[id(jj)] = (jj, tuple(jj))
+        return hit[1]
+
+    present = {(root.uid, root_fn): {key_of(idxs)}}
     visited = set()
     stack = [entries[0]]
     while stack:
@@ -395,7 +407,7 @@ def coupled_members(graph, chan, root_name, idxs, aux=None):
             if not jj:
                 continue
             key = (target.uid, tfn)
-            tj = tuple(jj)
+            tj = key_of(jj)
             have = present.setdefault(key, set())
             if target.uid in visited and tj in have:
                 continue
@@ -405,17 +417,20 @@ def coupled_members(graph, chan, root_name, idxs, aux=None):
             stack.append(e)
     merged, order = {}, []
     for node, fn, ii in entries:
+        if node.name is None:
+            continue                                   # pseudo nodes carry no member
         key = (node.uid, fn)
         if key not in merged:
-            merged[key] = (node, fn, set())
+            merged[key] = (node, fn, set(), set())
             order.append(key)
-        merged[key][2].update(ii)
+        if id(ii) not in merged[key][3]:
+            merged[key][3].add(id(ii))
+            merged[key][2].update(ii)
     out = []
     for key in order:
-        node, fn, ii = merged[key]
-        if node.name is not None:
-            kind = fn if node.kind in ('conv', 'linear') else ('out' if node.kind == 'dw' else node.kind)
-            out.append(Member(node.name, kind, sorted(ii)))
+        node, fn, ii, _ = merged[key]
+        kind = fn if node.kind in ('conv', 'linear') else ('out' if node.kind == 'dw' else node.kind)
+        out.append(Member(node.name, kind, sorted(ii)))
     if aux is not None:
         aux.extend((n, len(ii)) for n, ii in sliced.values() if not isinstance(n.part[1], int))
     return out
