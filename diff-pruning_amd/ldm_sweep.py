@@ -6,9 +6,10 @@ mean_B mean_CHW (eps - eps_hat)^2 at timestep t (ddpm.py:881-889,1024-1056); Dif
 loss_t / max_s loss_s < thr (0.1) -- BEFORE the backward of the breaking step, unlike the DDPM script;
 otherwise backward, gradients accumulating.  ~93 % of a step is the no-grad CFG sampling.
 
-`LatentDiffusion` / `DDIMSampler` are not importable in the build container (pytorch_lightning, omegaconf, taming
-absent), so this file follows their source lines and is checked against oracle/ldm_ref.py: parity unpinned for the
-driver, pinned for the UNet it drives.  Randomness (class ids, x_T, the loss noise) comes from caller-supplied
+The sampler, the noise schedule, q_sample / get_loss_at_t / p_losses and the class embedder are pinned against the
+reference's own `DDIMSampler` and `LatentDiffusion` methods (tests/golden/ldm_sampler.npz, ldm_loss_at_t.npz); the for-loop
+of the prune_ldm.py script around them (module-level code, not importable) follows its source lines and is checked
+against oracle/ldm_ref.py: parity unpinned for that loop only.  Randomness (class ids, x_T, the loss noise) comes from caller-supplied
 generators so that the CPU oracle can replay the same draws (the reference uses the device RNG).
 """
 import random

@@ -4,8 +4,12 @@ Parity: the UNet forward/backward is PINNED against the reference's own `UNetMod
 omegaconf stub; fixtures tests/golden/ldm_unet.npz from tests/golden/make_golden_ldm.py).
 The noise schedule and the CFG DDIM sampler are PINNED against the reference's own `DDIMSampler` + `make_beta_schedule`
 (both import cleanly) driven over the reference UNetModel: tests/golden/ldm_sampler.npz (make_golden_ldm.py sampler).
-`LatentDiffusion` itself is NOT importable here (pytorch_lightning absent), so the ~10 lines of get_loss_at_t / p_losses /
-q_sample and the driver loop of prune_ldm.py are restated from the source lines and remain **parity unpinned**.
+get_loss_at_t / p_losses / q_sample / get_learned_conditioning and ClassEmbedder are PINNED against the reference's own
+`LatentDiffusion` methods (tests/golden/ldm_loss_at_t.npz, make_golden_ldm.py loss: `ddpm.py` imports with empty stand-in
+modules for the absent pytorch_lightning / torchvision / taming / clip / kornia, none of whose code is on this path; the
+object's DDPM.__init__ really runs over the reference DiffusionWrapper + UNetModel).  What remains **parity unpinned** is
+the 25-line for-loop of the prune_ldm.py SCRIPT itself (max-loss bookkeeping, threshold test before backward), which is
+module-level script code, not an importable function: restated from the source lines.
 
 Reference lines followed (relative to /root/reference/ldm_exp):
   ldm/modules/diffusionmodules/openaimodel.py:710-742      UNetModel.forward
@@ -237,7 +241,7 @@ def ldm_param_shapes(cfg):
 
 
 # ------------------------------------------------------------------------------------------------------
-# LatentDiffusion pieces (schedule + sampler pinned by ldm_sampler.npz; q_sample / loss-at-t restated from source, unpinned)
+# LatentDiffusion pieces (schedule + sampler pinned by ldm_sampler.npz; q_sample / loss-at-t pinned by ldm_loss_at_t.npz)
 # ------------------------------------------------------------------------------------------------------
 def ldm_alphas_cumprod(n_timestep=1000, linear_start=0.0015, linear_end=0.0195):
     """util.py:21-25 ('linear') + ddpm.py register_schedule: fp64 tables, cast to fp32."""

@@ -227,5 +227,80 @@ def ldm_sampler():
     print('ldm sampler ok:', tuple(samples.shape), 'steps', list(sampler.ddim_timesteps)[:4], '...', float(samples.abs().mean()))
 
 
+def ldm_loss():
+    """Pins get_loss_at_t / p_losses / q_sample / get_learned_conditioning of the LDM importance pass
+    (ldm_exp/prune_ldm.py:122-123 -> ldm/models/diffusion/ddpm.py:881-889, 1022-1056, 274-277, 553-565) and ClassEmbedder
+    (ldm/modules/encoders/modules.py:21-33) by running the reference's OWN methods.  `ddpm.py` imports pytorch_lightning,
+    torchvision.utils, taming, clip and kornia at module level (all absent here); empty stand-in modules satisfy those import
+    statements -- none of their code is on this path (LightningModule only contributes `nn.Module` + a `.device` property).
+    The object is a LatentDiffusion whose base-class __init__ (DDPM.__init__: the reference's DiffusionWrapper around the
+    reference's UNetModel, register_schedule with the cin256-v2 linear_start / linear_end, logvar, loss weights) really runs;
+    LatentDiffusion.__init__ itself (first-stage autoencoder, checkpoint plumbing) is skipped and the five attributes
+    get_loss_at_t reads are set as configs/latent-diffusion/cin256-v2.yaml sets them."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules.setdefault(name, m)
+
+    class LightningModule(torch.nn.Module):
+        @property
+        def device(self):
+            return torch.device('cpu')
+
+    mod('pytorch_lightning', LightningModule=LightningModule)
+    mod('pytorch_lightning.utilities')
+    mod('pytorch_lightning.utilities.distributed', rank_zero_only=lambda f: f)
+    mod('torchvision'); mod('torchvision.utils', make_grid=None)
+    for n in ('taming', 'taming.modules', 'taming.modules.vqvae'):
+        mod(n)
+    mod('taming.modules.vqvae.quantize', VectorQuantizer2=object)
+    mod('clip'); mod('kornia')
+    from ldm.models.diffusion.ddpm import DDPM, LatentDiffusion
+    from ldm.modules.encoders.modules import ClassEmbedder
+
+    cfg = gc.LDM_TINY_CFG
+    ld = LatentDiffusion.__new__(LatentDiffusion)
+    ld.num_timesteps_cond = 1              # LatentDiffusion.__init__ default, read by its register_schedule override (ddpm.py:498)
+    DDPM.__init__(ld, unet_config={'target': 'ldm.modules.diffusionmodules.openaimodel.UNetModel', 'params': dict(cfg)},
+                  conditioning_key='crossattn', linear_start=0.0015, linear_end=0.0195, timesteps=1000, use_ema=False,
+                  monitor=None, image_size=cfg['image_size'], channels=cfg['in_channels'])
+    ld.cond_stage_trainable, ld.shorten_cond_schedule, ld.cond_stage_forward = True, False, None
+    ld.cond_stage_key = 'class_label'
+    ld.cond_stage_model = ClassEmbedder(cfg['context_dim'], n_classes=1001, key='class_label')
+    ld.eval()
+    gc.det_init_(ld.model.diffusion_model, 9)
+    with torch.no_grad():
+        ld.cond_stage_model.embedding.weight.copy_(torch.from_numpy(gc.det_param('embedding.weight', (1001, cfg['context_dim']), 61)))
+    assert float(ld.logvar.abs().max()) == 0.0 and ld.l_simple_weight == 1.0 and ld.original_elbo_weight == 0.0
+    B, H = 3, cfg['image_size']
+    x = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 62))
+    xc = torch.tensor([3, 500, 1000])
+    out = dict(class_ids=xc.numpy(), context=ld.get_learned_conditioning({'class_label': xc}).detach().numpy(),
+               sqrt_acp=ld.sqrt_alphas_cumprod.numpy().astype(np.float64),
+               sqrt_1macp=ld.sqrt_one_minus_alphas_cumprod.numpy().astype(np.float64))
+    ts = [0, 1, 250, 999]
+    losses, noisy = [], []
+    for k, t in enumerate(ts):
+        noise = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 70 + k))
+        tt = torch.full((B,), t, dtype=torch.long)
+        ld.zero_grad()
+        loss = ld.get_loss_at_t(x, {'class_label': xc}, tt, noise=noise)
+        losses.append(float(loss[0]))
+        noisy.append(ld.q_sample(x, tt, noise).numpy())
+        if t == 250:
+            loss[0].backward()
+            gs = {n: p.grad for n, p in ld.model.diffusion_model.named_parameters()}
+            out['grad_abs_sum_names'] = np.array(sorted(gs))
+            out['grad_abs_sum'] = np.array([float(gs[n].abs().sum()) for n in sorted(gs)], dtype=np.float64)
+            out['grad_embedding_rows'] = ld.cond_stage_model.embedding.weight.grad[xc].numpy()
+    out.update(ts=np.array(ts), losses=np.array(losses, dtype=np.float64), x_noisy=np.stack(noisy))
+    np.savez(os.path.join(HERE, 'ldm_loss_at_t.npz'), **out)
+    print('ldm loss ok: t', ts, 'losses', losses)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'loss':
+    ldm_loss()
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'sampler':
     ldm_sampler()

@@ -1344,3 +1344,64 @@ def test_upsample_conv_as_four_low_resolution_convs(mocked, monkeypatch):
     lhs = (weff * g).sum()
     rhs = (w.detach() * mocked.ups_wfold(g, torch.zeros_like(w.detach()), accumulate=False)).sum()
     assert abs(float(lhs - rhs)) < 1e-9
+
+
+def test_ldm_loss_at_t_matches_reference_latent_diffusion(mocked, monkeypatch):
+    """get_loss_at_t / p_losses / q_sample / get_learned_conditioning / ClassEmbedder against the reference's OWN methods
+    (tests/golden/ldm_loss_at_t.npz, written by make_golden_ldm.py `loss` from ldm/models/diffusion/ddpm.py:881-889,1022-1056,
+    274-277 and ldm/modules/encoders/modules.py:21-33 on the reference UNetModel): the oracle restatement, the product's schedule
+    tables and class embedder, and the product's loss step on mocked kernels (loss and the gradients it back-propagates)."""
+    from oracle import ldm_ref as R
+    ldm, ldm_sweep = pkg('ldm'), pkg('ldm_sweep')
+    g = load_npz('ldm_loss_at_t.npz')
+    cfg = gc.LDM_TINY_CFG
+    B, H = 3, cfg['image_size']
+    acp = R.ldm_alphas_cumprod()
+    assert np.allclose(np.sqrt(np.asarray(acp, dtype=np.float64)), g['sqrt_acp'], rtol=1e-6)
+    sched = ldm_sweep.LdmSchedule()
+    assert np.allclose(sched.sqrt_alphas_cumprod.numpy(), g['sqrt_acp'], rtol=1e-6)
+    assert np.allclose(sched.sqrt_one_minus_alphas_cumprod.numpy(), g['sqrt_1macp'], rtol=1e-6)
+    emb_w = torch.from_numpy(gc.det_param('embedding.weight', (1001, cfg['context_dim']), 61))
+    xc = torch.from_numpy(g['class_ids'])
+    embedder = ldm_sweep.ClassEmbedder(cfg['context_dim'], 1001)
+    with torch.no_grad():
+        embedder.embedding.weight.copy_(emb_w)
+    context = embedder(xc)
+    assert torch.equal(context, torch.from_numpy(g['context']))
+    x = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 62))
+    P = {n: torch.from_numpy(gc.det_param(n, s, 9)).requires_grad_(True) for n, s in R.ldm_param_shapes(cfg).items()}
+    # product step on mocked kernels
+    for m in (ldm, ldm_sweep):
+        monkeypatch.setattr(m, 'ops', mocked)
+    monkeypatch.setattr(mocked, 'q_sample', lambda x0, n, sa, sb, t: sa[t][:, None, None, None] * x0 + sb[t][:, None, None, None] * n,
+                        raising=False)
+
+    def cpu_engine(self):
+        if self._engine is None:
+            self._engine = ldm.LdmEngine(self.config)
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        return self._engine
+    monkeypatch.setattr(ldm.UNetModel, 'engine', cpu_engine)
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    pkg('sweep').flatten_grads(model)
+    step = ldm_sweep.LdmSweepStep(model, sched)
+    for k, t in enumerate(g['ts']):
+        noise = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 70 + k))
+        tt = torch.full((B,), int(t), dtype=torch.long)
+        assert float((R.q_sample(acp, x, tt, noise) - torch.from_numpy(g['x_noisy'][k])).abs().max()) < 1e-6
+        loss = R.ldm_loss_at_t(P, cfg, acp, x, tt, context, noise)
+        assert abs(float(loss) - g['losses'][k]) < 2e-6 * abs(g['losses'][k]), (t, float(loss), g['losses'][k])
+        got = step.loss(x, tt, context, noise)
+        assert abs(float(got) - g['losses'][k]) < 5e-6 * abs(g['losses'][k]), (t, float(got))
+        if int(t) == 250:
+            loss.backward()
+            step.backward()
+            names = [str(n) for n in g['grad_abs_sum_names']]
+            for n, want in zip(names, g['grad_abs_sum']):
+                assert abs(float(P[n].grad.abs().sum()) - want) < 2e-4 * max(want, 1e-6), n
+            got_g = dict(model.named_parameters())
+            worst = max(relerr(got_g[n].grad, P[n].grad) for n in names if float(P[n].grad.abs().max()) > 1e-7)
+            assert worst < 1e-4
+        else:
+            step.discard()
