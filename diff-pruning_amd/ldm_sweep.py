@@ -8,8 +8,8 @@ otherwise backward, gradients accumulating.  ~93 % of a step is the no-grad CFG 
 
 The sampler, the noise schedule, q_sample / get_loss_at_t / p_losses and the class embedder are pinned against the
 reference's own `DDIMSampler` and `LatentDiffusion` methods (tests/golden/ldm_sampler.npz, ldm_loss_at_t.npz); the for-loop
-of the prune_ldm.py script around them (module-level code, not importable) follows its source lines and is checked
-against oracle/ldm_ref.py: parity unpinned for that loop only.  Randomness (class ids, x_T, the loss noise) comes from caller-supplied
+of the prune_ldm.py script around them (module-level code, lines 103-131) is pinned by tests/golden/ldm_driver.json, recorded
+by executing those source lines over the reference objects (losses, accumulated gradients, the break before backward).  Randomness (class ids, x_T, the loss noise) comes from caller-supplied
 generators so that the CPU oracle can replay the same draws (the reference uses the device RNG).
 """
 import random

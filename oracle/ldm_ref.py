@@ -7,9 +7,12 @@ The noise schedule and the CFG DDIM sampler are PINNED against the reference's o
 get_loss_at_t / p_losses / q_sample / get_learned_conditioning and ClassEmbedder are PINNED against the reference's own
 `LatentDiffusion` methods (tests/golden/ldm_loss_at_t.npz, make_golden_ldm.py loss: `ddpm.py` imports with empty stand-in
 modules for the absent pytorch_lightning / torchvision / taming / clip / kornia, none of whose code is on this path; the
-object's DDPM.__init__ really runs over the reference DiffusionWrapper + UNetModel).  What remains **parity unpinned** is
-the 25-line for-loop of the prune_ldm.py SCRIPT itself (max-loss bookkeeping, threshold test before backward), which is
-module-level script code, not an importable function: restated from the source lines.
+object's DDPM.__init__ really runs over the reference DiffusionWrapper + UNetModel).  The for-loop of the prune_ldm.py
+SCRIPT (lines 103-131: class draw, CFG sampling, loss at t, max-loss bookkeeping, threshold test before backward) is module-
+level code, not an importable function; it is PINNED by tests/golden/ldm_driver.json, for which make_golden_ldm.py `driver`
+EXECUTES those source lines (read from the reference file at generation time) over that LatentDiffusion object and the
+reference DDIMSampler with replayable draws -- a 1000-iteration run that never reaches the threshold and a second run
+constructed to break at t = 2.
 
 Reference lines followed (relative to /root/reference/ldm_exp):
   ldm/modules/diffusionmodules/openaimodel.py:710-742      UNetModel.forward

@@ -227,16 +227,8 @@ def ldm_sampler():
     print('ldm sampler ok:', tuple(samples.shape), 'steps', list(sampler.ddim_timesteps)[:4], '...', float(samples.abs().mean()))
 
 
-def ldm_loss():
-    """Pins get_loss_at_t / p_losses / q_sample / get_learned_conditioning of the LDM importance pass
-    (ldm_exp/prune_ldm.py:122-123 -> ldm/models/diffusion/ddpm.py:881-889, 1022-1056, 274-277, 553-565) and ClassEmbedder
-    (ldm/modules/encoders/modules.py:21-33) by running the reference's OWN methods.  `ddpm.py` imports pytorch_lightning,
-    torchvision.utils, taming, clip and kornia at module level (all absent here); empty stand-in modules satisfy those import
-    statements -- none of their code is on this path (LightningModule only contributes `nn.Module` + a `.device` property).
-    The object is a LatentDiffusion whose base-class __init__ (DDPM.__init__: the reference's DiffusionWrapper around the
-    reference's UNetModel, register_schedule with the cin256-v2 linear_start / linear_end, logvar, loss weights) really runs;
-    LatentDiffusion.__init__ itself (first-stage autoencoder, checkpoint plumbing) is skipped and the five attributes
-    get_loss_at_t reads are set as configs/latent-diffusion/cin256-v2.yaml sets them."""
+def _latent_diffusion():
+    """The reference's LatentDiffusion object used by ldm_loss / ldm_driver (see ldm_loss for what runs and what is stubbed)."""
     def mod(name, **attrs):
         m = types.ModuleType(name)
         m.__dict__.update(attrs)
@@ -271,6 +263,20 @@ def ldm_loss():
     gc.det_init_(ld.model.diffusion_model, 9)
     with torch.no_grad():
         ld.cond_stage_model.embedding.weight.copy_(torch.from_numpy(gc.det_param('embedding.weight', (1001, cfg['context_dim']), 61)))
+    return ld, cfg
+
+
+def ldm_loss():
+    """Pins get_loss_at_t / p_losses / q_sample / get_learned_conditioning of the LDM importance pass
+    (ldm_exp/prune_ldm.py:122-123 -> ldm/models/diffusion/ddpm.py:881-889, 1022-1056, 274-277, 553-565) and ClassEmbedder
+    (ldm/modules/encoders/modules.py:21-33) by running the reference's OWN methods.  `ddpm.py` imports pytorch_lightning,
+    torchvision.utils, taming, clip and kornia at module level (all absent here); empty stand-in modules satisfy those import
+    statements -- none of their code is on this path (LightningModule only contributes `nn.Module` + a `.device` property).
+    The object is a LatentDiffusion whose base-class __init__ (DDPM.__init__: the reference's DiffusionWrapper around the
+    reference's UNetModel, register_schedule with the cin256-v2 linear_start / linear_end, logvar, loss weights) really runs;
+    LatentDiffusion.__init__ itself (first-stage autoencoder, checkpoint plumbing) is skipped and the five attributes
+    get_loss_at_t reads are set as configs/latent-diffusion/cin256-v2.yaml sets them."""
+    ld, cfg = _latent_diffusion()
     assert float(ld.logvar.abs().max()) == 0.0 and ld.l_simple_weight == 1.0 and ld.original_elbo_weight == 0.0
     B, H = 3, cfg['image_size']
     x = torch.from_numpy(gc.det_noise((B, cfg['in_channels'], H, H), 62))
@@ -297,6 +303,106 @@ def ldm_loss():
     np.savez(os.path.join(HERE, 'ldm_loss_at_t.npz'), **out)
     print('ldm loss ok: t', ts, 'losses', losses)
 
+
+def ldm_driver(K=4):
+    """Pins the importance-pass loop of the prune_ldm.py SCRIPT (ldm_exp/prune_ldm.py: from `import random` to `loss.backward()`,
+    lines 103-127) by EXECUTING those source lines, read from the reference file at generation time, in a namespace that holds
+    the reference LatentDiffusion object of ldm_loss, the reference DDIMSampler, and the script's own preamble values at reduced
+    size (2 samples per class, 2 DDIM steps; pruner 'diff-pruning').  Randomness is made replayable by replacing the three
+    sources the loop consumes -- random.sample, torch.randn, torch.randn_like -- with counter-based deterministic draws
+    (golden_common.det_noise(shape, 5000 + call index)).  All 1000 iterations run (the 0.1 threshold never fires on a random
+    UNet: recorded, so the restatement's no-break path is what is pinned).  Recorded: every loss, the class ids and draw
+    indices of the first K iterations, and per-parameter |grad| sums after K backward passes (snapshot taken inside the
+    script's own print of iteration K, which precedes that iteration's backward)."""
+    import builtins
+    import random as _random
+    from ldm.models.diffusion.ddim import DDIMSampler
+    ld, cfg = _latent_diffusion()
+
+    class CpuSampler(DDIMSampler):
+        def register_buffer(self, name, attr):    # the reference moves every buffer to 'cuda' here; no arithmetic
+            setattr(self, name, attr)
+
+    n = 2
+    calls, class_draws, printed, snap = [], [], [], {}
+
+    scale_draw = {}                            # draw index -> factor (the break scenario shrinks one loss-noise draw)
+
+    def det(shape):
+        shape = tuple(int(v) for v in shape)
+        calls.append(shape)
+        return torch.from_numpy(gc.det_noise(shape, 5000 + len(calls) - 1)) * scale_draw.get(len(calls) - 1, 1.0)
+
+    def det_randn(*size, **kw):
+        return det(size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size)
+
+    def det_sample(population, k):
+        c = len(class_draws)
+        ids = [(37 * c + 101 * i + 11) % len(population) for i in range(k)]
+        class_draws.append((ids, len(calls)))
+        return ids
+
+    def rec_print(*a):
+        printed.append([float(v) for v in a])
+        if int(a[0]) == K:
+            for name, p in ld.model.diffusion_model.named_parameters():
+                snap[name] = float(p.grad.abs().sum())
+
+    src = open('/root/reference/ldm_exp/prune_ldm.py').read().splitlines()
+    i0 = src.index('import random')
+    i1 = next(i for i in range(i0, len(src)) if src[i].strip() == 'loss.backward()')
+    block = '\n'.join(src[i0:i1 + 1])
+    ns = dict(model=ld, sampler=CpuSampler(ld), args=types.SimpleNamespace(pruner='diff-pruning'), n_samples_per_class=n,
+              ddim_steps=2, scale=3.0, ddim_eta=0.0, torch=torch, print=rec_print,
+              uc=ld.get_learned_conditioning({ld.cond_stage_key: torch.tensor(n * [1000])}))
+    ld.zero_grad()
+    keep = (torch.randn, torch.randn_like, _random.sample)
+    torch.randn, torch.randn_like, _random.sample = det_randn, lambda x: det(x.shape), det_sample
+    try:
+        exec(compile(block, 'prune_ldm.py[%d:%d]' % (i0 + 1, i1 + 1), 'exec'), ns)
+    finally:
+        torch.randn, torch.randn_like, _random.sample = keep
+    losses = [p[2] for p in printed]
+    assert len(losses) == 1000 and len(snap) > 0
+    per_iter = len(calls) // len(class_draws)
+    first = []
+    for k in range(K):
+        ids, c0 = class_draws[k]
+        first.append(dict(class_ids=ids, x_T_draw=5000 + c0, noise_draw=5000 + c0 + per_iter - 1,
+                          shapes=[list(c) for c in calls[c0:c0 + per_iter]]))
+    rec = dict(n_samples=n, ddim_steps=2, scale=3.0, thr=0.1, lines=[i0 + 1, i1 + 1], iterations=len(losses), losses=losses,
+               max_loss=float(ns['max_loss']), first=first, K=K, grad_abs_sum_after_K=snap, draws_per_iteration=per_iter)
+    # Second scenario, for the branch the run above never takes: the threshold break.  The UNet's output convolution is zeroed
+    # (eps_hat = 0, so loss = mean(noise^2)) and the loss-noise draw of iteration 2 is scaled by 0.3 -> loss ratio 0.09 < 0.1:
+    # the script must stop at t = 2 WITHOUT that iteration's backward (gradients = two passes).
+    with torch.no_grad():
+        for pn, pp in ld.model.diffusion_model.named_parameters():
+            if pn.startswith('out.2.'):
+                pp.zero_()
+    ld.zero_grad()
+    del calls[:], class_draws[:], printed[:]
+    scale_draw[2 * per_iter + per_iter - 1] = 0.3
+    ns.update(sampler=CpuSampler(ld))
+    ns.pop('max_loss', None)
+    torch.randn, torch.randn_like, _random.sample = det_randn, lambda x: det(x.shape), det_sample
+    try:
+        exec(compile(block, 'prune_ldm.py[%d:%d]' % (i0 + 1, i1 + 1), 'exec'), ns)
+    finally:
+        torch.randn, torch.randn_like, _random.sample = keep
+    assert len(printed) == 2 and len(class_draws) == 3, (len(printed), len(class_draws))       # broke inside iteration 2, before its print
+    rec['break_case'] = dict(zeroed_prefix='out.2.', scaled_draw=5000 + 3 * per_iter - 1, factor=0.3, printed_losses=[p[2] for p in printed],
+                             breaking_loss=float(ns['loss']), max_loss=float(ns['max_loss']), stopped_at=int(ns['t']),
+                             class_ids=[c[0] for c in class_draws],
+                             grad_abs_sum={pn: float(pp.grad.abs().sum()) for pn, pp in ld.model.diffusion_model.named_parameters()
+                                           if pp.grad is not None and float(pp.grad.abs().sum()) > 0})
+    json.dump(rec, open(os.path.join(HERE, 'ldm_driver.json'), 'w'))
+    print('break case: stopped at t =', ns['t'], 'loss', float(ns['loss']), 'ratio', float(ns['loss']) / float(ns['max_loss']))
+    print('ldm driver ok: lines', i0 + 1, i1 + 1, 'iterations', len(losses), 'losses', losses[:3], 'min ratio', min(losses) / rec['max_loss'])
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'driver':
+    ldm_driver()
+    sys.exit(0)
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'loss':
     ldm_loss()

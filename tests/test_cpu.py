@@ -1405,3 +1405,74 @@ def test_ldm_loss_at_t_matches_reference_latent_diffusion(mocked, monkeypatch):
             assert worst < 1e-4
         else:
             step.discard()
+
+
+def test_ldm_driver_loop_matches_the_reference_script(mocked, monkeypatch):
+    """The importance-pass loop of the prune_ldm.py script (lines 103-131: class draw, CFG DDIM sampling, get_loss_at_t, max-loss
+    bookkeeping, threshold test, backward) against tests/golden/ldm_driver.json, which make_golden_ldm.py `driver` recorded by
+    EXECUTING those source lines over the reference LatentDiffusion / DDIMSampler with replayable draws: the first K iterations
+    of the oracle restatement and of the product driver (mocked kernels) reproduce the script's losses and the gradients it had
+    accumulated after K backward passes; the recorded run never reaches the 0.1 threshold (1000 iterations), as stated."""
+    from oracle import ldm_ref as R
+    ldm, ldm_sweep = pkg('ldm'), pkg('ldm_sweep')
+    fx = load_json('ldm_driver.json')
+    K, n, S = fx['K'], fx['n_samples'], fx['ddim_steps']
+    assert fx['iterations'] == 1000 and min(l / fx['max_loss'] for l in fx['losses']) > fx['thr']
+    cfg = gc.LDM_TINY_CFG
+    emb_w = torch.from_numpy(gc.det_param('embedding.weight', (1001, cfg['context_dim']), 61))
+    draws = []
+    for it in fx['first']:
+        shape = tuple(it['shapes'][0])
+        assert shape == (n, 3, 64, 64) and tuple(it['shapes'][-1]) == shape
+        draws.append((torch.tensor(it['class_ids']), torch.from_numpy(gc.det_noise(shape, it['x_T_draw'])),
+                      torch.from_numpy(gc.det_noise(shape, it['noise_draw']))))
+    P, losses = _ldm_oracle_sweep(cfg, emb_w, draws, S, fx['thr'])
+    assert len(losses) == K and np.allclose(losses, fx['losses'][:K], rtol=5e-6), (losses, fx['losses'][:K])
+    for name, want in fx['grad_abs_sum_after_K'].items():
+        assert abs(float(P[name].grad.abs().sum()) - want) < 3e-4 * want + 1e-6, name      # (biases in front of a GroupNorm: pure rounding noise)
+    # the product driver on mocked kernels
+    for m in (ldm, ldm_sweep):
+        monkeypatch.setattr(m, 'ops', mocked)
+
+    def cpu_engine(self):
+        if self._engine is None:
+            self._engine = ldm.LdmEngine(self.config)
+        self._engine.bind({n_: p.detach() for n_, p in self.named_parameters()}, None)
+        return self._engine
+    monkeypatch.setattr(ldm.UNetModel, 'engine', cpu_engine)
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    embedder = ldm_sweep.ClassEmbedder(cfg['context_dim'], 1001)
+    with torch.no_grad():
+        embedder.embedding.weight.copy_(emb_w)
+    res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=K, thr=fx['thr'], n_samples=n, ddim_steps=S, scale=fx['scale'],
+                                         latent_shape=(3, 64, 64), draws=lambda t: draws[t])
+    assert res['steps'] == K and res['accumulated'] == K and np.allclose(res['losses'], fx['losses'][:K], rtol=2e-5)
+    got = dict(model.named_parameters())
+    for name, want in fx['grad_abs_sum_after_K'].items():
+        assert abs(float(got[name].grad.abs().sum()) - want) < 1e-3 * want + 1e-6, name
+    # The threshold branch, which that run never takes: the script re-run with the UNet's output convolution zeroed (eps_hat = 0,
+    # loss = mean(noise^2)) and the loss-noise draw of iteration 2 scaled by 0.3 stops at t = 2 BEFORE that iteration's backward.
+    bc = fx['break_case']
+    assert bc['stopped_at'] == 2 and bc['breaking_loss'] / bc['max_loss'] < fx['thr'] and len(bc['printed_losses']) == 2
+    per = fx['draws_per_iteration']
+    draws_b = []
+    for t, ids in enumerate(bc['class_ids']):
+        noise = torch.from_numpy(gc.det_noise((n, 3, 64, 64), 5000 + per * t + per - 1))
+        if 5000 + per * t + per - 1 == bc['scaled_draw']:
+            noise = noise * bc['factor']
+        draws_b.append((torch.tensor(ids), torch.from_numpy(gc.det_noise((n, 3, 64, 64), 5000 + per * t)), noise))
+    model_b = ldm.UNetModel(**cfg)
+    gc.det_init_(model_b, 9)
+    with torch.no_grad():
+        for pn, pp in model_b.named_parameters():
+            if pn.startswith(bc['zeroed_prefix']):
+                pp.zero_()
+    res = ldm_sweep.ldm_importance_sweep(model_b, embedder, num_steps=10, thr=fx['thr'], n_samples=n, ddim_steps=S, scale=fx['scale'],
+                                         latent_shape=(3, 64, 64), draws=lambda t: draws_b[t])
+    assert res['steps'] == 3 and res['accumulated'] == 2
+    assert np.allclose(res['losses'], bc['printed_losses'] + [bc['breaking_loss']], rtol=2e-5)
+    got = dict(model_b.named_parameters())
+    for name, p_ in got.items():
+        want = bc['grad_abs_sum'].get(name, 0.0)
+        assert abs(float(p_.grad.abs().sum()) - want) < 1e-3 * want + 1e-6, name
