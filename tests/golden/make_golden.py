@@ -693,6 +693,44 @@ def do_traced():
     json.dump(res, open(os.path.join(HERE, 'traced_groups.json'), 'w'))
 
 
+def do_script_loop():
+    """Provenance of `sweep()` above: the accumulation loop of the ddpm_prune.py SCRIPT (the `if args.pruner in ['taylor',
+    'diff-pruning']:` block, lines 94-106) is module-level code inside `if __name__ == '__main__'`, so the fixtures drive the
+    reference model with the restatement `sweep()`.  Here the script's own source lines are read from the reference file,
+    dedented and EXECUTED on the tiny UNet -- plain Taylor over all 1000 timesteps and Diff-Pruning with the fixture's threshold --
+    and every accumulated gradient must be bit-identical to what `sweep()` accumulates (same stop step).  The verdict is stored
+    in script_loop_check.json."""
+    import textwrap
+    src = open('/root/reference/ddpm_prune.py').read().splitlines()
+    i1 = next(i for i in range(len(src)) if 'if loss<loss_max * args.thr: break' in src[i])
+    i0 = max(i for i in range(i1) if src[i].strip().startswith("if args.pruner in ['taylor', 'diff-pruning']"))
+    block = textwrap.dedent('\n'.join(src[i0:i1 + 1]))
+    cfg = gc.TINY_CFG
+    H = cfg['sample_size']
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((2, 3, H, H), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, H, H), 2))
+    out = dict(lines=[i0 + 1, i1 + 1])
+    for pruner_name, thr in (('taylor', None), ('diff-pruning', 0.99)):
+        ours = build_ref_unet(cfg, 5)
+        losses = sweep(ours, sched, clean, noise, 1000, thr=thr)
+        theirs = build_ref_unet(cfg, 5)
+        theirs.zero_grad(); theirs.eval()
+        ns = dict(args=types_ns(pruner=pruner_name, thr=thr, batch_size=2), tqdm=lambda it: it, torch=torch, clean_images=clean,
+                  noise=noise, scheduler=sched, model=theirs, print=lambda *a: None)
+        exec(compile(block, 'ddpm_prune.py[%d:%d]' % (i0 + 1, i1 + 1), 'exec'), ns)
+        same = all(torch.equal(a.grad, b.grad) for a, b in zip(ours.parameters(), theirs.parameters()))
+        assert same and ns['step_k'] + 1 == len(losses), (pruner_name, ns['step_k'], len(losses))
+        out[pruner_name] = dict(steps=len(losses), gradients_bit_identical_to_sweep=bool(same))
+    json.dump(out, open(os.path.join(HERE, 'script_loop_check.json'), 'w'))
+    print('script loop ok:', out)
+
+
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads', 'long_sweep', 'lr', 'ddpm', 'dropout', 'fid']
     for w in what:

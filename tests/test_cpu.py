@@ -1476,3 +1476,14 @@ def test_ldm_driver_loop_matches_the_reference_script(mocked, monkeypatch):
     for name, p_ in got.items():
         want = bc['grad_abs_sum'].get(name, 0.0)
         assert abs(float(p_.grad.abs().sum()) - want) < 1e-3 * want + 1e-6, name
+
+
+def test_fixture_sweep_loop_is_the_reference_scripts_loop():
+    """Provenance: the reference's accumulation loop is module-level script code (ddpm_prune.py:94-106), so the fixtures were
+    produced by a ten-line restatement of it inside make_golden.py.  `make_golden.py script_loop` executes the script's own source
+    lines on the reference UNet and records that they accumulate bit-identical gradients and stop at the same step."""
+    chk = load_json('script_loop_check.json')
+    assert chk['lines'] == [94, 106]
+    assert chk['taylor'] == dict(steps=1000, gradients_bit_identical_to_sweep=True)
+    assert chk['diff-pruning']['gradients_bit_identical_to_sweep'] is True
+    assert chk['diff-pruning']['steps'] == load_json('tiny_prune.json')['early_exit']['steps']
