@@ -726,6 +726,83 @@ def do_script_loop():
     print('script loop ok:', out)
 
 
+def do_train_loop(K=3):
+    """The finetune loop of the ddpm_train.py SCRIPT (the body of `for step, batch in enumerate(train_dataloader):`, lines 427-475:
+    noise / antithetic timestep draw, add_noise, zero_grad, forward, per-image summed loss, backward, clip, Adam step, LR-scheduler
+    step, EMA step) EXECUTED from the reference file's own source lines for K batches, with the objects the script builds around
+    it (ddpm_train.py:318-350): the reference UNet2DModel (tiny config, dropout 0) and DDPMScheduler, torch.optim.Adam with the
+    argparse defaults and the lr of scripts/finetune_ddpm_cifar10.sh, diffusers' get_scheduler('cosine', warm-up 2 of 10 steps --
+    so the lr changes every step), the vendored EMAModel, and a real accelerate.Accelerator(cpu=True) after prepare().
+    torch.randn / torch.randint are replaced by counter-based replayable draws.  Recorded per step: loss, lr after the step, the
+    timesteps; at the end every parameter and EMA tensor's |.| sum and three full tensors."""
+    import textwrap
+    import accelerate
+    from diffusers.optimization import get_scheduler
+    from diffusers.training_utils import EMAModel
+    src = open('/root/reference/ddpm_train.py').read().splitlines()
+    i0 = next(i for i, l in enumerate(src) if l.strip() == 'for step, batch in enumerate(train_dataloader):')
+    i1 = next(i for i in range(i0, len(src)) if l_strip(src[i]) == 'logs["ema_decay"] = ema_model.cur_decay_value')
+    block = textwrap.dedent('\n'.join(src[i0:i1 + 1]))
+    cfg = gc.TINY_CFG
+    H, B = cfg['sample_size'], 4
+    model = build_ref_unet(cfg, 5)
+    noise_scheduler = DDPMScheduler(num_train_timesteps=1000)
+    args = types_ns(resume_from_checkpoint=None, gradient_accumulation_steps=1, use_ema=True, learning_rate=2e-4, adam_beta1=0.9,
+                    adam_beta2=0.999, adam_weight_decay=0.0, adam_epsilon=1e-8, ema_max_decay=0.9999, ema_inv_gamma=1.0,
+                    ema_power=0.75)
+    ema_model = EMAModel(model.parameters(), decay=args.ema_max_decay, use_ema_warmup=False, inv_gamma=args.ema_inv_gamma,
+                         power=args.ema_power, model_cls=UNet2DModel, model_config=model.config)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+                                 weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
+    lr_scheduler = get_scheduler('cosine', optimizer=optimizer, num_warmup_steps=2, num_training_steps=10)
+    batches = [torch.from_numpy(gc.det_clean((B, 3, H, H), 10 + k)) for k in range(K)]
+    accelerator = accelerate.Accelerator(cpu=True)
+    model, optimizer, lr_scheduler = accelerator.prepare(model, optimizer, lr_scheduler)
+    calls, steps = [], []
+
+    def det_randn(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        calls.append(('randn', shape))
+        return torch.from_numpy(gc.det_noise(shape, 7000 + len(calls) - 1))
+
+    def det_randint(low=0, high=None, size=None, **kw):
+        calls.append(('randint', tuple(size)))
+        n = size[0]
+        return (torch.arange(n) * 389 + 173 * len(calls) + 7) % (high - low) + low
+
+    class Bar:
+        def update(self, n):
+            steps.append(dict(loss=float(ns['loss'].detach()), lr_after=float(ns['lr_scheduler'].get_last_lr()[0]),
+                              timesteps=[int(t) for t in ns['timesteps']], noise_draw=7000 + len(calls) - 2))
+
+    ns = dict(train_dataloader=batches, model=model, args=args, epoch=0, first_epoch=0, resume_step=0, progress_bar=Bar(), torch=torch,
+              noise_scheduler=noise_scheduler, accelerator=accelerator, optimizer=optimizer, lr_scheduler=lr_scheduler,
+              ema_model=ema_model, global_step=0)
+    keep = (torch.randn, torch.randint)
+    torch.randn, torch.randint = det_randn, det_randint
+    try:
+        exec(compile(block, 'ddpm_train.py[%d:%d]' % (i0 + 1, i1 + 1), 'exec'), ns)
+    finally:
+        torch.randn, torch.randint = keep
+    assert len(steps) == K and ns['global_step'] == K and model.training
+    names = [n for n, _ in model.named_parameters()]
+    full = ['conv_in.weight', 'mid_block.attentions.0.to_q.weight', 'conv_out.bias']
+    P = dict(model.named_parameters())
+    E = dict(zip(names, ema_model.shadow_params))
+    json.dump(dict(lines=[i0 + 1, i1 + 1], batch=B, steps=steps, lr=args.learning_rate, ema_decay=args.ema_max_decay,
+                   scheduler=dict(name='cosine', num_warmup_steps=2, num_training_steps=10),
+                   param_abs_sum={n: float(P[n].detach().abs().sum()) for n in names},
+                   ema_abs_sum={n: float(E[n].detach().abs().sum()) for n in names},
+                   full={n: gc.f32_to_b64(P[n].detach().numpy()) for n in full},
+                   full_ema={n: gc.f32_to_b64(E[n].detach().numpy()) for n in full}),
+              open(os.path.join(HERE, 'train_loop.json'), 'w'))
+    print('train loop ok: lines', i0 + 1, i1 + 1, [(round(s_['loss'], 4), s_['lr_after']) for s_ in steps])
+
+
+def l_strip(line):
+    return line.strip()
+
+
 def types_ns(**kw):
     import types
     return types.SimpleNamespace(**kw)

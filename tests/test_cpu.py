@@ -1487,3 +1487,64 @@ def test_fixture_sweep_loop_is_the_reference_scripts_loop():
     assert chk['taylor'] == dict(steps=1000, gradients_bit_identical_to_sweep=True)
     assert chk['diff-pruning']['gradients_bit_identical_to_sweep'] is True
     assert chk['diff-pruning']['steps'] == load_json('tiny_prune.json')['early_exit']['steps']
+
+
+def test_finetune_loop_matches_the_reference_script(mocked, monkeypatch):
+    """The finetune loop of the ddpm_train.py script (lines 426-475) against tests/golden/train_loop.json, recorded by EXECUTING
+    those source lines over the reference UNet2DModel / DDPMScheduler / torch Adam / diffusers get_scheduler('cosine', warm-up) /
+    vendored EMAModel / accelerate.Accelerator with replayable draws: three optimizer steps of the oracle restatement and of the
+    product's FinetuneEngine (mocked kernels) give the script's losses, learning rates, parameters and EMA weights."""
+    from oracle import diffusion_ref as D
+    train = pkg('train')
+    fx = load_json('train_loop.json')
+    assert fx['lines'] == [426, 475]
+    monkeypatch.setattr(train, '_require_hip_device', lambda dev: None)
+    cfg = gc.TINY_CFG
+    B = fx['batch']
+    sc = fx['scheduler']
+    # oracle
+    P = oracle_params(cfg, 5)
+    names = list(P)
+    plist = [P[n] for n in names]
+    m = [torch.zeros_like(p) for p in plist]
+    v = [torch.zeros_like(p) for p in plist]
+    ema = [p.detach().clone() for p in plist]
+    lrs = train.get_scheduler(sc['name'], fx['lr'], num_warmup_steps=sc['num_warmup_steps'], num_training_steps=sc['num_training_steps'])
+    # product
+    model = _cpu_model(cfg, 5)
+    sched = pkg('diffusion').DDPMScheduler()
+    monkeypatch.setattr(type(sched), '_acp_on', lambda self, dev: self.alphas_cumprod, raising=False)
+    ft = train.FinetuneEngine(model, sched, lr=fx['lr'], ema_decay=fx['ema_decay'],
+                              lr_scheduler=train.get_scheduler(sc['name'], fx['lr'], num_warmup_steps=sc['num_warmup_steps'],
+                                                               num_training_steps=sc['num_training_steps']))
+    for k, st in enumerate(fx['steps']):
+        clean = torch.from_numpy(gc.det_clean((B, 3, 16, 16), 10 + k))
+        noise = torch.from_numpy(gc.det_noise((B, 3, 16, 16), st['noise_draw']))
+        t = torch.tensor(st['timesteps'])
+        assert len(st['timesteps']) == B and all(a + b == 999 for a, b in zip(st['timesteps'][:B // 2], st['timesteps'][B // 2 + 1:]))
+        for p in plist:
+            p.grad = None
+        lo = D.finetune_loss(P, cfg, clean, noise, t)
+        lo.backward()
+        with torch.no_grad():
+            D.adam_ema_step([p.data for p in plist], [p.grad for p in plist], m, v, ema, k + 1, lr=lrs.get_last_lr()[0],
+                            ema_decay=fx['ema_decay'])
+        lrs.step()
+        assert abs(float(lo.detach()) - st['loss']) < 2e-5 * st['loss'], (k, float(lo.detach()), st['loss'])
+        assert abs(lrs.get_last_lr()[0] - st['lr_after']) < 1e-12
+        loss = ft.step(clean, noise, t)
+        assert abs(float(loss) - st['loss']) < 5e-5 * st['loss'], (k, float(loss), st['loss'])
+        assert abs(ft.lr_scheduler.get_last_lr()[0] - st['lr_after']) < 1e-12
+    live = dict(model.named_parameters())
+    es = ft.ema_state()
+    for i, n in enumerate(names):
+        want_p, want_e = fx['param_abs_sum'][n], fx['ema_abs_sum'][n]
+        assert abs(float(plist[i].detach().abs().sum()) - want_p) < 1e-4 * want_p + 1e-6, n
+        assert abs(float(ema[i].abs().sum()) - want_e) < 1e-5 * want_e + 1e-6, n
+        assert abs(float(live[n].detach().abs().sum()) - want_p) < 2e-4 * want_p + 1e-6, n
+        assert abs(float(es[n].abs().sum()) - want_e) < 1e-5 * want_e + 1e-6, n
+    for n, b64 in fx['full'].items():
+        want = torch.from_numpy(gc.b64_to_f32(b64))
+        assert relerr(P[n].detach(), want) < 2e-4 and relerr(live[n].detach(), want) < 2e-4, n
+        want_e = torch.from_numpy(gc.b64_to_f32(fx['full_ema'][n]))
+        assert relerr(es[n], want_e) < 1e-5, n
