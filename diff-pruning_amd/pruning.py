@@ -506,9 +506,12 @@ class DependencyGraph:
         self.model = model
         cfg = getattr(model, 'config', None)
         cfg = dict(cfg) if cfg is not None and hasattr(cfg, 'keys') else {}
-        if 'model_channels' in cfg:
+        # The written-down graphs are for exactly two architectures (this package's classes or the reference's own of the same
+        # name); anything else -- including other Diffusers models that share config keys -- is traced.
+        cls = type(model).__name__
+        if cls == 'UNetModel' and 'model_channels' in cfg:
             self.graph = LdmGraph(cfg)
-        elif 'block_out_channels' in cfg and 'down_block_types' in cfg:
+        elif cls == 'UNet2DModel' and 'block_out_channels' in cfg and 'down_block_types' in cfg:
             self.graph = UNetGraph(cfg)
         else:
             if example_inputs is None:
