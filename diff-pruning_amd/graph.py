@@ -251,8 +251,12 @@ class ChannelView:
         return self._out(name)
 
     def out_channels(self, node):
-        if node.kind in ('conv', 'linear', 'gn', 'ln', 'bn', 'dw'):
+        if node.kind in ('conv', 'linear', 'convT', 'gn', 'ln', 'bn', 'dw', 'inorm', 'embed'):
             return self._out(node.name)
+        if node.kind == 'prelu':
+            c = self._out(node.name)
+            if c is not None:                      # per-channel slopes; a single shared slope says nothing about the width
+                return c
         if node.kind == 'cat':
             return sum(self.out_channels(i) for i in node.inputs)
         if node.kind == 'const':
@@ -296,7 +300,7 @@ def _fns(node):
     """(in-channel pruning fn, out-channel pruning fn) of a node.  Layers with a weight matrix have two different ones;
     everything else prunes 'its channels' with ONE function (function.py: prune_in_channels = prune_out_channels for the
     norms and the depthwise convolution, ops.py dummy pruners for element-wise / concat / split / reshape)."""
-    return ('in', 'out') if node.kind in ('conv', 'linear') else ('p', 'p')
+    return ('in', 'out') if node.kind in ('conv', 'linear', 'convT') else ('p', 'p')
 
 
 def _to_input(chan, node, k, ii):
@@ -429,7 +433,7 @@ def coupled_members(graph, chan, root_name, idxs, aux=None):
     out = []
     for key in order:
         node, fn, ii, _ = merged[key]
-        kind = fn if node.kind in ('conv', 'linear') else ('out' if node.kind == 'dw' else node.kind)
+        kind = fn if node.kind in ('conv', 'linear', 'convT') else ('out' if node.kind == 'dw' else node.kind)
         out.append(Member(node.name, kind, sorted(ii)))
     if aux is not None:
         aux.extend((n, len(ii)) for n, ii in sliced.values() if not isinstance(n.part[1], int))
@@ -441,7 +445,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
     `chan_fn()` returns a fresh ChannelView (channel counts change while the caller prunes between yields)."""
     visited = set()
     for node in graph.order:
-        if node.kind not in ('conv', 'linear', 'dw'):
+        if node.kind not in ('conv', 'linear', 'dw', 'convT'):
             continue
         if node.name in ignored or node.name in visited:
             continue
@@ -450,7 +454,7 @@ def all_groups(graph, chan_fn, ignored=('conv_out',)):
         members = coupled_members(graph, chan, node.name, list(range(n_out)))
         prunable = True
         for m in members:
-            if m.kind in ('out', 'gn', 'ln', 'bn'):  # members pruned through an out-channel pruning function
+            if m.kind in ('out', 'gn', 'ln', 'bn', 'inorm', 'prelu', 'embed'):  # pruned through an out-channel pruning function
                 visited.add(m.name)
                 if m.name in ignored:
                     prunable = False

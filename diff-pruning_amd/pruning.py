@@ -121,6 +121,54 @@ def prune_batchnorm_out_channels(layer, idxs):
     return layer
 
 
+def prune_conv_transpose_out_channels(layer, idxs):
+    """function.py ConvPruner, `transposed` branch: the weight is [Cin, Cout, k, k]."""
+    keep = _keep(layer.out_channels, idxs, layer.weight.device)
+    layer.out_channels = layer.out_channels - len(set(idxs))
+    _slice_param(layer, 'weight', 1, keep)
+    _slice_param(layer, 'bias', 0, keep)
+    return layer
+
+
+def prune_conv_transpose_in_channels(layer, idxs):
+    keep = _keep(layer.in_channels, idxs, layer.weight.device)
+    layer.in_channels = layer.in_channels - len(set(idxs))
+    _slice_param(layer, 'weight', 0, keep)
+    return layer
+
+
+def prune_instancenorm_out_channels(layer, idxs):
+    """function.py InstanceNormPruner (running statistics, when tracked, are sliced too so that the module stays usable)."""
+    dev = layer.weight.device if layer.affine else (layer.running_mean.device if layer.running_mean is not None else 'cpu')
+    keep = _keep(layer.num_features, idxs, dev)
+    layer.num_features = layer.num_features - len(set(idxs))
+    if layer.affine:
+        _slice_param(layer, 'weight', 0, keep)
+        _slice_param(layer, 'bias', 0, keep)
+    if layer.running_mean is not None:
+        layer.running_mean = layer.running_mean.data.index_select(0, keep)
+        layer.running_var = layer.running_var.data.index_select(0, keep)
+    return layer
+
+
+def prune_prelu_out_channels(layer, idxs):
+    """function.py PReLUPruner: a single shared slope is not touched."""
+    if layer.num_parameters == 1:
+        return layer
+    keep = _keep(layer.num_parameters, idxs, layer.weight.device)
+    layer.num_parameters = layer.num_parameters - len(set(idxs))
+    _slice_param(layer, 'weight', 0, keep)
+    return layer
+
+
+def prune_embedding_out_channels(layer, idxs):
+    """function.py EmbeddingPruner: the embedding dimension (columns of the table)."""
+    keep = _keep(layer.embedding_dim, idxs, layer.weight.device)
+    layer.embedding_dim = layer.embedding_dim - len(set(idxs))
+    _slice_param(layer, 'weight', 1, keep)
+    return layer
+
+
 def prune_depthwise_conv_out_channels(layer, idxs):
     """function.py DepthwiseConvPruner: one filter per channel, so in_channels, out_channels and groups shrink together."""
     keep = _keep(layer.out_channels, idxs, layer.weight.device)
@@ -135,6 +183,9 @@ function = SimpleNamespace(
     prune_batchnorm_out_channels=prune_batchnorm_out_channels, prune_batchnorm_in_channels=prune_batchnorm_out_channels,
     prune_depthwise_conv_out_channels=prune_depthwise_conv_out_channels,
     prune_depthwise_conv_in_channels=prune_depthwise_conv_out_channels,
+    prune_instancenorm_out_channels=prune_instancenorm_out_channels, prune_instancenorm_in_channels=prune_instancenorm_out_channels,
+    prune_prelu_out_channels=prune_prelu_out_channels, prune_prelu_in_channels=prune_prelu_out_channels,
+    prune_embedding_out_channels=prune_embedding_out_channels, prune_embedding_in_channels=prune_embedding_out_channels,
     prune_conv_out_channels=prune_conv_out_channels, prune_conv_in_channels=prune_conv_in_channels,
     prune_linear_out_channels=prune_linear_out_channels, prune_linear_in_channels=prune_linear_in_channels,
     prune_groupnorm_out_channels=prune_groupnorm_out_channels, prune_groupnorm_in_channels=prune_groupnorm_in_channels,
@@ -148,6 +199,14 @@ def _handler_for(layer, kind):
         return prune_groupnorm_out_channels
     if kind == 'bn':
         return prune_batchnorm_out_channels
+    if kind == 'inorm':
+        return prune_instancenorm_out_channels
+    if kind == 'prelu':
+        return prune_prelu_out_channels
+    if kind == 'embed':
+        return prune_embedding_out_channels
+    if isinstance(layer, nn.modules.conv._ConvNd) and layer.transposed:
+        return prune_conv_transpose_out_channels if kind == 'out' else prune_conv_transpose_in_channels
     if isinstance(layer, nn.modules.conv._ConvNd) and layer.groups > 1:
         return prune_depthwise_conv_out_channels
     if isinstance(layer, nn.Linear):
@@ -162,8 +221,12 @@ def _out_channels(layer):
         return layer.num_channels
     if isinstance(layer, nn.LayerNorm):
         return layer.normalized_shape[-1]
-    if isinstance(layer, nn.modules.batchnorm._BatchNorm):
+    if isinstance(layer, (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm)):
         return layer.num_features
+    if isinstance(layer, nn.PReLU):
+        return layer.num_parameters if layer.num_parameters > 1 else None
+    if isinstance(layer, nn.Embedding):
+        return layer.embedding_dim
     return layer.out_channels
 
 
@@ -174,8 +237,12 @@ def _in_channels(layer):
         return layer.num_channels
     if isinstance(layer, nn.LayerNorm):
         return layer.normalized_shape[-1]
-    if isinstance(layer, nn.modules.batchnorm._BatchNorm):
+    if isinstance(layer, (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm)):
         return layer.num_features
+    if isinstance(layer, nn.PReLU):
+        return layer.num_parameters if layer.num_parameters > 1 else None
+    if isinstance(layer, nn.Embedding):
+        return layer.embedding_dim
     return layer.in_channels
 
 
@@ -261,6 +328,8 @@ class Importance(abc.ABC):
 
 
 _MODES = {'sum_sq': 0, 'sum_abs': 1, 'abs_sum': 2}
+_NO_TERM = ('ln', 'bn', 'inorm', 'prelu', 'embed')                     # member kinds the vendored criteria have no branch for
+_OUT_KINDS = ('out', 'gn', 'ln', 'bn', 'inorm', 'prelu', 'embed')      # members pruned through an out-channel pruning function
 _F_SQ, _F_ABS, _F_SIGNED, _F_GN_ABS, _F_GRAD_SQ, _F_SUM = 0, 1, 2, 3, 4, 5      # dp_wg_reduce modes (include/dp_hip.h)
 
 
@@ -298,6 +367,8 @@ class TaylorImportance(Importance):
             n_full = w.shape[0]
         else:
             dim = 0 if kind == 'out' else 1
+            if getattr(layer, 'transposed', False):        # ConvTranspose: weight [Cin, Cout, k, k] (importance.py:390-392,404-406)
+                dim = 1 - dim
             n_full = w.shape[dim]
             full = torch.empty(n_full, dtype=torch.float32, device=dev)
             if dim == 1:
@@ -313,7 +384,7 @@ class TaylorImportance(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
-            if kind is None or kind in ('ln', 'bn'):  # LayerNorm / BatchNorm members carry no term (importance.py:383-418)
+            if kind is None or kind in _NO_TERM:      # LayerNorm / BatchNorm / ... members carry no term (importance.py:383-418)
                 continue
             layer = dep.target.module
             if kind == 'gn' and (not layer.affine or not self.groupnorm_term):
@@ -364,6 +435,8 @@ class _GradCriterion(Importance):
             w, g, dim, modes = w.reshape(-1, 1), g.reshape(-1, 1), 0, self.gn_modes
         else:
             dim, modes = (0 if kind == 'out' else 1), self.conv_modes
+            if getattr(layer, 'transposed', False):
+                dim = 1 - dim
         n_full = w.shape[dim]
         full = torch.empty(n_full, dtype=torch.float32, device=w.device)
         if dim == 1:
@@ -380,7 +453,7 @@ class _GradCriterion(Importance):
         for dep, idxs in group:
             idxs.sort()
             kind = _member_kind(dep)
-            if kind is None or kind in ('ln', 'bn'):
+            if kind is None or kind in _NO_TERM:
                 continue
             layer = dep.target.module
             if kind == 'gn' and (not layer.affine or not self.gn_modes):
@@ -555,7 +628,9 @@ class DependencyGraph:
 
     def check_pruning_group(self, group):
         for dep, idxs in group:
-            n = _out_channels(dep.target.module) if dep.kind in ('out', 'gn', 'ln', 'bn') else _in_channels(dep.target.module)
+            n = _out_channels(dep.target.module) if dep.kind in _OUT_KINDS else _in_channels(dep.target.module)
+            if n is None:                        # a PReLU with one shared slope has no channel count
+                continue
             if n <= len(idxs):
                 return False
         return True
@@ -584,7 +659,8 @@ class MetaPruner:
         self.iterative_steps, self.current_step = iterative_steps, 0
         self.layer_init_out_ch, self.layer_init_in_ch = {}, {}
         for m in model.modules():
-            if isinstance(m, (nn.modules.conv._ConvNd, nn.Linear, nn.GroupNorm, nn.LayerNorm, nn.modules.batchnorm._BatchNorm)):
+            if isinstance(m, (nn.modules.conv._ConvNd, nn.Linear, nn.GroupNorm, nn.LayerNorm, nn.modules.batchnorm._BatchNorm,
+                              nn.modules.instancenorm._InstanceNorm, nn.PReLU, nn.Embedding)) and _out_channels(m) is not None:
                 self.layer_init_out_ch[m] = _out_channels(m)
                 self.layer_init_in_ch[m] = _in_channels(m)
         self.per_step_ch_sparsity = iterative_sparsity_scheduler(ch_sparsity, iterative_steps)
@@ -623,7 +699,9 @@ class MetaPruner:
     def _check_sparsity(self, group):
         for dep, _ in group:
             m = dep.target.module
-            if dep.kind in ('out', 'gn', 'ln', 'bn'):
+            if m not in self.layer_init_out_ch:
+                continue                             # e.g. a PReLU with one shared slope
+            if dep.kind in _OUT_KINDS:
                 n = _out_channels(m)
                 if n < self.layer_init_out_ch[m] * (1 - self.max_ch_sparsity) or n == 1:
                     return False

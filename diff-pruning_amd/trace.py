@@ -23,9 +23,10 @@ Where the reference infers shapes from neighbouring layers, this tracer reads th
 On graphs where the reference's inference is right, both give the same groups: tests/golden/traced_groups.json
 (written by the reference's DependencyGraph on the toy networks of tests/helpers.py) pins that.
 
-Supported prunable leaves: Conv1d/2d/3d (groups == 1, or depthwise), Linear, BatchNorm1d/2d/3d, GroupNorm, LayerNorm.
-Anything else that owns parameters (ConvTranspose, grouped convolutions, PReLU, Embedding, LSTM, MultiheadAttention,
-parameters used outside a module) raises: silently treating them as element-wise would enumerate wrong groups.
+Supported prunable leaves: Conv1d/2d/3d (groups == 1, or depthwise), ConvTranspose (groups == 1), Linear, BatchNorm1d/2d/3d,
+InstanceNorm, GroupNorm, LayerNorm, PReLU, Embedding.  Anything else that owns parameters (grouped convolutions, LSTM,
+MultiheadAttention, parameters used outside a module) raises: silently treating them as element-wise would enumerate wrong
+groups.
 """
 import torch
 from torch import nn
@@ -43,7 +44,7 @@ def _module_kind(m):
     """Node kind of a prunable leaf module, or None."""
     if isinstance(m, nn.modules.conv._ConvNd):
         if m.transposed:
-            return None
+            return 'convT' if m.groups == 1 else None
         if m.groups == 1:
             return 'conv'
         return 'dw' if is_depthwise(m) else None
@@ -51,6 +52,12 @@ def _module_kind(m):
         return 'linear'
     if isinstance(m, nn.modules.batchnorm._BatchNorm):
         return 'bn'
+    if isinstance(m, nn.modules.instancenorm._InstanceNorm):
+        return 'inorm'
+    if isinstance(m, nn.PReLU):
+        return 'prelu'
+    if isinstance(m, nn.Embedding):
+        return 'embed'
     for t, k in _NORM_KINDS.items():
         if isinstance(m, t):
             return k

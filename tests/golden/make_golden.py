@@ -94,6 +94,12 @@ def kind_of(dep):
         return 'ln'
     if h in (f.prune_depthwise_conv_out_channels, f.prune_depthwise_conv_in_channels):
         return 'out'
+    if h in (f.prune_instancenorm_out_channels, f.prune_instancenorm_in_channels):
+        return 'inorm'
+    if h in (f.prune_prelu_out_channels, f.prune_prelu_in_channels):
+        return 'prelu'
+    if h in (f.prune_embedding_out_channels, f.prune_embedding_in_channels):
+        return 'embed'
     return 'other'
 
 

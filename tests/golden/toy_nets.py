@@ -148,6 +148,28 @@ class TimeCondUNet(nn.Module):
         return self.out_a(m), self.out_b(m)
 
 
+class Generator(nn.Module):
+    """Class-conditional generator: Embedding -> Linear -> view(N, C, 4, 4) -> ConvTranspose2d -> InstanceNorm2d(affine) ->
+    PReLU(per channel) -> Conv2d -> PReLU(one shared slope) -> Conv2d: the four further layer kinds of the tracer."""
+
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Embedding(10, 12)
+        self.fc = nn.Linear(12, 8 * 4 * 4)
+        self.up = nn.ConvTranspose2d(8, 10, 4, stride=2, padding=1)
+        self.norm = nn.InstanceNorm2d(10, affine=True)
+        self.act = nn.PReLU(10)
+        self.conv = nn.Conv2d(10, 6, 3, padding=1)
+        self.act2 = nn.PReLU()
+        self.head = nn.Conv2d(6, 3, 1)
+
+    def forward(self, labels):
+        h = self.fc(self.embed(labels))
+        h = self.up(h.view(h.shape[0], -1, 4, 4))
+        h = self.act(self.norm(h))
+        return self.head(self.act2(self.conv(h)))
+
+
 class ZeroEquiv(nn.Module):
     """ReLU-only, norm-free network (so that removing a channel == zeroing the layer that produces it) with an image-first
     concatenation, a three-way uneven split, a flatten and a depthwise convolution: the semantic check of the tracer."""
@@ -183,6 +205,7 @@ NETS = {
     'res_cat': (ResCat, _img(3, 8), ['head']),
     'token_mixer': (TokenMixer, lambda: (torch.linspace(-1, 1, 2 * 5 * 6).reshape(2, 5, 6),), ['head']),
     'mobile_block': (MobileBlock, _img(3, 8), ['head']),
+    'generator': (Generator, lambda: (torch.tensor([1, 7]),), ['head']),
     'time_cond_unet': (TimeCondUNet, lambda: (torch.linspace(-1, 1, 2 * 3 * 64).reshape(2, 3, 8, 8),
                                               torch.linspace(0, 1, 16).reshape(2, 8)), ['out_a', 'out_b']),
 }

@@ -1038,7 +1038,7 @@ def test_compare_directories_ssim_and_fid_paths(report, tmp_path):
     assert abs(f_self) < 1e-3 and f_ab > 0 and abs(f_ab - f_npz) < 1e-6 * max(f_ab, 1.0)
 
 
-@pytest.mark.parametrize('name', ['res_cat', 'plain_cnn', 'token_mixer'])
+@pytest.mark.parametrize('name', ['res_cat', 'plain_cnn', 'token_mixer', 'generator'])
 def test_traced_model_taylor_prune_on_device(report, name):
     """Row f2: the device criterion on a network that is NOT one of the two UNet families.  A plain-PyTorch toy network
     (tests/golden/toy_nets.py) lives on the GPU, its gradients come from torch autograd, the groups from the autograd
@@ -1062,9 +1062,11 @@ def test_traced_model_taylor_prune_on_device(report, name):
         want = torch.zeros(n0, dtype=torch.float64)
         for dep, ix in all_g:
             m = dep.target.module
-            if len(ix) != n0 or dep.kind in ('ln', 'bn'):
+            if len(ix) != n0 or dep.kind in ('ln', 'bn', 'inorm', 'prelu', 'embed'):
                 continue
             wg = (m.weight.data.double() * m.weight.grad.data.double()).cpu()
+            if getattr(m, 'transposed', False):              # ConvTranspose: [Cin, Cout, k, k] (importance.py:390-392)
+                wg = wg.transpose(0, 1)
             if dep.kind == 'out':
                 want += wg[ix].flatten(1).square().sum(1)
             elif dep.kind == 'in':
@@ -1078,5 +1080,5 @@ def test_traced_model_taylor_prune_on_device(report, name):
         n_groups += 1
     with torch.no_grad():
         y = model(*inputs)
-    assert torch.isfinite(y).all() and n_groups >= 3
+    assert torch.isfinite(y).all() and n_groups >= 2
     report['traced/%s' % name] = dict(groups=n_groups, score_rel_err=worst, params_after=sum(p.numel() for p in model.parameters()))

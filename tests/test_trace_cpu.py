@@ -148,17 +148,17 @@ def test_pruning_a_traced_group_equals_zeroing_its_producers():
 def test_tracer_refuses_what_it_has_no_rule_for():
     trace, pruning = pkg('trace'), pkg('pruning')
 
-    class WithEmbedding(nn.Module):
+    class WithAttention(nn.Module):
         def __init__(self):
             super().__init__()
-            self.emb = nn.Embedding(10, 8)
+            self.mha = nn.MultiheadAttention(8, 2, batch_first=True)
             self.fc = nn.Linear(8, 4)
 
-        def forward(self, i):
-            return self.fc(self.emb(i))
+        def forward(self, x):
+            return self.fc(self.mha(x, x, x)[0])
 
-    with pytest.raises(NotImplementedError, match='emb'):
-        trace.TracedGraph(WithEmbedding(), (torch.tensor([1, 2]),))
+    with pytest.raises(NotImplementedError, match='mha'):
+        trace.TracedGraph(WithAttention(), (torch.randn(2, 3, 8),))
 
     class Bare(nn.Module):
         def __init__(self):
