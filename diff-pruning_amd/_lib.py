@@ -88,6 +88,8 @@ SIGNATURES = {
     'dp_mse_fwd_bwd': [_vp, _vp, _ll, _f, _vp, _vp, _i, _vp, _vp],
     'dp_early_exit_update': [_vp, _f, _vp, _vp, _i, _vp],
     'dp_zero_if_stopped': [_vp, _ll, _vp, _vp],
+    'dp_early_exit_update_ratio': [_vp, _f, _vp, _vp, _i, _vp],
+    'dp_randn_philox': [_vp, _ll, _ll, C.c_ulonglong, C.c_uint, C.c_uint, _vp],
     'dp_sum_partials': [_vp, _i, _f, _vp, _vp],
     'dp_downsum2x2': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],
     'dp_upsample2x': [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _vp],

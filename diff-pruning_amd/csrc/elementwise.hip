@@ -244,6 +244,27 @@ extern "C" int dp_early_exit_update(const float* loss, float thr, float* state, 
     return DP_LAUNCH_CHECK();
 }
 
+// The LDM script's form of the same test (ldm_exp/prune_ldm.py:104,124-129): `max_loss = -1` initially (the host writes -1 into
+// state[0]), `if loss > max_loss: max_loss = loss;  if loss / max_loss < thres: break` -- the quotient rounded to fp32 as the
+// division of two fp32 0-d tensors is.  thr < 0 never fires (plain Taylor: only the losses are recorded).
+__global__ void early_exit_update_ratio_kernel(const float* __restrict__ loss, float thr, float* __restrict__ state,
+                                               float* __restrict__ losses, int max_steps) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || state[1] != 0.f) return;
+    const float l = loss[0];
+    const int k = (int)state[2];
+    if (k < max_steps) losses[k] = l;
+    state[2] = (float)(k + 1);
+    float mx = state[0];
+    if (l > mx) mx = l;
+    state[0] = mx;
+    if (__fdiv_rn(l, mx) < thr) state[1] = 1.f;
+}
+extern "C" int dp_early_exit_update_ratio(const float* loss, float thr, float* state, float* losses, int max_steps,
+                                          void* stream) {
+    DP_LAUNCH(early_exit_update_ratio_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, thr, state, losses, max_steps);
+    return DP_LAUNCH_CHECK();
+}
+
 // x *= (stopped ? 0 : 1): the ddpm_exp flavour tests the threshold BEFORE the backward pass, so dOut of the breaking step
 // itself has to be cancelled after the state update
 __global__ void scale_if_stopped_kernel(float* __restrict__ x, long long n, const float* __restrict__ state) {
@@ -588,6 +609,43 @@ extern "C" int dp_dropout_mask(float* m, long long idx0, long long n, const dp_d
     if (!drop || !drop->thr24) return (int)hipErrorInvalidValue;
     DP_LAUNCH(dropout_mask_kernel, dim3(dp_grid(n)), dim3(256), 0, (hipStream_t)stream, m, idx0, n,
                        dp_drop_host(drop));
+    return DP_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Standard-normal draws as a pure function of (seed, stream, step, logical element index): Philox4x32-10 on counter
+// (idx4 lo, idx4 hi, stream, step), key = seed; the four words give two Box-Muller pairs
+//   u = w * 2^-32 + 2^-33 in (0, 1],  r = sqrt(-2 ln u_a),  (r cos 2 pi u_b, r sin 2 pi u_b).
+// Element idx takes output idx & 3 (0: r0 cos, 1: r0 sin, 2: r1 cos, 3: r1 sin).  The LDM importance pass draws x_T and the
+// loss noise with it (the reference draws both from the device RNG: ddim.py `torch.randn(shape, device=device)`,
+// ddpm.py p_losses `torch.randn_like(x_start)`): idx is the GLOBAL index of the latent element, so a rank's shard holds
+// exactly its slice of the one-process draw.  Restated in oracle/philox_ref.py.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dp_u01(unsigned w) { return fmaf((float)w, 2.3283064365386963e-10f, 1.1641532182693481e-10f); }
+__global__ void randn_philox_kernel(float* __restrict__ out, long long idx0, long long n, unsigned seed_lo, unsigned seed_hi,
+                                    unsigned stream_id, unsigned step) {
+    const long long q0 = idx0 >> 2;
+    const long long nq = ((idx0 + n + 3) >> 2) - q0;
+    GS_LOOP(j, nq) {
+        const unsigned long long q = (unsigned long long)(q0 + j);
+        const uint4 r = dp_philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), stream_id, step), seed_lo, seed_hi);
+        const float ra = sqrtf(-2.f * logf(dp_u01(r.x))), rb = sqrtf(-2.f * logf(dp_u01(r.z)));
+        const float ta = 6.2831853071795865f * dp_u01(r.y), tb = 6.2831853071795865f * dp_u01(r.w);
+        const float v[4] = {ra * cosf(ta), ra * sinf(ta), rb * cosf(tb), rb * sinf(tb)};
+        const long long base = (long long)(q << 2) - idx0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = base + e;
+            if (i >= 0 && i < n) out[i] = v[e];
+        }
+    }
+}
+extern "C" int dp_randn_philox(float* out, long long idx0, long long n, unsigned long long seed, unsigned stream_id,
+                               unsigned step, void* stream) {
+    if (n <= 0) return 0;
+    if (idx0 < 0) return (int)hipErrorInvalidValue;
+    DP_LAUNCH(randn_philox_kernel, dim3(dp_grid((n + 3) / 4 + 1)), dim3(256), 0, (hipStream_t)stream, out, idx0, n,
+              (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), stream_id, step);
     return DP_LAUNCH_CHECK();
 }
 

@@ -10,7 +10,15 @@ The sampler, the noise schedule, q_sample / get_loss_at_t / p_losses and the cla
 reference's own `DDIMSampler` and `LatentDiffusion` methods (tests/golden/ldm_sampler.npz, ldm_loss_at_t.npz); the for-loop
 of the prune_ldm.py script around them (module-level code, lines 103-131) is pinned by tests/golden/ldm_driver.json, recorded
 by executing those source lines over the reference objects (losses, accumulated gradients, the break before backward).  Randomness (class ids, x_T, the loss noise) comes from caller-supplied
-generators so that the CPU oracle can replay the same draws (the reference uses the device RNG).
+generators so that the CPU oracle can replay the same draws (the reference uses the device RNG); by default x_T and the
+loss noise are Philox draws made on the device (`ops.randn_philox`), functions of (seed, step, global latent element).
+
+Data parallelism (4 GPUs): the `n_samples` latents of a step are sharded over the ranks (uneven
+shards allowed: 6 over 4 = 2, 2, 1, 1); every rank samples its own latents (the sampling is 93 % of a step and independent
+per latent), scales its loss and gradient by 1 / numel_global, the scalar loss is all-reduced on the stream for the
+early-exit test (so every rank stops at the same t), and the flat gradient buffer is all-reduced ONCE at the end.  The
+max-loss / threshold state lives on the device (`dp_early_exit_update_ratio`): the breaking step's dOut is cancelled there
+(`dp_zero_if_stopped`), the host reads the stop flag one step late from pinned memory, so no step waits for the host.
 """
 import random
 
@@ -81,25 +89,30 @@ def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0
 
 
 class LdmSweepStep:
-    """loss at timestep t + backward on the HIP engine (get_loss_at_t + loss.backward())."""
+    """loss at timestep t + backward on the HIP engine (get_loss_at_t + loss.backward()).
+    `global_numel`: elements of the GLOBAL latent batch (mean_B mean_CHW == mean over every element of it); a rank's loss
+    and gradient are its share of that mean."""
 
-    def __init__(self, model, schedule):
+    def __init__(self, model, schedule, global_numel=None):
         self.model, self.schedule = model, schedule
+        self.global_numel = global_numel
         self.eng = model.engine()
         self._P = {n: p.detach() for n, p in model.named_parameters()}
         self._G = {n: p.grad for n, p in model.named_parameters()}
 
-    def loss(self, x_start, t, context, noise):
+    def loss(self, x_start, t, context, noise, stop_state=None):
         self.eng.bind(self._P, self._G)          # model(...) calls of the sampler re-bind the engine without gradients
         sa, sb = self.schedule.tables(x_start.device)
         x_noisy = ops.q_sample(x_start.contiguous(), noise.contiguous(), sa, sb, t)
         out = self.eng.forward(x_noisy, t, context, save=True)
-        n = out.numel()                      # mean_B(mean_CHW) == mean over every element
-        loss, dout = ops.mse_fwd_bwd(out, noise.contiguous(), 2.0 / n, 1.0 / n)
+        n = self.global_numel or out.numel()     # mean_B(mean_CHW) == mean over every element
+        loss, dout = ops.mse_fwd_bwd(out, noise.contiguous(), 2.0 / n, 1.0 / n, stop_state=stop_state)
         self._dout = dout
         return loss
 
-    def backward(self):
+    def backward(self, cancel_if_stopped=None):
+        if cancel_if_stopped is not None:        # the breaking step contributes no gradient (prune_ldm.py:127-131)
+            ops.zero_if_stopped(self._dout, cancel_if_stopped)
         self.eng.backward(self._dout)
         self._dout = None
 
@@ -108,38 +121,160 @@ class LdmSweepStep:
         self._dout = None
 
 
+def shard_bounds(n, rank, world):
+    """[lo, hi) of rank's share of n items: the first n % world ranks hold one more (6 over 4 -> 2, 2, 1, 1)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class _Stager:
+    """Host -> device staging that never blocks the host on the stream: a ring of pinned buffers + non_blocking copies
+    (a pageable `.to(device)` waits for everything enqueued before it).  CPU tensors pass through (mocked-kernel tests)."""
+
+    def __init__(self, device, depth=4):
+        self.device, self.depth, self.ring = device, depth, {}
+        self.on = device.type == 'cuda'
+
+    def __call__(self, t):
+        if not self.on:
+            return t
+        key = (tuple(t.shape), t.dtype)
+        slot = self.ring.setdefault(key, dict(bufs=[], evs=[], i=0))
+        if len(slot['bufs']) < self.depth:
+            slot['bufs'].append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
+            slot['evs'].append(torch.cuda.Event())
+        i = slot['i'] % len(slot['bufs'])
+        if slot['i'] >= self.depth:
+            slot['evs'][i].synchronize()             # that copy left the buffer `depth` steps ago
+        slot['bufs'][i].copy_(t)
+        d = slot['bufs'][i].to(self.device, non_blocking=True)
+        slot['evs'][i].record()
+        slot['i'] += 1
+        return d
+
+
+class _LaggedFlag:
+    """The stop flag of the on-device early exit, read ONE step late: after step t has been enqueued the host looks at the
+    state copied out after step t-1 (pinned memory + event), so the device always has a full step queued behind the one the
+    host waits for.  On the CPU (mocked kernels) the state is read directly, with the same one-step lag."""
+
+    def __init__(self, device):
+        self.on = device.type == 'cuda'
+        self.prev = None
+        if self.on:
+            self.bufs = [torch.zeros(3, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self.evs = [torch.cuda.Event() for _ in range(2)]
+        self.k = 0
+
+    def push(self, state):
+        """Returns True when the state recorded by the PREVIOUS push says `stopped`."""
+        stopped = False
+        if self.prev is not None:
+            if self.on:
+                self.evs[self.prev].synchronize()
+                stopped = float(self.bufs[self.prev][1]) != 0.0
+            else:
+                stopped = self.prev_val
+        i = self.k & 1
+        if self.on:
+            self.bufs[i].copy_(state, non_blocking=True)
+            self.evs[i].record()
+        else:
+            self.prev_val = float(state[1]) != 0.0
+        self.prev = i
+        self.k += 1
+        return stopped
+
+
+X_T_STREAM, NOISE_STREAM = 0x7854, 0x6e73          # Philox stream ids of the two draws of a step ('xT', 'ns')
+
+
 def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1, n_samples=6, ddim_steps=20, scale=3.0,
-                         latent_shape=(3, 64, 64), uncond_class=1000, class_rng=None, generator=None, draws=None):
+                         latent_shape=(3, 64, 64), uncond_class=1000, class_rng=None, generator=None, draws=None,
+                         group=None, seed=0, device_exit=True, reduce_grads=True, shard=None):
     """prune_ldm.py:101-131.  thr=None -> plain Taylor over `num_steps` (thres 0.0 in the reference).
-    `draws(t)` may supply (class_ids, x_T, noise) for step t (used by the parity tests); otherwise they are drawn from
-    `class_rng` (random.Random) and `generator` (torch CPU generator).  Returns dict(losses, steps, accumulated)."""
+
+    Draws of step t, always those of the GLOBAL batch of `n_samples` latents (every rank makes the same draws and keeps its
+    shard): `draws(t)` may supply (class_ids, x_T, noise) host tensors (parity tests); with a torch CPU `generator` x_T and
+    noise come from it; otherwise they are device Philox draws keyed by (`seed`, t, global element).  Class ids come from
+    `class_rng` (random.Random; the script's `random.sample(range(1000), n)`).
+    `group`: torch.distributed process group (None = default group when initialised).  device_exit=False reads the loss on
+    the host after every step, as the script does.  `shard=(rank, world)` computes that rank's share in THIS process without
+    any collective (what one rank of a `world`-rank job contributes; the linearity tests sum such shares).  Returns dict(losses [global], steps, accumulated, flat_grads, shard)."""
+    import torch.distributed as dist
     from .sweep import flatten_grads
     dev = next(model.parameters()).device
+    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if use_dist else (0, 1)
+    if shard is not None:
+        if use_dist:
+            raise ValueError('shard=(rank, world) emulates one rank in a single process: not inside a process group')
+        rank, world = shard
+    lo, hi = shard_bounds(n_samples, rank, world)
+    n_loc = hi - lo
+    if n_loc == 0:
+        raise ValueError('%d latents cannot be sharded over %d ranks: every rank needs at least one' % (n_samples, world))
     schedule = schedule or LdmSchedule()
     flat = flatten_grads(model)
-    step = LdmSweepStep(model, schedule)
+    per = 1
+    for d in latent_shape:
+        per *= int(d)
+    step = LdmSweepStep(model, schedule, global_numel=n_samples * per)
     class_rng = class_rng or random.Random(0)
-    uc = embedder(torch.tensor(n_samples * [uncond_class]))
+    stage = _Stager(dev)
+    uc = embedder(stage(torch.tensor(n_loc * [uncond_class])))
+    shape_loc = (n_loc,) + tuple(latent_shape)
+    on_device = device_exit and hasattr(ops, 'early_exit_update_ratio')
+    if on_device:
+        state = torch.tensor([-1.0, 0.0, 0.0], dtype=torch.float32)        # max_loss = -1 (prune_ldm.py:104)
+        state = stage(state) if dev.type == 'cuda' else state
+        losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=dev)
+        flag = _LaggedFlag(dev)
     losses, max_loss, accumulated = [], -1.0, 0
     with model.pin_weights():                    # the importance pass never writes weights: pack the operands once
         for t in range(num_steps):
             if draws is not None:
                 xc, x_T, noise = draws(t)
+                xc, x_T, noise = stage(xc[lo:hi]), stage(x_T[lo:hi]), stage(noise[lo:hi])
             else:
-                xc = torch.tensor(class_rng.sample(range(1000), n_samples))
-                x_T = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
-                noise = torch.randn((n_samples,) + tuple(latent_shape), generator=generator)
+                xc = stage(torch.tensor(class_rng.sample(range(1000), n_samples)[lo:hi]))
+                if generator is not None:
+                    x_T = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
+                    noise = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
+                else:
+                    x_T = ops.randn_philox(shape_loc, seed, X_T_STREAM, t, idx0=lo * per, device=dev)
+                    noise = ops.randn_philox(shape_loc, seed, NOISE_STREAM, t, idx0=lo * per, device=dev)
             c = embedder(xc)
-            samples = ddim_sample_cfg(model, schedule, x_T.to(dev), c, uc, S=ddim_steps, scale=scale)
-            tt = torch.full((n_samples,), t, dtype=torch.long, device=dev)
-            loss = step.loss(samples, tt, c, noise.to(dev))
+            samples = ddim_sample_cfg(model, schedule, x_T, c, uc, S=ddim_steps, scale=scale)
+            tt = torch.full((n_loc,), t, dtype=torch.long, device=dev)
+            if on_device:
+                loss = step.loss(samples, tt, c, noise, stop_state=state)
+                if use_dist:
+                    dist.all_reduce(loss, group=group)       # stream-ordered under RCCL: the host does not wait
+                ops.early_exit_update_ratio(loss, -1.0 if thr is None else thr, state, losses_dev)
+                step.backward(cancel_if_stopped=state)       # the breaking step (and any step enqueued after it) adds 0
+                if flag.push(state):
+                    break
+                continue
+            loss = step.loss(samples, tt, c, noise)
+            if use_dist:
+                dist.all_reduce(loss, group=group)
             lv = float(loss)                         # host sync, as `if loss > max_loss` in the reference
             losses.append(lv)
             if lv > max_loss:
                 max_loss = lv
-            if thr is not None and lv / max_loss < thr:
+            if thr is not None and np.float32(np.float32(lv) / np.float32(max_loss)) < np.float32(thr):
                 step.discard()
                 break
             step.backward()
             accumulated += 1
-    return dict(losses=losses, steps=len(losses), accumulated=accumulated, flat_grads=flat)
+    if on_device:
+        st = [float(v) for v in state.cpu()]
+        steps = int(st[2])
+        losses = [float(v) for v in losses_dev[:steps].cpu()]
+        accumulated = steps - 1 if st[1] != 0.0 else steps
+    if use_dist and reduce_grads:
+        dist.all_reduce(flat, group=group)           # the one exchange step of the pass (sum of the per-shard gradients)
+    return dict(losses=losses, steps=len(losses), accumulated=accumulated, flat_grads=flat, shard=(lo, hi),
+                global_batch=n_samples)

@@ -934,6 +934,23 @@ def early_exit_update(loss, thr, state, losses):
             'dp_early_exit_update')
 
 
+def early_exit_update_ratio(loss, thr, state, losses):
+    """The LDM script's form (prune_ldm.py:124-129): state[0] starts at -1, stop when loss / max_loss < thr (fp32 quotient)."""
+    L.check(_lib().dp_early_exit_update_ratio(_p(loss), float(thr), _p(state), _p(losses), losses.numel(), _stream()),
+            'dp_early_exit_update_ratio')
+
+
+def randn_philox(shape, seed, stream_id, step, idx0=0, device=None, out=None):
+    """Standard-normal tensor whose element i is the Philox/Box-Muller draw of logical index idx0 + i (see include/dp_hip.h):
+    a rank holding latents [lo, hi) of a global batch passes idx0 = lo * per_latent and gets its slice of the global draw."""
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=_f32, device=device)
+    assert out.is_cuda and out.is_contiguous() and out.dtype == _f32, 'randn_philox fills an fp32 device tensor'
+    L.check(_lib().dp_randn_philox(_p(out), int(idx0), out.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                   int(stream_id) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF, _stream()), 'dp_randn_philox')
+    return out
+
+
 def zero_if_stopped(x, state):
     assert x.is_contiguous()
     L.check(_lib().dp_zero_if_stopped(_p(x), x.numel(), _p(state), _stream()), 'dp_zero_if_stopped')

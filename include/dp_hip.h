@@ -112,6 +112,12 @@ typedef struct dp_dropout {
 int dp_dropout_apply(const float* x, long long x_img_stride, float* y, long long y_img_stride, int N, long long per_img,
                      const dp_dropout* drop, void* stream);
 int dp_dropout_mask(float* m, long long idx0, long long n, const dp_dropout* drop, void* stream);
+/* out[i] = standard-normal draw of logical element idx0 + i: Philox4x32-10 on counter (idx >> 2 lo, hi, stream_id, step), key
+ * seed, Box-Muller on the word pairs (see csrc/elementwise.hip).  Replaces the device-RNG draws of the LDM importance pass
+ * (ldm/models/diffusion/ddim.py:122 `torch.randn(shape, device=device)`, ddpm.py:1023 `torch.randn_like(x_start)`) with a
+ * stream that does not depend on how the latents are sharded over ranks. */
+int dp_randn_philox(float* out, long long idx0, long long n, unsigned long long seed, unsigned stream_id, unsigned step,
+                    void* stream);
 
 /* GroupNorm (+ optional SiLU) (+ optional dropout of the result, drop may be NULL) forward over a (virtually
  * concatenated) NCHW tensor.
@@ -196,6 +202,10 @@ int dp_mse_fwd_bwd(const float* out, const float* noise, long long n, float gsca
  * dp_zero_if_stopped cancels an already computed dOut (ddpm_exp flavour: threshold test before the backward pass). */
 int dp_early_exit_update(const float* loss, float thr, float* state, float* losses, int max_steps, void* stream);
 int dp_zero_if_stopped(float* x, long long n, const float* state, void* stream);
+/* The same state machine in the LDM script's form (ldm_exp/prune_ldm.py:104,124-129: `max_loss = -1` -- the caller initialises
+ * state[0] = -1 -- `if loss > max_loss: max_loss = loss; if loss / max_loss < thres: break`, the quotient rounded to fp32).
+ * thr < 0 never stops (plain Taylor pass: losses are only recorded). */
+int dp_early_exit_update_ratio(const float* loss, float thr, float* state, float* losses, int max_steps, void* stream);
 /* dst[0] = scale * sum_i partial[i]  (single block, fixed order) */
 int dp_sum_partials(const float* partial, int n, float scale, float* dst, void* stream);
 

@@ -75,3 +75,24 @@ class DropSpec:
         per = x[0].numel()
         m = dropout_multipliers(x.numel(), p, self.seed, site, self.step, self.n_off * per)
         return x * torch.from_numpy(m).view(x.shape)
+
+
+def randn(n, seed, stream_id, step, idx0=0):
+    """Restatement of csrc/elementwise.hip randn_philox_kernel: fp32 standard-normal draws of the logical elements
+    [idx0, idx0 + n): counter (idx >> 2 lo, hi, stream_id, step), key seed; u = w * 2^-32 + 2^-33 (one fp32 fma);
+    words (0, 1) and (2, 3) are Box-Muller pairs (r cos, r sin).  The device's logf / cosf / sinf differ from numpy's in the
+    last bits, so the kernel is compared to this within a few ulp of the draw, not bit for bit."""
+    idx = np.arange(idx0, idx0 + n, dtype=np.uint64)
+    q = idx >> np.uint64(2)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    w = philox4x32_10((q & _MASK).astype(np.uint32), (q >> _S32).astype(np.uint32), np.uint32(int(stream_id) & 0xFFFFFFFF),
+                      np.uint32(int(step) & 0xFFFFFFFF), seed & 0xFFFFFFFF, seed >> 32)
+
+    def u01(x):                      # fmaf(float(w), 2^-32, 2^-33): float(w) rounds to fp32 first, the fma rounds once
+        return (x.astype(np.float32).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33).astype(np.float32)
+    ra = np.sqrt(np.float32(-2.0) * np.log(u01(w[0])), dtype=np.float32)
+    rb = np.sqrt(np.float32(-2.0) * np.log(u01(w[2])), dtype=np.float32)
+    ta = np.float32(6.2831853071795865) * u01(w[1])
+    tb = np.float32(6.2831853071795865) * u01(w[3])
+    v = np.stack([ra * np.cos(ta), ra * np.sin(ta), rb * np.cos(tb), rb * np.sin(tb)], axis=-1).astype(np.float32)
+    return v[np.arange(n), (idx & np.uint64(3)).astype(np.int64)]

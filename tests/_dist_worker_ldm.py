@@ -1,0 +1,119 @@
+"""Worker for tests/test_dist_cpu.py: one rank of a gloo job running the PRODUCT's data-parallel LDM importance pass
+(diff-pruning_amd/ldm_sweep.py: latents sharded unevenly over the ranks, stream-ordered loss all-reduce, on-device early-exit
+state machine, one flat-gradient all-reduce) with the kernel wrappers replaced by CPU stand-ins."""
+import importlib
+import json
+import os
+import random
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE, os.path.join(HERE, 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import golden_common as gc   # noqa: E402
+import mock_ops              # noqa: E402
+
+
+def pkg(sub):
+    return importlib.import_module('diff-pruning_amd.' + sub)
+
+
+def patch():
+    for sub in ('engine', 'ldm', 'ldm_sweep', 'pruning', 'sweep'):
+        pkg(sub).ops = mock_ops
+    ldm = pkg('ldm')
+
+    def cpu_engine(self):
+        if self._engine is None:
+            self._engine = ldm.LdmEngine(self.config)
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        return self._engine
+    ldm.UNetModel.engine = cpu_engine
+
+
+def fresh_model(cfg, zero_prefix=None):
+    model = pkg('ldm').UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    if zero_prefix:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.startswith(zero_prefix):
+                    p.zero_()
+    return model
+
+
+def masks_of(model):
+    ldm, pruning = pkg('ldm'), pkg('pruning')
+    channel_groups = {}
+    for m in model.modules():
+        if isinstance(m, ldm.CrossAttention):
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    pr = pruning.MagnitudePruner(model, None, importance=pruning.TaylorImportance(), iterative_steps=1,
+                                 channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.out], round_to=2)
+    for g in pr.step(interactive=True):
+        g.prune()
+    return [r[3] for r in pr.records]
+
+
+def main():
+    rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    torch.set_num_threads(2)
+    patch()
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % port, rank=rank, world_size=world)
+    ldm_sweep = pkg('ldm_sweep')
+    cfg = gc.LDM_TINY_CFG
+    out = {}
+    # (1) the reference script's own run (tests/golden/ldm_driver.json: 2 latents of 3 x 64 x 64 -> shards 1 + 1): the first K
+    #     iterations, then the break case (threshold taken at t = 2, before that step's backward)
+    fx = json.load(open(os.path.join(HERE, 'golden', 'ldm_driver.json')))
+    n, S = fx['n_samples'], fx['ddim_steps']
+    emb_w = torch.from_numpy(gc.det_param('embedding.weight', (1001, cfg['context_dim']), 61))
+    embedder = ldm_sweep.ClassEmbedder(cfg['context_dim'], 1001)
+    with torch.no_grad():
+        embedder.embedding.weight.copy_(emb_w)
+    draws = [(torch.tensor(it['class_ids']), torch.from_numpy(gc.det_noise((n, 3, 64, 64), it['x_T_draw'])),
+              torch.from_numpy(gc.det_noise((n, 3, 64, 64), it['noise_draw']))) for it in fx['first']]
+    model = fresh_model(cfg)
+    res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=fx['K'], thr=fx['thr'], n_samples=n, ddim_steps=S,
+                                         scale=fx['scale'], latent_shape=(3, 64, 64), draws=lambda t: draws[t])
+    out['driver'] = dict(losses=res['losses'], steps=res['steps'], accumulated=res['accumulated'], shard=res['shard'],
+                         grad_abs_sum={k: float(p.grad.abs().sum()) for k, p in model.named_parameters()})
+    bc = fx['break_case']
+    per = fx['draws_per_iteration']
+    draws_b = []
+    for t, ids in enumerate(bc['class_ids']):
+        noise = torch.from_numpy(gc.det_noise((n, 3, 64, 64), 5000 + per * t + per - 1))
+        if 5000 + per * t + per - 1 == bc['scaled_draw']:
+            noise = noise * bc['factor']
+        draws_b.append((torch.tensor(ids), torch.from_numpy(gc.det_noise((n, 3, 64, 64), 5000 + per * t)), noise))
+    model = fresh_model(cfg, bc['zeroed_prefix'])
+    res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=10, thr=fx['thr'], n_samples=n, ddim_steps=S,
+                                         scale=fx['scale'], latent_shape=(3, 64, 64), draws=lambda t: draws_b[min(t, 2)])
+    out['break'] = dict(losses=res['losses'], steps=res['steps'], accumulated=res['accumulated'],
+                        grad_abs_sum={k: float(p.grad.abs().sum()) for k, p in model.named_parameters()})
+    # (2) uneven shards: 3 latents (2 + 1 on two ranks) of 3 x 16 x 16, the product's default draws (class ids from
+    #     random.Random, x_T / noise from the Philox stream keyed by the GLOBAL element index), early exit at a threshold the
+    #     run crosses; then the 109-group prune from the reduced gradients
+    emb16 = ldm_sweep.ClassEmbedder(cfg['context_dim'], 1001)
+    with torch.no_grad():
+        emb16.embedding.weight.copy_(emb_w)
+    model = fresh_model(cfg)
+    res = ldm_sweep.ldm_importance_sweep(model, emb16, num_steps=12, thr=float(sys.argv[5]), n_samples=3, ddim_steps=2,
+                                         latent_shape=(3, 16, 16), class_rng=random.Random(3), seed=11)
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    out['uneven'] = dict(losses=res['losses'], steps=res['steps'], accumulated=res['accumulated'], shard=res['shard'],
+                         grads=grads, masks=masks_of(model))
+    torch.save(out, os.path.join(outdir, 'ldm_r%d_w%d.pt' % (rank, world)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -305,7 +305,51 @@ def add_noise(x0, noise, acp, t, out=None):
 
 def mse_fwd_bwd(out, noise, gscale, loss_scale, want_grad=True, stop_state=None):
     d = out - noise
+    if stop_state is not None and float(stop_state[1]) != 0.0:      # dp_mse_fwd_bwd: dOut = 0 once the sweep has stopped
+        gscale = 0.0
     return (loss_scale * d.square().sum()).reshape(1), (gscale * d if want_grad else None)
+
+
+def _early_exit(loss, thr, state, losses, ratio):
+    """early_exit_update_kernel / early_exit_update_ratio_kernel of csrc/elementwise.hip, in fp32."""
+    import numpy as np
+    if float(state[1]) != 0.0:
+        return
+    l = np.float32(float(loss.reshape(-1)[0]))
+    k = int(state[2])
+    if k < losses.numel():
+        losses[k] = float(l)
+    state[2] = float(k + 1)
+    mx = np.float32(float(state[0]))
+    if l > mx:
+        mx = l
+    state[0] = float(mx)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        stop = (np.float32(l / mx) < np.float32(thr)) if ratio else (l < np.float32(mx * np.float32(thr)))
+    if stop:
+        state[1] = 1.0
+
+
+def early_exit_update(loss, thr, state, losses):
+    _early_exit(loss, thr, state, losses, False)
+
+
+def early_exit_update_ratio(loss, thr, state, losses):
+    _early_exit(loss, thr, state, losses, True)
+
+
+def zero_if_stopped(x, state):
+    if float(state[1]) != 0.0:
+        x.zero_()
+    return x
+
+
+def randn_philox(shape, seed, stream_id, step, idx0=0, device=None, out=None):
+    from oracle import philox_ref
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return torch.from_numpy(philox_ref.randn(n, seed, stream_id, step, idx0)).view(tuple(shape))
 
 
 def downsum2x2(dy, out=None):

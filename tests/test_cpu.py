@@ -1468,14 +1468,23 @@ def test_ldm_driver_loop_matches_the_reference_script(mocked, monkeypatch):
         for pn, pp in model_b.named_parameters():
             if pn.startswith(bc['zeroed_prefix']):
                 pp.zero_()
-    res = ldm_sweep.ldm_importance_sweep(model_b, embedder, num_steps=10, thr=fx['thr'], n_samples=n, ddim_steps=S, scale=fx['scale'],
-                                         latent_shape=(3, 64, 64), draws=lambda t: draws_b[t])
-    assert res['steps'] == 3 and res['accumulated'] == 2
-    assert np.allclose(res['losses'], bc['printed_losses'] + [bc['breaking_loss']], rtol=2e-5)
-    got = dict(model_b.named_parameters())
-    for name, p_ in got.items():
-        want = bc['grad_abs_sum'].get(name, 0.0)
-        assert abs(float(p_.grad.abs().sum()) - want) < 1e-3 * want + 1e-6, name
+    # device_exit=True: the max-loss / threshold state machine of dp_early_exit_update_ratio (mocked), the breaking step's dOut
+    # cancelled, the host reading the flag one step late -- so ONE more step is enqueued after the break (it re-uses the last
+    # draws here) and must leave losses, step count and gradients untouched.  device_exit=False: the script's host-side test.
+    for device_exit in (True, False):
+        for p_ in model_b.parameters():
+            p_.grad = None
+        asked = []
+        res = ldm_sweep.ldm_importance_sweep(model_b, embedder, num_steps=10, thr=fx['thr'], n_samples=n, ddim_steps=S,
+                                             scale=fx['scale'], latent_shape=(3, 64, 64), device_exit=device_exit,
+                                             draws=lambda t: (asked.append(t), draws_b[min(t, 2)])[1])
+        assert asked == ([0, 1, 2, 3] if device_exit else [0, 1, 2])
+        assert res['steps'] == 3 and res['accumulated'] == 2
+        assert np.allclose(res['losses'], bc['printed_losses'] + [bc['breaking_loss']], rtol=2e-5)
+        got = dict(model_b.named_parameters())
+        for name, p_ in got.items():
+            want = bc['grad_abs_sum'].get(name, 0.0)
+            assert abs(float(p_.grad.abs().sum()) - want) < 1e-3 * want + 1e-6, name
 
 
 def test_fixture_sweep_loop_is_the_reference_scripts_loop():

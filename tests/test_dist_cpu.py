@@ -50,3 +50,53 @@ def test_two_rank_sweep_equals_single_process(tmp_path):
     for n, p in one['ft_params'].items():
         assert torch.equal(r0['ft_params'][n], r1['ft_params'][n])
         assert float((r0['ft_params'][n] - p).abs().max()) <= 2e-4 * float(p.abs().max()) + 1e-7, n
+
+
+def _run_ldm(world, outdir, thr):
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_dist_worker_ldm.py'), str(r), str(world), port, outdir,
+                               str(thr)]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+
+
+def test_two_rank_ldm_importance_pass_equals_single_process(tmp_path):
+    """Config C5's data-parallel form: the latents of a step sharded over two ranks -- 1 + 1 on the reference
+    script's own recorded run (tests/golden/ldm_driver.json: losses, gradients after K backward passes, the break before the
+    backward at t = 2), 2 + 1 on a 3-latent run with the default Philox draws -- give the losses, the stop step, the
+    accumulated gradients and the 109 prune masks of one process."""
+    import json
+    out = str(tmp_path)
+    _run_ldm(1, out, 0.97)
+    _run_ldm(2, out, 0.97)
+    one = torch.load(os.path.join(out, 'ldm_r0_w1.pt'))
+    r0 = torch.load(os.path.join(out, 'ldm_r0_w2.pt'))
+    r1 = torch.load(os.path.join(out, 'ldm_r1_w2.pt'))
+    fx = json.load(open(os.path.join(HERE, 'golden', 'ldm_driver.json')))
+    # (1) against the script's recorded run
+    assert tuple(r0['driver']['shard']) == (0, 1) and tuple(r1['driver']['shard']) == (1, 2)
+    for r in (one, r0, r1):
+        d = r['driver']
+        assert d['steps'] == d['accumulated'] == fx['K']
+        assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(d['losses'], fx['losses'][:fx['K']]))
+        for name, want in fx['grad_abs_sum_after_K'].items():
+            assert abs(d['grad_abs_sum'][name] - want) < 1e-3 * want + 1e-6, name
+        b, bc = r['break'], fx['break_case']
+        assert b['steps'] == 3 and b['accumulated'] == 2
+        assert all(abs(a - w) <= 2e-5 * abs(w) for a, w in zip(b['losses'], bc['printed_losses'] + [bc['breaking_loss']]))
+        for name, got in b['grad_abs_sum'].items():
+            want = bc['grad_abs_sum'].get(name, 0.0)
+            assert abs(got - want) < 1e-3 * want + 1e-6, name
+    assert r0['driver']['losses'] == r1['driver']['losses']
+    # (2) uneven shards, default draws, early exit
+    u1, a, b = one['uneven'], r0['uneven'], r1['uneven']
+    assert tuple(a['shard']) == (0, 2) and tuple(b['shard']) == (2, 3) and tuple(u1['shard']) == (0, 3)
+    assert a['steps'] == b['steps'] == u1['steps'] == 3 and a['accumulated'] == b['accumulated'] == u1['accumulated'] == 2
+    for x, y, z in zip(u1['losses'], a['losses'], b['losses']):
+        assert abs(x - y) <= 1e-5 * abs(x) and y == z
+    for n, g in u1['grads'].items():
+        assert torch.equal(a['grads'][n], b['grads'][n])                    # all-reduced: identical on both ranks
+        scale = float(g.abs().max())
+        if scale > 1e-7:
+            assert float((a['grads'][n] - g).abs().max()) <= 5e-5 * scale, n
+    assert len(u1['masks']) == 109 and a['masks'] == b['masks'] == u1['masks']

@@ -812,3 +812,51 @@ def test_upsample_conv_subpixel_primitives_and_composite(ops, report, shape):
              dgrad=relerr(dx, xr.grad), wgrad=relerr(gw, gw0.double().cpu() + wr.grad))
     report['ups_subpixel/%s' % (shape,)] = e
     assert max(e.values()) < 2e-5, e
+
+
+def test_randn_philox_matches_oracle_and_is_shard_invariant(ops, report):
+    """dp_randn_philox (x_T and the loss noise of the LDM importance pass) against oracle/philox_ref.randn: the same Philox
+    words and Box-Muller pairing (device logf / cosf / sinf vs numpy: a few ulp of the draw), a window that starts at an odd
+    offset beyond 2^32 elements, and any shard of a draw BIT-equal to that slice of the whole draw."""
+    from oracle import philox_ref as PH
+    worst, stats = 0.0, None
+    for seed, sid, step, idx0, n in ((21, 0x7854, 0, 0, 1 << 20), ((1 << 62) + 5, 3, 999, (1 << 34) + 3, 4099),
+                                     (0, 0, 0, 2, 7)):
+        got = ops.randn_philox((n,), seed, sid, step, idx0=idx0, device=DEV).cpu().numpy()
+        want = PH.randn(n, seed, sid, step, idx0)
+        worst = max(worst, float(np.abs(got - want).max()))
+        if stats is None:
+            stats = dict(mean=float(got.mean()), std=float(got.std()), kurt=float((got ** 4).mean()), absmax=float(np.abs(got).max()))
+    whole = ops.randn_philox((6, 3, 64, 64), 21, 1, 5, device=DEV)
+    per = 3 * 64 * 64
+    n_bad = 0
+    for lo, hi in ((0, 2), (2, 4), (4, 5), (5, 6), (1, 6)):
+        part = ops.randn_philox((hi - lo, 3, 64, 64), 21, 1, 5, idx0=lo * per, device=DEV)
+        n_bad += int((part != whole[lo:hi]).sum())
+    odd = ops.randn_philox((1001,), 21, 1, 5, idx0=4099, device=DEV)             # unaligned start and end
+    n_bad += int((odd != whole.reshape(-1)[4099:5100]).sum())
+    report['randn_philox'] = dict(abs_worst=worst, shard_mismatches=n_bad, **stats)
+    assert worst < 5e-6 and n_bad == 0                     # |draw| <= 6.8; 5e-6 absolute ~ a few fp32 ulp of the largest draws
+    assert abs(stats['mean']) < 5e-3 and abs(stats['std'] - 1) < 5e-3 and abs(stats['kurt'] - 3) < 0.05
+
+
+def test_early_exit_ratio_state_machine(ops):
+    """dp_early_exit_update_ratio = prune_ldm.py:104,124-129 (`max_loss = -1; if loss > max_loss: max_loss = loss; if loss /
+    max_loss < thres: break`) on a loss sequence, against the same lines evaluated on fp32 0-d tensors on the host."""
+    seq = [0.5, 0.8, 0.3, 0.081, 0.0799999, 0.5, 0.01]
+    for thr in (0.1, -1.0):
+        state = torch.tensor([-1.0, 0.0, 0.0], device=DEV)
+        rec = torch.zeros(16, device=DEV)
+        for l in seq:
+            ops.early_exit_update_ratio(torch.tensor([l], device=DEV), thr, state, rec)
+        mx, want = torch.tensor(-1.0), []
+        for l in seq:
+            lt = torch.tensor(l, dtype=torch.float32)
+            want.append(float(lt))
+            if lt > mx:
+                mx = lt
+            if thr >= 0 and bool(lt / mx < thr):
+                break
+        st = state.cpu().tolist()
+        assert int(st[2]) == len(want) and rec[:len(want)].cpu().tolist() == want and float(mx) == st[0]
+        assert st[1] == (1.0 if len(want) < len(seq) else 0.0)
