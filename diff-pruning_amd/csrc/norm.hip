@@ -727,12 +727,18 @@ __global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumBatch b) 
 }
 
 extern "C" int dp_colsum_accum_batch(const dp_colsum_item* items, int n, void* stream) {
-    for (int lo = 0; lo < n; lo += DP_COLSUM_BATCH) {
+    // Two items of ONE launch must not share a destination: different workgroups would read-modify-write it unordered.
+    // A repeated destination therefore closes the launch (launches are stream-ordered, so the sums stay deterministic).
+    int i = 0;
+    while (i < n) {
         ColsumBatch b;
         b.n = 0;
         int blocks = 0;
-        for (int i = lo; i < n && b.n < DP_COLSUM_BATCH; ++i) {
+        for (; i < n && b.n < DP_COLSUM_BATCH; ++i) {          // `i` is the consumed index: empty items do not shift the window
             if (items[i].C <= 0) continue;
+            bool dup = false;
+            for (int j = 0; j < b.n && !dup; ++j) dup = (b.e[j].dst == items[i].dst);
+            if (dup) break;
             b.blk_start[b.n] = blocks;
             b.e[b.n] = items[i];
             blocks += (items[i].C + 63) / 64;

@@ -1,7 +1,8 @@
 """Data input pipeline: the datasets and transforms of the reference's training scripts with the
 per-pixel work on the device.
 
-  utils.py:8-24      UnlabeledImageFolder           -> UnlabeledImageFolder (same file discovery: recursive glob per extension)
+  utils.py:8-24      UnlabeledImageFolder           -> UnlabeledImageFolder (recursive glob per extension; see the class for the
+                     one deliberate deviation from the reference's pattern)
   utils.py:31-58     get_dataset: CIFAR-10 = RandomHorizontalFlip + ToTensor + Normalize(0.5, 0.5);
                      image folders = Resize(256) + RandomCrop(256) + the same three
   ddpm_exp/datasets/__init__.py:30-60,176-192   Resize + flip + ToTensor, then data_transform (uniform dequantization, 2x - 1)
@@ -33,8 +34,14 @@ class UnlabeledImageFolder:
     def __init__(self, root, transform=None, exts=("*.jpg", "*.png", "*.jpeg", "*.webp")):
         self.root, self.transform = root, transform
         self.files = []
-        for ext in exts:      # the reference formats '**/*.{}'.format("*.jpg") -> '**/*.*.jpg'; kept: same files found
-            self.files.extend(glob.glob(os.path.join(root, '**/*.{}'.format(ext)), recursive=True))
+        # The reference formats '**/*.{}'.format("*.jpg") -> '**/*.*.jpg' (utils.py:16), which only matches names with TWO
+        # dots ("a.b.jpg"): on an ordinary folder it finds nothing and training silently iterates zero batches.  Deliberate
+        # deviation: '**/' + ext finds every file with the extension (a superset of the reference's matches), in sorted order
+        # per extension so that every rank of a data-parallel run indexes the same list; an empty folder is an error.
+        for ext in exts:
+            self.files.extend(sorted(glob.glob(os.path.join(root, '**', ext), recursive=True)))
+        if not self.files:
+            raise FileNotFoundError('no image files (%s) under %r' % (', '.join(exts), root))
 
     def __len__(self):
         return len(self.files)
@@ -99,11 +106,17 @@ def epoch_permutation(n, seed, epoch):
     return np.random.default_rng([int(seed) & 0xFFFFFFFF, int(epoch)]).permutation(n)
 
 
-def crop_offsets(n_off, count, max_y, max_x, seed, epoch):
-    """RandomCrop offsets of global samples n_off .. n_off+count-1 (a function of the sample index, not of the draw order)."""
-    r = np.random.default_rng([int(seed) & 0xFFFFFFFF, int(epoch), 0xC0])
-    ys = r.integers(0, max_y + 1, size=n_off + count)[n_off:] if max_y > 0 else np.zeros(count, dtype=np.int64)
-    xs = r.integers(0, max_x + 1, size=n_off + count)[n_off:] if max_x > 0 else np.zeros(count, dtype=np.int64)
+def crop_offsets(indices, heights, widths, crop, seed, epoch):
+    """RandomCrop(crop) offsets, drawn PER IMAGE from that image's own size as torchvision does (`RandomCrop.get_params`:
+    i in [0, h - crop], j in [0, w - crop]) -- after Resize(256) on the shorter side a folder holds 256 x 341 and 341 x 256
+    images side by side.  Counter-based: sample `g` (global index within the epoch) always gets the same pair, whichever rank
+    or batch asks, and a batch costs O(batch) draws."""
+    ys, xs = np.zeros(len(indices), dtype=np.int64), np.zeros(len(indices), dtype=np.int64)
+    for k, (g, h, w) in enumerate(zip(indices, heights, widths)):
+        if h < crop or w < crop:
+            raise ValueError('RandomCrop(%d) on a %d x %d image' % (crop, h, w))
+        u = np.random.default_rng([int(seed) & 0xFFFFFFFF, int(epoch), 0xC0, int(g)]).random(2)
+        ys[k], xs[k] = int(u[0] * (h - crop + 1)), int(u[1] * (w - crop + 1))
     return ys, xs
 
 
@@ -164,8 +177,8 @@ class DeviceLoader:
                 return
             items = [self.ds[int(i)] for i in idx]
             if self.crop is not None:                                   # transforms.RandomCrop(crop) on HWC arrays
-                ys, xs = crop_offsets(lo, len(items), items[0].shape[0] - self.crop, items[0].shape[1] - self.crop,
-                                      self.seed, self.epoch)
+                ys, xs = crop_offsets(range(lo, lo + len(items)), [it.shape[0] for it in items], [it.shape[1] for it in items],
+                                      self.crop, self.seed, self.epoch)
                 items = [it[y:y + self.crop, x:x + self.crop] for it, y, x in zip(items, ys, xs)]
             yield to_device_batch(np.stack(items), hwc, self.device, self.mode, self.flip_p, self.seed, self.epoch, lo,
                                   self.dequant)

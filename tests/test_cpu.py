@@ -1232,13 +1232,34 @@ def test_data_pipeline_host_logic(tmp_path, monkeypatch):
     for i in range(6):
         a = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
         imgs.append(a)
-        Image.fromarray(a).save(str(root / ('sub' if i % 2 else '.') / ('im%d.x.png' % i)))       # name.*.png, see utils.py:14
+        # ordinary names AND the two-dot names that are all the reference's '**/*.*.png' pattern (utils.py:16) can match
+        Image.fromarray(a).save(str(root / ('sub' if i % 2 else '.') / ('im%d%s.png' % (i, '.x' if i < 3 else ''))))
     ds = data.UnlabeledImageFolder(str(root), exts=('*.png',))
     assert len(ds) == 6 and ds[0].dtype == np.uint8 and ds[0].shape == (20, 24, 3)
     got = sorted(ds[i].tobytes() for i in range(6))
     assert got == sorted(a.tobytes() for a in imgs)                    # lossless PNG round trip, every file found once
     ds2 = data.UnlabeledImageFolder(str(root), transform=data.resize_shorter_side(10), exts=('*.png',))
     assert ds2[0].shape == (10, 12, 3)
+    (tmp_path / 'empty').mkdir()
+    with pytest.raises(FileNotFoundError):
+        data.UnlabeledImageFolder(str(tmp_path / 'empty'))
+    # RandomCrop offsets come from each image's OWN size (landscape and portrait images in one batch, utils.py:52-53 after
+    # Resize on the shorter side), are functions of the global sample index, and cover the whole admissible range
+    mixed = data.ArrayDataset(np.zeros((1, 1, 1, 3), dtype=np.uint8))
+    shapes = [(16, 21), (21, 16), (16, 16), (30, 16)] * 8
+    mixed.__class__ = type('Mixed', (data.ArrayDataset,), {'__len__': lambda self: len(shapes), '__getitem__': lambda self, i: (
+        np.arange(shapes[i][0] * shapes[i][1] * 3, dtype=np.int64).reshape(shapes[i] + (3,)) % 251).astype(np.uint8)})
+    seen = []
+    monkeypatch.setattr(data, 'to_device_batch', lambda u8, *a, **k: (seen.append(u8), torch.zeros(1))[1])
+    list(data.DeviceLoader(mixed, 8, 'cpu', shuffle=False, seed=3, crop=16))
+    assert [b.shape for b in seen] == [(8, 16, 16, 3)] * 4
+    ys, xs = data.crop_offsets(range(32), [h for h, w in shapes], [w for h, w in shapes], 16, 3, 0)
+    assert all(0 <= y <= h - 16 and 0 <= x <= w - 16 for y, x, (h, w) in zip(ys, xs, shapes))
+    assert max(ys[3::4]) > 7 and max(xs[0::4]) >= 4 and set(ys[0::4]) == {0} and set(xs[1::4]) == {0}
+    y2, x2 = data.crop_offsets(range(8, 16), [h for h, w in shapes[8:16]], [w for h, w in shapes[8:16]], 16, 3, 0)
+    assert list(y2) == list(ys[8:16]) and list(x2) == list(xs[8:16])          # a function of the sample, not of the batch
+    crop0 = seen[0][3]                                                         # sample 3: 30 x 16 portrait
+    assert np.array_equal(crop0, mixed[3][ys[3]:ys[3] + 16, xs[3]:xs[3] + 16])
     # CIFAR-10 python batches
     base = tmp_path / 'c10' / 'cifar-10-batches-py'
     base.mkdir(parents=True)

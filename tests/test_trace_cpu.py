@@ -240,3 +240,88 @@ def test_trace_entry_points_dict_inputs_forward_fn_and_output_transform():
     assert len(list(pruning.DependencyGraph(frozen, inputs2).get_all_groups([frozen.fc2]))) == 3
     assert not any(p.requires_grad for p in frozen.parameters())
     assert trace.TracedGraph(frozen, inputs2).layers.keys() == {'conv1', 'bn1', 'conv2', 'bn2', 'fc1', 'fc2'}
+
+
+# ---- round 3: the advisor's counter-examples (silently wrong groups in round 2) ---------------------------------------
+class _Conv1dCat(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c = nn.Conv1d(3, 4, 3, padding=1), nn.Conv1d(3, 6, 3, padding=1), nn.Conv1d(10, 5, 3, padding=1)
+
+    def forward(self, x):
+        return self.c(torch.relu(torch.cat([self.a(x), self.b(x)], dim=1)))
+
+
+class _Conv3dFlatten(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv, self.fc = nn.Conv3d(2, 4, 3, padding=1), nn.Linear(4 * 2 * 2 * 2, 3)
+
+    def forward(self, x):
+        return self.fc(torch.relu(self.conv(x)).flatten(1))
+
+
+class _UntrackedCat(nn.Module):
+    """cat([timestep-derived map (integer input: no grad_fn), conv_a(x), cond * 2 (derived from a model input)]) -> conv_c"""
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.c = nn.Conv2d(3, 4, 3, padding=1), nn.Conv2d(2 + 4 + 3, 5, 3, padding=1)
+
+    def forward(self, x, t, cond):
+        tm = t.float()[:, None, None, None].expand(-1, 2, x.shape[2], x.shape[3])
+        return self.c(torch.cat([tm, torch.relu(self.a(x)), cond * 2], dim=1))
+
+
+def _group(model, inputs, layer, idxs):
+    dg = pkg('pruning').DependencyGraph(model, inputs)
+    g = dg.get_pruning_group(layer, None, idxs)
+    return g, {d.target.name + ':' + d.kind: i for d, i in g}
+
+
+def test_conv1d_concatenation_and_conv3d_flatten():
+    """3-D tensors from Conv1d are [N, C, L]: cat(dim=1) is a channel concatenation (offset 4 for the second producer), and a
+    Conv3d feature map flattened in front of a Linear maps channel c to the 8 features c*8 .. c*8+7.  Pruned models run."""
+    m = _Conv1dCat().eval()
+    x = torch.randn(2, 3, 7)
+    g, got = _group(m, (x,), m.b, [0, 1])
+    assert got == {'b:out': [0, 1], 'c:in': [4, 5]}
+    g.prune()
+    assert m(x).shape == (2, 5, 7) and m.c.in_channels == 8
+    _, got = _group(m, (x,), m.a, [3])
+    assert got == {'a:out': [3], 'c:in': [3]}
+    m3 = _Conv3dFlatten().eval()
+    x3 = torch.randn(2, 2, 2, 2, 2)
+    g, got = _group(m3, (x3,), m3.conv, [1])
+    assert got == {'conv:out': [1], 'fc:in': list(range(8, 16))}
+    g.prune()
+    assert m3(x3).shape == (2, 3) and m3.fc.in_features == 24
+
+
+def test_untracked_and_input_derived_cat_inputs_keep_their_slots():
+    """A cat input without a grad_fn (integer-derived map) and one derived from a model input both keep their channel slots:
+    pruning a.out[0] removes c.in[2] (behind the 2-channel map), not c.in[0]; zeroing == pruning."""
+    m = _UntrackedCat().eval()
+    x, t, cond = torch.randn(2, 3, 6, 6), torch.tensor([3, 500]), torch.randn(2, 3, 6, 6)
+    ref = copy.deepcopy(m)
+    g, got = _group(m, (x, t, cond), m.a, [0, 3])
+    assert got == {'a:out': [0, 3], 'c:in': [2, 5]}
+    with torch.no_grad():
+        ref.a.weight[[0, 3]] = 0
+        ref.a.bias[[0, 3]] = 0
+        want = ref(x, t, cond)
+        g.prune()
+        assert torch.allclose(m(x, t, cond), want, atol=1e-6)
+    assert m.c.in_channels == 7
+
+
+def test_ambiguous_3d_concatenation_raises():
+    class Bad(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = nn.Conv1d(6, 4, 1)
+
+        def forward(self, x, y):
+            return self.c(torch.cat([x * 2, y * 3], dim=1))         # no leaf module in front: [N, C, L] or [B, T, C]?
+    with pytest.raises(NotImplementedError):
+        pkg('pruning').DependencyGraph(Bad(), (torch.randn(2, 3, 5), torch.randn(2, 3, 5)))
