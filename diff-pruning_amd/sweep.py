@@ -202,7 +202,7 @@ def _f32_lt_prod(loss, loss_max, thr):
 
 def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None, loss_kind='mse', group=None,
                  step_fn=None, flat_grads=None, reduce_grads=True, use_graph=None, micro_batch=None,
-                 accumulate_breaking_step=True, device_exit=True, poll_every=8):
+                 accumulate_breaking_step=True, device_exit=True, poll_every=8, timings=None):
     """Runs the sweep; returns dict(losses=[python floats of the GLOBAL loss per executed step], steps=int).
 
     thr=None: plain Taylor.  thr=x: Diff-Pruning early exit.  accumulate_breaking_step=True is ddpm_prune.py:102-106
@@ -218,8 +218,12 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     slower than eager launches at every batch size on this stack -- C1-size model, batch 4, 200 timesteps: 24-26 ms per step
     replayed vs 14.7 eager (tools/bench_c1_long.py); batch 256: +3 % -- the ~750-node graph launch costs more host time than
     the ctypes launches it replaces.  None = False unless DP_GRAPH=auto (shards of <= GRAPH_AUTO_PIXELS pixels swept for
-    >= GRAPH_AUTO_STEPS timesteps).  Kept for runtimes where graph launch is cheap."""
+    >= GRAPH_AUTO_STEPS timesteps).  Kept for runtimes where graph launch is cheap.
+    timings: a dict that receives host wall-clock marks (bench.py): 'enqueue_s' (all timesteps enqueued), 'sweep_s' (device
+    done with them) and 'allreduce_s' (the gradient exchange alone; only then is the exchange followed by a device sync)."""
+    import time
     import torch.distributed as dist
+    t_start = time.perf_counter()
     use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     B_local = clean_images.shape[0]
     per_img = clean_images[0].numel()
@@ -309,6 +313,8 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
                 break
         else:
             pending.append(l)
+    if timings is not None:
+        timings['enqueue_s'] = time.perf_counter() - t_start
     if hasattr(step_fn, 'finish'):
         step_fn.finish()
     if pending:
@@ -316,8 +322,14 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         if use_dist:
             dist.all_reduce(stacked, group=group)
         losses = [float(v) for v in stacked.cpu()]
+    if timings is not None:
+        torch.cuda.synchronize()
+        timings['sweep_s'] = time.perf_counter() - t_start
     if use_dist and reduce_grads and flat_grads is not None:
         dist.all_reduce(flat_grads, group=group)      # the one exchange step of the sweep (sum of per-shard grads)
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings['allreduce_s'] = time.perf_counter() - t_start - timings['sweep_s']
     return dict(losses=losses, steps=steps, global_batch=B_global)
 
 
