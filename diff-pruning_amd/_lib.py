@@ -119,6 +119,10 @@ SIGNATURES = {
     'dp_ssim': [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     'dp_ssim_workspace': [_i, _i, _i, _i],
     'dp_mse_per_image': [_vp, _vp, _i, _ll, _vp, _vp],
+    'dp_replay_build': [_vp, C.POINTER(C.c_void_p)],
+    'dp_replay_launch': [_vp, _vp, _vp],
+    'dp_replay_info': [_vp, C.POINTER(C.c_int)],
+    'dp_replay_free': [_vp],
     'dp_version': [],
     'dp_launch_count': [],
 }

@@ -308,6 +308,13 @@ class UNetEngine:
                 t.record_stream(self._side)
         return self._side
 
+    def replay_side_stream(self, device):
+        """Second stream for the native replay of a captured step (ops.ReplayList): the forked chains of the capture alternate
+        between the two replay streams, so it has the same priority as the main one."""
+        if getattr(self, '_replay_side', None) is None or self._replay_side.device != torch.device(device):
+            self._replay_side = torch.cuda.Stream(device=device)
+        return self._replay_side
+
     def _join_side(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)

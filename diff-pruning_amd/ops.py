@@ -1107,3 +1107,31 @@ def cfg_combine(e_uncond, e_cond, scale, out=None):
     L.check(_lib().dp_cfg_combine(_p(e_uncond), _p(e_cond), float(scale), _p(out), e_cond.numel(), _stream()),
             'dp_cfg_combine')
     return out
+
+
+class ReplayList:
+    """Native replay of a captured step (include/dp_hip.h dp_replay_*): `graph` is a torch.cuda.CUDAGraph built with
+    keep_graph=True and already captured; it is kept alive here (the kernel arguments live in it) and never instantiated."""
+
+    def __init__(self, graph):
+        self.graph = graph
+        h = C.c_void_p()
+        L.check(_lib().dp_replay_build(C.c_void_p(graph.raw_cuda_graph()), C.byref(h)), 'dp_replay_build')
+        self.handle = h
+        info = (C.c_int * 8)()
+        L.check(_lib().dp_replay_info(self.handle, info), 'dp_replay_info')
+        self.info = dict(zip(('nodes', 'kernels', 'memsets', 'memcpys', 'empty', 'cross_stream_waits', 'side_nodes', 'events'),
+                             [int(v) for v in info]))
+
+    def launch(self, side_stream):
+        """Re-issue the step on torch's current stream (+ `side_stream` for the forked chains: a torch stream or None)."""
+        side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else _stream()
+        L.check(_lib().dp_replay_launch(self.handle, _stream(), side), 'dp_replay_launch')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib().dp_replay_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -42,6 +42,7 @@ class HipSweepStep:
     per-image loss scaling is the global one, so the result is the same sum) -- for shards whose activations would
     exceed the 2 GiB-per-tensor limit of the buffer descriptors (e.g. 256x256 images at batch >= 64 per GPU)."""
     _graph = None
+    _replay = None
     micro = None
     _half = None
     stop_state = None          # device [loss_max, stopped, steps] of the on-device Diff-Pruning early exit (taylor_sweep)
@@ -165,9 +166,14 @@ class HipSweepStep:
         self.eng.ctx = None
         self._dout = None
 
-    def capture(self):
-        """Record one timestep (~900 kernel launches) into a hipGraph; afterwards every step is: write t, replay.
-        Removes the ~60 ms of Python/ctypes launch overhead per step -- the launch-bound regime at small batch."""
+    def capture(self, native=None):
+        """Record one timestep (~700 kernel launches) into a hipGraph; afterwards every step is: write t, replay.
+        Removes the ~60 ms of Python/ctypes launch overhead per step -- the launch-bound regime at small batch.
+        native (default: True unless DP_REPLAY=graph): the captured graph is not instantiated; its nodes are read back and
+        re-issued from the library's C loop (csrc/replay.hip: dp_replay_build / dp_replay_launch) -- hipGraphLaunch itself costs
+        more host time than the eager launches on this stack."""
+        if native is None:
+            native = os.environ.get('DP_REPLAY', 'native') != 'graph'
         self.eng.prepare_packs()
         ops._workspace(1 << 26, self.clean.device)          # split-K workspace must exist before capture
         self._t = torch.zeros(self.B, dtype=torch.long, device=self.clean.device)
@@ -179,16 +185,22 @@ class HipSweepStep:
         self._step(self._t)
         self.stop_state = real_state
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if native else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._loss = self._step(self._t)
         self._graph = g
+        self._replay = None
+        if native:
+            self._replay = ops.ReplayList(g)               # raises when the graph holds a node it cannot re-issue
         return self
 
     def __call__(self, k):
         if self._graph is not None:
             self._t.fill_(int(k))
-            self._graph.replay()
+            if self._replay is not None:
+                self._replay.launch(self.eng.replay_side_stream(self.clean.device))
+            else:
+                self._graph.replay()
             return self._loss.clone()
         t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
         return self._step(t)          # [1] device tensor: this rank's share of L_t

@@ -312,6 +312,17 @@ int dp_mse_per_image(const float* a, const float* b, int N, long long per, float
 int dp_u8_to_float(const unsigned char* src, int hwc, int N, int C, int H, int W, float* out, long long out_img_stride,
                    int mode, unsigned flip_thr24, int dequant, const dp_dropout* rng, void* stream);
 
+/* Native replay list (csrc/replay.hip): re-issue the kernels / memsets of a stream-captured step from a C loop.  The
+ * reference's loop re-launches ~700 ATen kernels per timestep from Python (ddpm_prune.py:94-106); here one timestep is captured
+ * once into a hipGraph (never instantiated: hipGraphLaunch of these graphs costs more host time than eager launches on this
+ * stack), its nodes are read back, list-scheduled onto two streams along the captured dependency edges, and
+ * dp_replay_launch re-issues them with hipLaunchKernel.  `graph`: hipGraph_t; it must outlive the list.
+ * info[8] = nodes, kernels, memsets, memcpys, empty nodes, cross-stream waits, nodes on the side stream, events. */
+int dp_replay_build(void* graph, void** out_handle);
+int dp_replay_launch(void* handle, void* main_stream, void* side_stream);
+int dp_replay_info(void* handle, int* info8);
+int dp_replay_free(void* handle);
+
 int dp_version(void);
 /* Number of kernel launches this library has issued since it was loaded (host counter; bench.py reports launches per step).
  * Returned in place of an error code. */
