@@ -188,7 +188,7 @@ class SweepWorkload:
                            'host_enqueue_ms_per_step': tm['enqueue_s'] / res['steps'] * 1e3,
                            'kernel_launches_per_step': launches / res['steps'],
                            'grad_allreduce_ms': tm.get('allreduce_s', 0.0) * 1e3,
-                           'wgrad_stream_overlap': bool(self.step.eng.overlap_wgrad), 'hipgraph': bool(self.env.args.graph),
+                           'wgrad_stream_overlap': bool(self.step.eng._overlap_now), 'hipgraph': bool(self.env.args.graph),
                            'diff_pruning_threshold': self.thr,
                            'pruned_groups': len(pr.records), 'params_after': sum(p.numel() for p in self.model.parameters()),
                            'loss_first_last': [res['losses'][0], res['losses'][-1]]})

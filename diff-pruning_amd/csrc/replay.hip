@@ -13,6 +13,7 @@
 // The graph object must outlive the replay list (kernel argument storage belongs to the graph).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -102,6 +103,7 @@ extern "C" int dp_replay_build(void* graph_v, void** out) {
         // kernel of the forked work continued the tail, the original chain goes on beside it)
         stream_of.assign(n, 0);
         pos_in_order.assign(n, 0);
+        const bool one_stream = getenv("DP_REPLAY_ONE_STREAM") != nullptr;     // experiment: capture order on one stream
         int tail[2] = {-1, -1};
         std::vector<int> ev_of(n, -1);
         int synced[2][2] = {{-1, -1}, {-1, -1}};      // synced[s][t]: stream s has waited for stream t's nodes up to this order position
@@ -115,6 +117,7 @@ extern "C" int dp_replay_build(void* graph_v, void** out) {
                 if (tail[ds] == d && (s < 0 || ds < s)) s = ds;
             }
             if (s < 0) s = deps[i].empty() ? 0 : (stream_of[deps[i][0]] ^ 1);
+            if (one_stream) s = 0;
             stream_of[i] = s;
             RNode& r = rp->nodes[oi];
             r.stream = s;

@@ -24,6 +24,7 @@ UPS_COPY = not os.environ.get('DP_NO_UPS_COPY')
 UPS_SUBPIXEL = not os.environ.get('DP_NO_UPS_SUBPIXEL')      # upsample convolutions as four 2x2 convolutions at low resolution
 _UPS_SPECS = ops.UPS_CLASS_SPECS
 S2_PARITY = not os.environ.get('DP_NO_S2_PARITY')
+OVERLAP_MIN_WORK = 4_000_000     # images x pixels x base width from which the weight-gradient side stream pays (UNetEngine.__init__)
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
 RES_DIFFUSERS = dict(norm1='.norm1', conv1='.conv1', temb='.time_emb_proj', norm2='.norm2', conv2='.conv2',
@@ -129,7 +130,12 @@ class UNetEngine:
         # Weight / bias gradients do not feed the backward chain: they run on a second HIP stream, so their MFMA work
         # fills the CUs while the main stream is in the HBM-bound GroupNorm / reduction kernels and in the launch
         # ramp / tail of its contraction kernels.  Same kernels, same accumulation order -> same bits.
-        self.overlap_wgrad = not os.environ.get('DP_NO_OVERLAP')
+        # [measured, round 3] every fork / join of the two streams costs tens of microseconds of cross-queue synchronisation on
+        # this stack (~80 per timestep): CIFAR UNet batch 4: 15.4 ms per timestep with the side stream, 11.2 without; batch 16:
+        # 16.1 / 12.0; batch 64: 24.4 / 25.4; LDM UNet, 6 latents: 51.1 / 55.8.  overlap_wgrad = None (default) decides per
+        # backward pass from the work of the step (images x pixels x base width >= OVERLAP_MIN_WORK); True / False force it.
+        self.overlap_wgrad = False if os.environ.get('DP_NO_OVERLAP') else (True if os.environ.get('DP_OVERLAP') else None)
+        self._overlap_now = True
         self._side, self._side_dev = None, None
         # Dropout (training mode only; utils.set_dropout, ddpm_train.py:380-382): {module name: p} of the nn.Dropout
         # holders with p > 0, or None.  Masks are Philox functions of (seed, crc32(module name), step, element index):
@@ -205,6 +211,14 @@ class UNetEngine:
             dx, pws = ops.groupnorm_bwd(x, x2, gamma, beta, stats, dz, G, silu, **kw)
             self._rows_src = None
         return dx, pws
+
+    def decide_overlap(self, x):
+        """Called by forward(save=True) with the network input: whether this step's weight gradients go to the side stream."""
+        if self.overlap_wgrad is None:
+            width = self.cfg.get('block_out_channels', [self.cfg.get('model_channels', 128)])[0]
+            self._overlap_now = x.shape[0] * x.shape[2] * x.shape[3] * width >= OVERLAP_MIN_WORK
+        else:
+            self._overlap_now = bool(self.overlap_wgrad)
 
     def _begin_backward(self):
         self._cq = ops.ColsumQueue() if (self.defer_colsum and hasattr(ops, 'ColsumQueue')) else None
@@ -298,7 +312,7 @@ class UNetEngine:
     def _side_stream(self, *tensors):
         """Fork: returns the side stream (ordered after everything enqueued so far on the current stream) or None.
         `tensors` are read by the side-stream work: the allocator must not recycle them before that work is done."""
-        if not self.overlap_wgrad or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
+        if not self._overlap_now or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
             return None
         if self._side is None or self._side_dev != tensors[0].device:        # the model may have moved to another GPU
             self._side, self._side_dev = _low_priority_stream(tensors[0].device), tensors[0].device
@@ -560,6 +574,8 @@ class UNetEngine:
         Lr = cfg['layers_per_block']
         nb = len(boc)
         ctx = {} if save else None
+        if save:
+            self.decide_overlap(sample)
         if cfg.get('center_input_sample', False):
             sample = 2 * sample - 1.0
         sample = sample.contiguous()

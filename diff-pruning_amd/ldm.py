@@ -282,6 +282,8 @@ class LdmEngine(UNetEngine):
         ctx2d = context.reshape(context.shape[0], context.shape[2]).contiguous().float()
         inp, out, mid = ldm_blocks(cfg)
         ctx = {} if save else None
+        if save:
+            self.decide_overlap(x)
         x = x.contiguous()
         t_emb = ops.timestep_embedding(timesteps.to(torch.float32), cfg['model_channels'], True, 0.0)
         h1 = self._linear('time_embed.0', t_emb)

@@ -19,8 +19,8 @@ from . import ops
 from .engine import UNetEngine
 
 
-GRAPH_AUTO_PIXELS = 16384       # taylor_sweep(use_graph=None) under DP_GRAPH=auto: shards up to this many pixels ...
-GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay a captured hipGraph
+GRAPH_AUTO_PIXELS = 8192        # taylor_sweep(use_graph=None): shards up to this many pixels (CIFAR: batch <= 8) ...
+GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay one captured timestep (native replay list)
 
 
 def flatten_grads(model):
@@ -226,11 +226,14 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     multi-process CPU tests drive the same control flow with a different per-step engine.
     device_exit / poll_every: keep the Diff-Pruning early-exit state on the device and read the stop flag every
     `poll_every` timesteps (False: read the loss on the host after every step, as the reference does).
-    use_graph: replay the timestep from a captured hipGraph (bit-identical; works with the on-device early exit).  Measured
-    slower than eager launches at every batch size on this stack -- C1-size model, batch 4, 200 timesteps: 24-26 ms per step
-    replayed vs 14.7 eager (tools/bench_c1_long.py); batch 256: +3 % -- the ~750-node graph launch costs more host time than
-    the ctypes launches it replaces.  None = False unless DP_GRAPH=auto (shards of <= GRAPH_AUTO_PIXELS pixels swept for
-    >= GRAPH_AUTO_STEPS timesteps).  Kept for runtimes where graph launch is cheap.
+    use_graph: capture one timestep once and replay it (bit-identical; works with the on-device early exit).  The replay is the
+    library's native list (csrc/replay.hip: the captured graph's nodes re-issued with hipLaunchKernel), not hipGraphLaunch.
+    [measured, round 3, CIFAR UNet, batch 4] eager with the weight-gradient side stream 15.4 ms per timestep, eager without it
+    11.2, hipGraph replay of the two-stream capture 27.6, native replay of a one-stream capture **8.5**: what made graph replay
+    slow in rounds 1-2 was the ~80 cross-stream edges per timestep (each costs tens of microseconds of cross-queue
+    synchronisation on this stack), not the node count.  At batch 16 replay and eager tie (11.8 / 12.0), from batch 64 on the
+    step is GPU-bound.  None = automatic: shards of <= GRAPH_AUTO_PIXELS pixels swept for >= GRAPH_AUTO_STEPS timesteps
+    (DP_GRAPH=off disables, DP_REPLAY=graph replays through hipGraphLaunch instead).
     timings: a dict that receives host wall-clock marks (bench.py): 'enqueue_s' (all timesteps enqueued), 'sweep_s' (device
     done with them) and 'allreduce_s' (the gradient exchange alone; only then is the exchange followed by a device sync)."""
     import time
@@ -250,7 +253,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     two_phase = thr is not None and not accumulate_breaking_step
     own_step = step_fn is None
     if use_graph is None:
-        use_graph = (os.environ.get('DP_GRAPH') == 'auto' and own_step and not two_phase and micro_batch is None
+        use_graph = (os.environ.get('DP_GRAPH', 'auto') == 'auto' and own_step and not two_phase and micro_batch is None
                      and clean_images.device.type == 'cuda' and num_steps >= GRAPH_AUTO_STEPS
                      and B_local * clean_images.shape[2] * clean_images.shape[3] <= GRAPH_AUTO_PIXELS)
     stop_state = losses_dev = None

@@ -128,10 +128,10 @@ def linear_wgrad(dy, x, gw, alpha=1.0, accumulate=True):
     return gw
 
 
-def bmm_tn(a, b, alpha=1.0, out=None):
+def bmm_tn(a, b, alpha=1.0, out=None, accumulate=False):
     r = alpha * torch.bmm(a.transpose(1, 2), b)
     if out is not None:
-        out.copy_(r)
+        out.copy_(out + r if accumulate else r)
         return out
     return r
 

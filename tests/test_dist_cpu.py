@@ -100,3 +100,33 @@ def test_two_rank_ldm_importance_pass_equals_single_process(tmp_path):
         if scale > 1e-7:
             assert float((a['grads'][n] - g).abs().max()) <= 5e-5 * scale, n
     assert len(u1['masks']) == 109 and a['masks'] == b['masks'] == u1['masks']
+
+
+def test_rank_sharded_sampling_feeds_one_allreduce_fid_statistics(tmp_path):
+    """ddpm_sample.py:55-74 on two ranks: per-rank folder `process_{rank}`, generator seed + rank, total // (batch * world)
+    batches each; the FID feature statistics of both ranks' samples come out of ONE all-reduce of (n, sum, outer-product sum)
+    and equal numpy's mean / cov over the union of the images the two folders hold."""
+    import numpy as np
+    from PIL import Image
+    out = str(tmp_path)
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_dist_worker_fid.py'), str(r), '2', port, out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(os.path.join(out, 'fid_r0_w2.npz')), np.load(os.path.join(out, 'fid_r1_w2.npz'))
+    assert int(r0['n']) == int(r1['n']) == 24
+    assert np.array_equal(r0['mu'], r1['mu']) and np.array_equal(r0['sigma'], r1['sigma'])
+    proj = np.random.default_rng(0).standard_normal((3 * 8 * 8, 12)).astype(np.float32)
+    feats = []
+    for r in range(2):
+        d = os.path.join(out, 'process_%d' % r)
+        for i in range(12):
+            a = np.asarray(Image.open(os.path.join(d, '%d.png' % i)), dtype=np.float32) / 255.0          # [8, 8, 3]
+            feats.append(a.transpose(2, 0, 1).reshape(-1) @ proj)
+    feats = np.stack(feats).astype(np.float64)
+    assert np.allclose(r0['mu'], feats.mean(0), rtol=1e-5, atol=1e-6)
+    assert np.allclose(r0['sigma'], np.cov(feats, rowvar=False), rtol=1e-4, atol=1e-5)
+    # the two ranks drew from different generators (seed + rank)
+    a0 = np.asarray(Image.open(os.path.join(out, 'process_0', '0.png')))
+    a1 = np.asarray(Image.open(os.path.join(out, 'process_1', '0.png')))
+    assert not np.array_equal(a0, a1)

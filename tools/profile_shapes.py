@@ -16,7 +16,8 @@ import golden_common as gc  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--target', type=float, default=135.0, help='TFLOP/s the "lost ms" column is priced against')
-ap.add_argument('--config', default='cifar', choices=['cifar', 'bedroom'])
+ap.add_argument('--config', default='cifar', choices=['cifar', 'bedroom', 'ldm', 'pruned'])
+ap.add_argument('--forward-only', action='store_true')
 args = ap.parse_args()
 ops = importlib.import_module('diff-pruning_amd.ops')
 unet = importlib.import_module('diff-pruning_amd.unet')
@@ -27,16 +28,47 @@ ops._cg_name = lambda p: 'cg M=%d C=%d N=%d taps=%d ks=%d z=%d' % (p.M, p.C, p.N
 ops._nt_name = lambda p: 'nt M=%d NC=%d P=%d taps=%d sp=%d z=%d' % (p.M, p.NCOLS, p.P, p.ntaps, p.splits, p.batches)
 dev = torch.device('cuda')
 B = args.batch
-cfg = gc.CIFAR_CFG if args.config == 'cifar' else gc.BEDROOM_CFG
-H = cfg['sample_size']
-model = unet.UNet2DModel(**cfg)
-gc.det_init_(model, 0)
-model = model.to(dev).eval()
-clean = torch.from_numpy(gc.det_clean((B, 3, H, H), 1)).to(dev)
-noise = torch.from_numpy(gc.det_noise((B, 3, H, H), 2)).to(dev)
-sweep.flatten_grads(model)
-step = sweep.HipSweepStep(model, diffusion.DDPMScheduler(), clean, noise, B * 3 * H * H, 'mse', B)
-step.eng.overlap_wgrad = False          # one kernel on the GPU at a time: clean per-shape durations
+if args.config == 'ldm':
+    # LDM cin256-v2 UNet: CFG forward at B latents (sampling: 2 x 6 = 12) or scored forward + backward (B = 6)
+    ldm = importlib.import_module('diff-pruning_amd.ldm')
+    model = ldm.UNetModel(**gc.LDM_CIN256_CFG)
+    gc.det_init_(model, 1)
+    model = model.to(dev).eval()
+    x = torch.randn(B, 3, 64, 64, device=dev); ctx = torch.randn(B, 1, 512, device=dev)
+    t = torch.full((B,), 500, device=dev); nz = torch.randn_like(x)
+    eng = model.engine()
+    eng.bind(eng.P, {n: torch.zeros_like(p) for n, p in model.named_parameters()})
+    eng.overlap_wgrad = False
+    eng.packs.pin_depth += 1
+
+    def step(k):
+        y = eng.forward(x, t, ctx, save=not args.forward_only)
+        if not args.forward_only:
+            l, d = ops.mse_fwd_bwd(y, nz, 2.0 / y.numel(), 1.0 / y.numel())
+            eng.backward(d)
+else:
+    cfg = gc.BEDROOM_CFG if args.config == 'bedroom' else gc.CIFAR_CFG
+    H = cfg['sample_size']
+    model = unet.UNet2DModel(**cfg)
+    gc.det_init_(model, 0)
+    model = model.to(dev).eval()
+    if args.config == 'pruned':
+        c0 = torch.from_numpy(gc.det_clean((16, 3, H, H), 1)).to(dev); n0 = torch.from_numpy(gc.det_noise((16, 3, H, H), 2)).to(dev)
+        sweep.taylor_sweep(model, diffusion.DDPMScheduler(), c0, n0, num_steps=2)
+        sweep.prune_model(model, 0.3)
+    clean = torch.from_numpy(gc.det_clean((B, 3, H, H), 1)).to(dev)
+    noise = torch.from_numpy(gc.det_noise((B, 3, H, H), 2)).to(dev)
+    sweep.flatten_grads(model)
+    if args.forward_only:
+        tt = torch.full((B,), 500, device=dev)
+        model.engine().packs.pin_depth += 1
+
+        def step(k):
+            with torch.no_grad():
+                model(clean, tt)
+    else:
+        step = sweep.HipSweepStep(model, diffusion.DDPMScheduler(), clean, noise, B * 3 * H * H, 'mse', B)
+        step.eng.overlap_wgrad = False          # one kernel on the GPU at a time: clean per-shape durations
 step(0); step(1)
 torch.cuda.synchronize()
 agg = {}
