@@ -8,7 +8,8 @@ key names, with every weight held by a real `nn.Conv2d` / `nn.Linear` / `nn.Grou
 Those layer objects are *parameter holders only*: their own `forward` is never called; all arithmetic
 runs in the HIP kernels through `UNetEngine`.  There is no PyTorch fallback.
 """
-from dataclasses import dataclass
+import math
+from collections import OrderedDict
 from types import SimpleNamespace
 
 import torch
@@ -17,9 +18,23 @@ import torch.nn as nn
 from .engine import UNetEngine, _PinnedWeights
 
 
-@dataclass
-class UNet2DOutput:
-    sample: torch.Tensor
+class UNet2DOutput(OrderedDict):
+    """diffusers.utils.BaseOutput behaviour (unet_2d.py:28-35): `.sample`, `["sample"]`, `[0]`, `.to_tuple()`, and -- being a
+    dict -- it is flattened by `torch_pruning.utils.flatten_as_list` when the reference's tracer walks the outputs."""
+
+    def __init__(self, sample=None):
+        super().__init__()
+        self['sample'] = sample
+
+    @property
+    def sample(self):
+        return OrderedDict.__getitem__(self, 'sample')
+
+    def __getitem__(self, k):
+        return OrderedDict.__getitem__(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+    def to_tuple(self):
+        return tuple(self.values())
 
 
 class FrozenConfig(dict):
@@ -210,6 +225,8 @@ class UNet2DModel(nn.Module):
         only: the HIP engine (packed operands, streams) is rebuilt on first use after loading."""
         state = dict(self.__dict__)
         state['_engine'] = None
+        state.pop('_leaf_cache', None)
+        state.pop('_structure_mode', None)
         return state
 
     # ------------------------------------------------------------------------------------------
@@ -266,9 +283,92 @@ class UNet2DModel(nn.Module):
         t = t.to(sample.device)
         return t * torch.ones(sample.shape[0], dtype=t.dtype, device=sample.device)
 
+    # ---- structure-only forward for autograd tracers (boundary B2, ddpm_prune.py:79-87) -------------------------------------
+    # `tp.pruner.MagnitudePruner(model, example_inputs, ...)` builds its DependencyGraph by registering forward hooks on the
+    # Conv2d / Linear / GroupNorm leaves, calling `model(**example_inputs)` and walking the `grad_fn`s of the result
+    # (ddpm_exp/torch_pruning/dependency.py:631-690).  The HIP engine never calls the holder modules and is ONE autograd
+    # node, so a hooked model takes this path instead: the reference's layer sequence (unet_2d.py:219-316, resnet.py:589-639,
+    # attention_processor.py:870-935) over the holder modules on a batch of ZERO images -- every leaf is called once, per-layer
+    # `grad_fn`s exist, shapes propagate, and there are NO VALUES: it cannot serve as a numerics path.
+    def _leaf_hooked(self):
+        leaves = self.__dict__.get('_leaf_cache')
+        if leaves is None:
+            leaves = [m for m in self.modules() if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm))]
+            self.__dict__['_leaf_cache'] = leaves
+        return any(m._forward_hooks or m._forward_pre_hooks for m in leaves)
+
+    def structure_forward(self, sample, timestep):
+        """Forward through the holder modules on a batch of ZERO images: every leaf runs once with the real ATen autograd
+        nodes behind it (the same graph the reference's model produces), shapes propagate, and not one value is computed."""
+        dev = self.conv_in.weight.device
+        x = torch.empty((0,) + tuple(sample.shape[1:]), dtype=torch.float32, device=dev)
+        self.__dict__['_structure_mode'] = True
+        try:
+            with torch.enable_grad():
+                return self.forward(x, None)
+        finally:
+            self.__dict__['_structure_mode'] = False
+
+    def _structure_layers(self, x):
+        F = torch.nn.functional
+        cfg = self.config
+        half = cfg['block_out_channels'][0] // 2
+        temb = torch.empty((x.shape[0], 2 * half), dtype=torch.float32, device=x.device)    # sinusoidal table: no parameters
+        emb = self.time_embedding.linear_2(F.silu(self.time_embedding.linear_1(temb)))
+
+        def resnet(r, h):
+            y = r.conv1(F.silu(r.norm1(h)))
+            y = y + r.time_emb_proj(F.silu(emb))[:, :, None, None]
+            y = r.conv2(r.dropout(F.silu(r.norm2(y))))
+            sc = r.conv_shortcut(h) if r.conv_shortcut is not None else h
+            return (sc + y) / r.output_scale_factor
+
+        def attention(a, h):                      # AttnProcessor2_0, op for op (the tracer's member order follows the op order)
+            N, C, H, W = h.shape
+            t = h.view(N, C, H * W).transpose(1, 2)
+            t = a.group_norm(t.transpose(1, 2)).transpose(1, 2)
+            q, k, v = a.to_q(t), a.to_k(t), a.to_v(t)
+            d = q.shape[-1] // a.heads
+            q, k, v = [z.view(N, H * W, a.heads, d).transpose(1, 2) for z in (q, k, v)]
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+            o = o.transpose(1, 2).reshape(N, H * W, a.heads * d)
+            o = a.to_out[1](a.to_out[0](o)).transpose(-1, -2).reshape(N, C, H, W)
+            return (o + h) / a.rescale_output_factor
+
+        h = self.conv_in(x)
+        skips = [h]
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = resnet(r, h)
+                if hasattr(blk, 'attentions'):
+                    h = attention(blk.attentions[j], h)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                d = blk.downsamplers[0]
+                h = d.conv(F.pad(h, (0, 1, 0, 1)) if d.padding == 0 else h)
+                skips.append(h)
+        h = resnet(self.mid_block.resnets[0], h)
+        if self.mid_block.attentions[0] is not None:
+            h = attention(self.mid_block.attentions[0], h)
+        h = resnet(self.mid_block.resnets[1], h)
+        for blk in self.up_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = resnet(r, torch.cat([h, skips.pop()], dim=1))
+                if hasattr(blk, 'attentions'):
+                    h = attention(blk.attentions[j], h)
+            if blk.upsamplers is not None:
+                h = blk.upsamplers[0].conv(F.interpolate(h, scale_factor=2.0, mode='nearest'))
+        return self.conv_out(F.silu(self.conv_norm_out(h)))
+
     def forward(self, sample, timestep, class_labels=None, return_dict=True):
         if class_labels is not None:
             raise ValueError('class conditioning is not part of this model')
+        if self.__dict__.get('_structure_mode'):
+            out = self._structure_layers(sample)
+            return UNet2DOutput(sample=out) if return_dict else (out,)
+        if self._leaf_hooked():
+            out = self.structure_forward(sample, timestep)
+            return out if return_dict else out.to_tuple()
         t = self._timesteps(sample, timestep)
         if self.training:
             self._dropout_step = getattr(self, '_dropout_step', 0) + 1       # a fresh mask per training-mode forward

@@ -814,6 +814,59 @@ def types_ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
+def do_b2():
+    """Boundary B2 (ddpm_prune.py:79-87): the REFERENCE's own pruner -- vendored `tp.pruner.MagnitudePruner`, whose
+    DependencyGraph traces `model(**example_inputs)` through forward hooks and grad_fns (dependency.py:631-690) -- is handed THIS
+    repository's drop-in `UNet2DModel` (on the CPU, where only its structure-only meta forward can run).  Recorded:
+      * the group tables the reference's tracer enumerates on the product model == the tables it enumerates on its own
+        Diffusers model (groups.json), member for member, for the CIFAR and bedroom topologies and the tiny UNet;
+      * config C1 end to end: the reference's sweep on its own model supplies the gradients (same parameter names), the
+        reference's pruner then scores, selects and SLICES the product model's holder modules: pruned index lists, parameter
+        shapes and count equal cifar_c1.json.
+    Written to b2_reference_pruner_on_product_model.json (booleans and counts only)."""
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    own_unet = importlib.import_module('diff-pruning_amd.unet')
+    own_pruning = importlib.import_module('diff-pruning_amd.pruning')
+    res = {}
+    want = json.load(open(os.path.join(HERE, 'groups.json')))
+    cfgb = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
+    for key, cfg, H, ref_table in (('cifar', gc.CIFAR_CFG, 32, want['cifar']), ('bedroom_topology', cfgb, 64, want['bedroom_topology']),
+                                   ('tiny', gc.TINY_CFG, 16, None)):
+        own = own_unet.UNet2DModel(**cfg).eval()
+        gc.det_init_(own, 0)
+        table = group_table(own, H)                                 # the reference's tracer on the product model
+        if ref_table is None:
+            ref_table = group_table(build_ref_unet(cfg, 0), H)
+        assert table == ref_table, key
+        res[key] = dict(groups=len(table), equal_to_reference_model=True)
+        print('b2', key, len(table), 'groups: reference tracer on the product model == on the reference model')
+    # C1 end to end with the reference's pruner driving the product model
+    cfg = gc.CIFAR_CFG
+    ref = build_ref_unet(cfg, 0)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    clean = torch.from_numpy(gc.det_clean((4, 3, 32, 32), 1))
+    noise = torch.from_numpy(gc.det_noise((4, 3, 32, 32), 2))
+    sweep(ref, sched, clean, noise, 8)
+    own = own_unet.UNet2DModel(**cfg).eval()
+    gc.det_init_(own, 0)
+    grads = {n: p.grad for n, p in ref.named_parameters()}
+    for n, p in own.named_parameters():
+        p.grad = grads[n].clone()
+    rec = prune_run(own, 32, 0.3)
+    own_pruning.fix_static_attributes(own)
+    c1 = json.load(open(os.path.join(HERE, 'cifar_c1.json')))
+    assert [r['root'] for r in rec] == [r['root'] for r in c1['prune']]
+    assert [r['pruned'] for r in rec] == [r['pruned'] for r in c1['prune']]
+    assert {n: list(p.shape) for n, p in own.named_parameters()} == c1['shapes_after']
+    n_after = sum(p.numel() for p in own.parameters())
+    assert n_after == c1['params_after'] == 19851157
+    res['c1_reference_pruner_on_product_model'] = dict(pruned_groups=len(rec), masks_equal=True, shapes_equal=True,
+                                                        params_after=int(n_after))
+    print('b2 C1: the reference pruner pruned the product model to', n_after, 'parameters, masks equal')
+    json.dump(res, open(os.path.join(HERE, 'b2_reference_pruner_on_product_model.json'), 'w'))
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['schedule', 'ddim', 'tiny', 'groups', 'c1', 'criteria', 'tiny_bedroom', 'optim', 'pretrained', 'groups_more', 'tiny_heads', 'long_sweep', 'lr', 'ddpm', 'dropout', 'fid']
     for w in what:

@@ -1578,3 +1578,59 @@ def test_finetune_loop_matches_the_reference_script(mocked, monkeypatch):
         assert relerr(P[n].detach(), want) < 2e-4 and relerr(live[n].detach(), want) < 2e-4, n
         want_e = torch.from_numpy(gc.b64_to_f32(fx['full_ema'][n]))
         assert relerr(es[n], want_e) < 1e-5, n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 3: boundary B2 for autograd tracers
+# ------------------------------------------------------------------------------------------------------------------
+def test_reference_pruner_traces_and_prunes_the_product_model():
+    """Boundary B2 (ddpm_prune.py:79-87).  tests/golden/b2_reference_pruner_on_product_model.json was written in the build
+    container by make_golden.py `b2`: the reference's vendored `tp.pruner.MagnitudePruner` was handed this repository's
+    UNet2DModel, its DependencyGraph traced it (forward hooks + grad_fns), the group tables equalled the ones it enumerates on
+    its own Diffusers model (member for member), and -- given the reference sweep's gradients -- it pruned the product model to
+    the C1 masks, shapes and 19 851 157 parameters."""
+    fx = load_json('b2_reference_pruner_on_product_model.json')
+    g = load_json('groups.json')
+    assert fx['cifar'] == dict(groups=len(g['cifar']), equal_to_reference_model=True) and fx['cifar']['groups'] == 50
+    assert fx['bedroom_topology'] == dict(groups=len(g['bedroom_topology']), equal_to_reference_model=True)
+    assert fx['tiny']['equal_to_reference_model'] is True
+    c1 = fx['c1_reference_pruner_on_product_model']
+    assert c1['masks_equal'] and c1['shapes_equal'] and c1['params_after'] == 19851157 == load_json('cifar_c1.json')['params_after']
+
+
+def test_hooked_model_runs_the_structure_only_forward():
+    """What that fixture rests on, checked without the reference: a model whose leaves carry forward hooks (how an autograd tracer
+    observes it) runs the layer sequence through its holder modules on a batch of ZERO images -- every Conv2d / Linear / GroupNorm
+    is called exactly once with a grad_fn behind its output, the result has no elements (it cannot serve as a numerics path), and
+    THIS repository's generic tracer, walking that graph, enumerates the reference's group tables (groups.json)."""
+    unet, trace, graph, pruning = pkg('unet'), pkg('trace'), pkg('graph'), pkg('pruning')
+    fx = load_json('groups.json')
+    cfgb = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
+    for key, cfg, H in (('cifar', gc.CIFAR_CFG, 32), ('bedroom_topology', cfgb, 64)):
+        model = unet.UNet2DModel(**cfg).eval()
+        leaves = [m for m in model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.GroupNorm))]
+        calls = {}
+        hooks = [m.register_forward_hook(lambda m, i, o: calls.__setitem__(m, calls.get(m, 0) + (o.grad_fn is not None)))
+                 for m in leaves]
+        out = model(sample=torch.randn(1, 3, H, H), timestep=torch.ones((1,)).long())
+        for h in hooks:
+            h.remove()
+        assert out.sample.shape == (0, 3, H, H) and out.sample.grad_fn is not None and out[0] is out.sample
+        assert len(calls) == len(leaves) and set(calls.values()) == {1}
+        with pytest.raises(RuntimeError):                            # un-hooked: the HIP engine, which has no CPU path
+            model(torch.randn(1, 3, H, H), torch.ones((1,)).long())
+        tg = trace.TracedGraph(model, {'sample': torch.randn(1, 3, H, H), 'timestep': torch.ones((1,)).long()})
+        n2m = dict(model.named_modules())
+        chan = graph.ChannelView(lambda name: pruning._out_channels(n2m[name]))
+        mine = [[[m.name, m.kind, _ranges(m.idxs)] for m in members] for _, members in graph.all_groups(tg, lambda: chan, ('conv_out',))]
+        assert mine == [t['members'] for t in fx[key]], key
+
+
+def _ranges(idxs):
+    out = []
+    for i in idxs:
+        if out and out[-1][1] == i:
+            out[-1][1] = i + 1
+        else:
+            out.append([i, i + 1])
+    return out
