@@ -241,6 +241,8 @@ class UNetEngine:
             self._cq.flush()
             self._cq = None
 
+    _temb_suffix = '.time_emb_proj'
+
     def _resnet_prefixes(self):
         cfg = self.cfg
         Lr, nb = cfg['layers_per_block'], len(cfg['block_out_channels'])
@@ -255,12 +257,13 @@ class UNetEngine:
         if hit is not None:
             return hit
         names = self._resnet_prefixes()
-        ws = [self.P[n + '.time_emb_proj.weight'] for n in names]
+        sfx = self._temb_suffix
+        ws = [self.P[n + sfx + '.weight'] for n in names]
         offs, o = {}, 0
         for n, w in zip(names, ws):
             offs[n] = (o, w.shape[0])
             o += w.shape[0]
-        val = (names, offs, torch.cat(ws, 0).contiguous(), torch.cat([self.P[n + '.time_emb_proj.bias'] for n in names], 0).contiguous())
+        val = (names, offs, torch.cat(ws, 0).contiguous(), torch.cat([self.P[n + sfx + '.bias'] for n in names], 0).contiguous())
         self.packs._c[('__temb_all__', 0)] = val
         return val
 
@@ -271,7 +274,8 @@ class UNetEngine:
         if hit is None:
             ws = [self.P[pre + n + '.weight'] for n in ('.to_q', '.to_k', '.to_v')]
             w = torch.cat(ws, 0).contiguous()
-            b = torch.cat([self.P[pre + n + '.bias'] for n in ('.to_q', '.to_k', '.to_v')], 0).contiguous()
+            b = (torch.cat([self.P[pre + n + '.bias'] for n in ('.to_q', '.to_k', '.to_v')], 0).contiguous()
+                 if (pre + '.to_q.bias') in self.P else None)        # the LDM transformer's projections are bias-free
             wp, ld = ops.pack_weight(w, 0)
             wd, ldd = ops.pack_weight(w, 1)
             hit = (wp, ld, b, wd, ldd, tuple(x.shape[0] for x in ws))

@@ -192,6 +192,15 @@ class UNetModel(nn.Module):
 class LdmEngine(UNetEngine):
     """Forward + hand-written backward of the LDM UNet (openaimodel.py:710-742) on the HIP kernels."""
 
+    _temb_suffix = '.emb_layers.1'
+
+    def _resnet_prefixes(self):
+        inp, out, _ = ldm_blocks(self.cfg)
+        names = ['input_blocks.%d.%d' % (bi, li) for bi, items in enumerate(inp) for li, it in enumerate(items) if it[0] == 'res']
+        names += ['middle_block.0', 'middle_block.2']
+        names += ['output_blocks.%d.%d' % (bi, li) for bi, items in enumerate(out) for li, it in enumerate(items) if it[0] == 'res']
+        return names
+
     def res_fwd(self, pre, xa, xb, semb, save):
         return self.resnet_fwd(pre, xa, xb, semb, 1.0, save, names=RES_LDM, G=32, eps=1e-5)
 
@@ -207,18 +216,30 @@ class LdmEngine(UNetEngine):
         inner = h.shape[1]
         # attn1: self-attention
         l1, ls1 = ops.layernorm_fwd(h, P[tb + '.norm1.weight'], P[tb + '.norm1.bias'])
-        q = self._conv(tb + '.attn1.to_q', l1, None, _SPEC1)
-        k = self._conv(tb + '.attn1.to_k', l1, None, _SPEC1)
-        v = self._conv(tb + '.attn1.to_v', l1, None, _SPEC1)
+        fused = self.fuse_qkv and hasattr(ops, 'empty_act')
+        if fused:                                     # one M = 3 * inner contraction instead of three (see UNetEngine.attn_fwd)
+            wp, ld, _, _, _, (cq, ck, cv) = self._qkv_pack(tb + '.attn1')
+            qkv = ops.conv_forward(l1, None, wp, ld, cq + ck + cv, _SPEC1)
+            q, k, v = qkv[:, :cq], qkv[:, cq:cq + ck], qkv[:, cq + ck:]
+        else:
+            q = self._conv(tb + '.attn1.to_q', l1, None, _SPEC1)
+            k = self._conv(tb + '.attn1.to_k', l1, None, _SPEC1)
+            v = self._conv(tb + '.attn1.to_v', l1, None, _SPEC1)
         ai = q.shape[1]
         s = ops.bmm_tn(q.view(N, ai, T), k.view(N, ai, T), alpha=scale)
         p = ops.softmax_fwd(s, out=s)
         o = ops.bmm_nt(v.view(N, ai, T), p)
         h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, ai, H, W), None, _SPEC1, res=h)
         # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
-        v2 = self._linear(tb + '.attn2.to_v', ctx2d)
-        o2 = self._linear(tb + '.attn2.to_out.0', v2)
-        h2 = ops.add_rowvec(h1, o2.contiguous())
+        hit = self._ctx_cache.get(pre) if self._ctx_cache is not None else None
+        if hit is not None:
+            v2, o2 = hit                              # sampling loop: same context and weights at every DDIM step
+        else:
+            v2 = self._linear(tb + '.attn2.to_v', ctx2d)
+            o2 = self._linear(tb + '.attn2.to_out.0', v2).contiguous()
+            if self._ctx_cache is not None:
+                self._ctx_cache[pre] = (v2, o2)
+        h2 = ops.add_rowvec(h1, o2)
         # feed-forward (GEGLU)
         l3, ls3 = ops.layernorm_fwd(h2, P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
         pr = self._conv(tb + '.ff.net.0.proj', l3, None, _SPEC1)
@@ -226,8 +247,27 @@ class LdmEngine(UNetEngine):
         h3 = self._conv(tb + '.ff.net.2', gg, None, _SPEC1, res=h2)
         out = self._conv(pre + '.proj_out', h3, None, _SPEC1, res=x)
         if save is not None:
-            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale)
+            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused)
         return out
+
+    # The cross-attention branch of every transformer block depends on the context token and the weights only
+    # (module docstring): inside a sampling loop -- frozen weights, one context for all DDIM steps -- it is computed once.
+    _ctx_cache = None
+
+    def context_cache(self, context):
+        """Context manager: `context` (the [B, 1, D] tensor handed to every forward inside the block) and the weights do not
+        change inside -> the 2 x 16 cross-attention projections run once instead of once per forward."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self):
+                eng._ctx_cache, eng._ctx_key = {}, (context.data_ptr(), tuple(context.shape))
+                return eng
+
+            def __exit__(self, *exc):
+                eng._ctx_cache = None
+                return False
+        return _Scope()
 
     def _ln_param_grads(self, name, pws):
         N, C = pws.shape[0], pws.shape[1]
@@ -235,7 +275,7 @@ class LdmEngine(UNetEngine):
         self._colsum(pws, N, C, 2, 0, self.G[name + '.bias'])
 
     def st_bwd(self, pre, dout, extra=None):
-        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale) = self.ctx.pop(pre)
+        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused) = self.ctx.pop(pre)
         P = self.P
         N, C, H, W = x.shape
         T = H * W
@@ -256,16 +296,30 @@ class LdmEngine(UNetEngine):
         # attn1
         do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, ai, H, W), None, _SPEC1, hw)
         do3 = do.view(N, ai, T)
-        dv = ops.bmm_nn(do3, p)
-        dp = ops.bmm_tn(do3, v.view(N, ai, T))
-        ds = ops.softmax_bwd(p, dp, scale, out=dp)
-        dq = ops.bmm_nt(k.view(N, ai, T), ds)
-        dk = ops.bmm_nn(q.view(N, ai, T), ds)
-        dl1 = torch.empty_like(l1)
-        first = True
-        for dproj, name in ((dq, '.attn1.to_q'), (dk, '.attn1.to_k'), (dv, '.attn1.to_v')):
-            self._conv_bwd(tb + name, dproj.view(N, ai, H, W), l1, None, _SPEC1, hw, dx_out=dl1, dx_accumulate=not first)
-            first = False
+        if fused:
+            # dq | dk | dv written straight into channel slices of one buffer; one K = 3 * inner input-gradient contraction
+            _, _, _, wd, ldd, (cq, ck, cv) = self._qkv_pack(tb + '.attn1')
+            d_qkv = ops.empty_act((N, cq + ck + cv, H, W), x.device)
+            sl = (d_qkv[:, :cq], d_qkv[:, cq:cq + ck], d_qkv[:, cq + ck:])
+            ops.bmm_nn(do3, p, out=sl[2].view(N, cv, T))
+            dp = ops.bmm_tn(do3, v.view(N, cv, T))
+            ds = ops.softmax_bwd(p, dp, scale, out=dp)
+            ops.bmm_nt(k.view(N, ck, T), ds, out=sl[0].view(N, cq, T))
+            ops.bmm_nn(q.view(N, cq, T), ds, out=sl[1].view(N, ck, T))
+            for dproj, name in zip(sl, ('.attn1.to_q', '.attn1.to_k', '.attn1.to_v')):
+                self._conv_bwd(tb + name, dproj, l1, None, _SPEC1, hw, need_dx=False)       # weight gradients only
+            dl1 = ops.conv_dgrad(d_qkv, wd, ldd, l1.shape[1], _SPEC1, hw)
+        else:
+            dv = ops.bmm_nn(do3, p)
+            dp = ops.bmm_tn(do3, v.view(N, ai, T))
+            ds = ops.softmax_bwd(p, dp, scale, out=dp)
+            dq = ops.bmm_nt(k.view(N, ai, T), ds)
+            dk = ops.bmm_nn(q.view(N, ai, T), ds)
+            dl1 = torch.empty_like(l1)
+            first = True
+            for dproj, name in ((dq, '.attn1.to_q'), (dk, '.attn1.to_k'), (dv, '.attn1.to_v')):
+                self._conv_bwd(tb + name, dproj.view(N, ai, H, W), l1, None, _SPEC1, hw, dx_out=dl1, dx_accumulate=not first)
+                first = False
         dh, pws = ops.layernorm_bwd(h, P[tb + '.norm1.weight'], ls1, dl1, add=dh2)
         self._ln_param_grads(tb + '.norm1', pws)
         dn0 = self._conv_bwd(pre + '.proj_in', dh, n0, None, _SPEC1, hw)
@@ -290,6 +344,14 @@ class LdmEngine(UNetEngine):
         a1 = ops.silu_fwd(h1)
         emb = self._linear('time_embed.2', a1)
         semb = ops.silu_fwd(emb)
+        # no-grad forwards (the sampling loop: 20 per importance step): the 22 emb_layers projections of silu(emb) as ONE GEMM
+        # against the concatenated weights, each ResBlock taking its column slice (UNetEngine.__init__, temb_batch)
+        self._temb = None
+        if ctx is None and self.temb_batch and hasattr(ops, 'empty_act'):
+            names, offs, W_all, b_all = self._temb_pack()
+            self._temb = (names, offs, ops.linear_forward(semb, W_all, b_all), W_all)
+        if self._ctx_cache is not None and (ctx is not None or self._ctx_key != (context.data_ptr(), tuple(context.shape))):
+            raise RuntimeError('context_cache(): a different context (or a gradient step) inside the cached block')
         hs = []
         h = x
         for bi, items in enumerate(inp):
@@ -330,6 +392,7 @@ class LdmEngine(UNetEngine):
         ho = h
         no, sto = ops.groupnorm_fwd(ho, None, P['out.0.weight'], P['out.0.bias'], 32, 1e-5, True)
         y = self._conv('out.2', no, None, _SPEC3)
+        self._temb = None
         if ctx is not None:
             ctx['_head'] = (x, t_emb, h1, a1, emb, semb, ho, no, sto)
             self.ctx = ctx

@@ -20,6 +20,7 @@ early-exit test (so every rank stops at the same t), and the flat gradient buffe
 max-loss / threshold state lives on the device (`dp_early_exit_update_ratio`): the breaking step's dOut is cancelled there
 (`dp_zero_if_stopped`), the host reads the stop flag one step late from pinned memory, so no step waits for the host.
 """
+import contextlib
 import random
 
 import numpy as np
@@ -79,12 +80,20 @@ def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0
     x = x_T.contiguous()
     B = x.shape[0]
     ctx2 = torch.cat([uncond, cond]).contiguous()
-    with model.pin_weights():                    # 2 * S forwards over frozen weights: pack the operands once
-        for i in reversed(range(len(steps))):
-            t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
-            e = model(torch.cat([x, x]), t, context=ctx2)
-            e_t = ops.cfg_combine(e[:B], e[B:], scale)
-            x = ops.ddim_step(x, e_t, float(a[i]), float(a_prev[i]), float(sig[i]), None, clip=False)
+    with model.pin_weights() as pinned:          # 2 * S forwards over frozen weights: pack the operands once
+        eng = getattr(pinned, '_engine', None)
+        cache = eng.context_cache(ctx2) if hasattr(eng, 'context_cache') else contextlib.nullcontext()
+        with cache:                              # one context for all S steps: the cross-attention branch is evaluated once
+            x = _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B)
+    return x
+
+
+def _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B):
+    for i in reversed(range(len(steps))):
+        t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
+        e = model(torch.cat([x, x]), t, context=ctx2)
+        e_t = ops.cfg_combine(e[:B], e[B:], scale)
+        x = ops.ddim_step(x, e_t, float(a[i]), float(a_prev[i]), float(sig[i]), None, clip=False)
     return x
 
 

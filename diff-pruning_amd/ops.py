@@ -167,6 +167,7 @@ def pick_tile(M, N, z=1):
 
 
 CONV_SPLITK_BLOCKS = int(os.environ.get('DP_CONV_SPLITK_BLOCKS', '512'))      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
+CONV_SPLITK_MID = not os.environ.get('DP_NO_SPLITK_MID')
 _n64 = os.environ.get('DP_CONV_N64', '0')         # default off: measured null (118.7 vs 124.4 TFLOP/s in isolation, 87.4 = 87.4 ms per step)
 CONV_N64_TILES = tuple(int(v) for v in _n64.split(',')) if _n64 not in ('0', '') else None      # [lo, hi) 128x128-tile counts run as 128x64
 
@@ -189,6 +190,12 @@ def _conv_ksplit(p, device):
     # K tiles per slice: at least 16 for grids that already hold a workgroup per second CU (a 1x1 conv at 8x8, 16 K tiles, ran
     # 38 us split in two against 26 us unsplit), 8 from 32 tiles on, 2 for the tiniest grids  [tools/bench_conv_small.py]
     s = min(CONV_SPLITK_BLOCKS // max(tiles, 1), n_iter // (16 if tiles >= 128 else 8 if tiles >= 32 else 2))
+    # Grids of one to two workgroups per CU (256 < tiles < 512: the 384-channel layers of the LDM UNet at 12 x 32 x 32 pixels are
+    # 288 tiles) leave a single wavefront per SIMD -- 62-78 TFLOP/s measured against 100+ with three resident workgroups -- and
+    # their second "round" is a 12 % tail: split K so that ~3-4 workgroups per CU are resident at once.  [round 3,
+    # tools/profile_shapes.py --config ldm]
+    if s < 2 and 256 < tiles < 512 and CONV_SPLITK_MID:
+        s = min(1024 // tiles, n_iter // 16)
     if s >= 2 and p.M >= 64:
         if p.tile != 3:
             p.tile = 0 if p.M > 64 else 1
