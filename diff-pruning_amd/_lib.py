@@ -51,6 +51,16 @@ class Dropout(C.Structure):
                 ('n_off', LL)]
 
 
+class ScoreMember(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('g', C.c_void_p), ('R', C.c_int), ('C', C.c_int), ('T', C.c_int), ('dim', C.c_int),
+                ('mode', C.c_int), ('blk0', C.c_int), ('full_off', LL), ('col_off', LL), ('idx_off', LL)]
+
+
+class SliceItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('R', C.c_int), ('C', C.c_int), ('T', C.c_int), ('dim', C.c_int),
+                ('n_keep', C.c_int), ('blk0', C.c_int), ('nblk', C.c_int), ('_pad', C.c_int), ('keep_off', LL)]
+
+
 class ColsumItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('wstride', C.c_int),
                 ('woff', C.c_int), ('accumulate', C.c_int), ('ld', C.c_int)]
@@ -99,6 +109,8 @@ SIGNATURES = {
     'dp_ups_wfold': [_vp, _ll, _vp, _i, _vp],
     'dp_wg_reduce': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     'dp_gather_add': [_vp, _vp, _i, _vp, _vp],
+    'dp_group_score': [C.POINTER(ScoreMember), _i, _i, _vp, _vp, _vp, _vp],
+    'dp_slice_batch': [C.POINTER(SliceItem), _i, _vp, _vp],
     'dp_sumsq_partials': [_vp, _ll, _vp, _i, _vp],
     'dp_clip_coef': [_vp, _i, _f, _vp, _vp, _vp],
     'dp_adam_ema': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],

@@ -997,6 +997,32 @@ def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
     return out
 
 
+def group_score(members, n0, idx_dev, scratch, score):
+    """One group's Taylor score in two launches (include/dp_hip.h dp_group_score).  members: list of dicts(w, g, R, C, T, dim,
+    mode, full_off, col_off, idx_off); idx_dev: int64 device tensor holding the members' index lists (or None)."""
+    n = len(members)
+    arr = (L.ScoreMember * n)()
+    assert score.is_cuda and scratch.is_cuda and all(m['w'].is_cuda and m['g'].is_cuda for m in members), \
+        'group_score takes device tensors (no CPU path)'
+    for a, m in zip(arr, members):
+        a.w, a.g = m['w'].data_ptr(), m['g'].data_ptr()
+        a.R, a.C, a.T, a.dim, a.mode = m['R'], m['C'], m['T'], m['dim'], m['mode']
+        a.full_off, a.col_off, a.idx_off = m['full_off'], m['col_off'], m['idx_off']
+    L.check(_lib().dp_group_score(arr, n, n0, _p(idx_dev), _p(scratch), _p(score), _stream()), 'dp_group_score')
+    return score
+
+
+def slice_batch(items, keep_dev):
+    """Channel slicing of every tensor of a group in one launch (dp_slice_batch).  items: list of (src, dst, R, C, T, dim,
+    n_keep, keep_off); keep_dev: int64 device tensor with the ascending kept-channel lists."""
+    n = len(items)
+    arr = (L.SliceItem * n)()
+    assert keep_dev.is_cuda and all(it[0].is_cuda and it[1].is_cuda for it in items), 'slice_batch takes device tensors (no CPU path)'
+    for a, (src, dst, R, Cc, T, dim, nk, off) in zip(arr, items):
+        a.src, a.dst, a.R, a.C, a.T, a.dim, a.n_keep, a.keep_off = src.data_ptr(), dst.data_ptr(), R, Cc, T, dim, nk, off
+    L.check(_lib().dp_slice_batch(arr, n, _p(keep_dev), _stream()), 'dp_slice_batch')
+
+
 def gather_add(src, idx_long, dst):
     """dst[i] += src[idx[i]]"""
     assert idx_long.dtype == torch.int64 and idx_long.numel() == dst.numel()

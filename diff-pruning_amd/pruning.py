@@ -13,6 +13,7 @@ argsort over the <= 1024 scores of a group and the channel slicing itself are ho
 to `tp.pruner.MagnitudePruner(importance=...)` unchanged (drop-in boundary B1 of SURVEY.md §8b).
 """
 import abc
+import os
 from types import SimpleNamespace
 
 import torch
@@ -284,8 +285,9 @@ class Group:
         [root module name, is_out_channel_pruning, root indices]."""
         if idxs is not None:
             raise NotImplementedError('re-indexing an enumerated group: ask the graph for get_pruning_group(module, fn, idxs)')
-        for dep, ix in self._items:
-            dep(ix)
+        if not _prune_group_batched(self._items):
+            for dep, ix in self._items:
+                dep(ix)
         for node, n in self._aux:                  # the outputs of a torch.split shrink with the tensor that is split
             j, info = node.part
             info.sizes[j] -= n
@@ -296,6 +298,83 @@ class Group:
 
     def details(self):
         return ['%s:%s(%d)' % (dep.kind, dep.target.name, len(idxs)) for dep, idxs in self._items]
+
+
+PRUNE_BATCH = not os.environ.get('DP_NO_PRUNE_BATCH')
+_BATCH_RULES = {}        # handler -> (weight dim, slices the bias too, attribute that holds the channel count)
+
+
+def _batch_rules():
+    if not _BATCH_RULES:
+        _BATCH_RULES.update({
+            prune_conv_out_channels: (0, True, 'out_channels'), prune_conv_in_channels: (1, False, 'in_channels'),
+            prune_linear_out_channels: (0, True, 'out_features'), prune_linear_in_channels: (1, False, 'in_features'),
+            prune_groupnorm_out_channels: (0, True, 'num_channels')})
+    return _BATCH_RULES
+
+
+def _prune_group_batched(items):
+    """function.py:85-146,168-207,274-302 for ALL members of a group in one kernel launch (ops.slice_batch): every weight, bias
+    and accumulated gradient keeps its un-pruned channels; the layers' channel attributes are updated as the per-member
+    functions do.  Returns False (nothing touched) when a member is not a plain Conv2d / Linear / GroupNorm on the device, or
+    when one tensor would be sliced twice in the group -- the caller then prunes member by member."""
+    if not PRUNE_BATCH or not hasattr(ops, 'slice_batch') or not items:
+        return False
+    rules = _batch_rules()
+    plan, seen = [], set()
+    for dep, idxs in items:
+        rule = rules.get(dep.handler)
+        layer = dep.target.module
+        if rule is None or getattr(layer, 'transposed', False) or getattr(layer, 'groups', 1) != 1:
+            return False
+        dim, with_bias, attr = rule
+        if isinstance(layer, nn.GroupNorm) and not layer.affine:
+            return False
+        names = ['weight'] + (['bias'] if with_bias and getattr(layer, 'bias', None) is not None else [])
+        for nm in names:
+            if (id(layer), nm) in seen or (getattr(layer, nm).device.type != 'cuda' and not getattr(ops, 'IS_MOCK', False)):
+                return False          # host-side structure edits (history replay on a CPU model) slice member by member
+            seen.add((id(layer), nm))
+        plan.append((layer, dim, names, attr, idxs))
+    keep_host, slices, assign = [], [], []
+    for layer, dim, names, attr, idxs in plan:
+        n = getattr(layer, attr)
+        drop = set(int(i) for i in idxs)
+        keep = [i for i in range(n) if i not in drop]
+        if not keep:
+            return False
+        off = len(keep_host)
+        keep_host.extend(keep)
+        for nm in names:
+            p = getattr(layer, nm)
+            d = dim if nm == 'weight' else 0
+            shp = list(p.shape)
+            R = shp[0]
+            Cc = shp[1] if len(shp) > 1 else 1
+            T = 1
+            for v in shp[2:]:
+                T *= v
+            new_shape = list(shp)
+            new_shape[d] = len(keep)
+            outs = []
+            for src in (p.data, p.grad.data if p.grad is not None else None):
+                if src is None:
+                    outs.append(None)
+                    continue
+                dst = torch.empty(new_shape, dtype=src.dtype, device=src.device)
+                slices.append((src.contiguous(), dst, R, Cc, T, d, len(keep), off))
+                outs.append(dst)
+            assign.append((layer, nm, outs[0], outs[1]))
+    dev = plan[0][0].weight.device
+    keep_dev = torch.tensor(keep_host, dtype=torch.long, device=dev)
+    ops.slice_batch(slices, keep_dev)
+    for layer, nm, w, g in assign:
+        newp = nn.Parameter(w)
+        newp.grad = g
+        setattr(layer, nm, newp)
+    for layer, dim, names, attr, idxs in plan:
+        setattr(layer, attr, getattr(layer, attr) - len(set(idxs)))
+    return True
 
 
 def _member_kind(dep):
@@ -378,6 +457,51 @@ class TaylorImportance(Importance):
             ops.wg_reduce(w.contiguous(), g.contiguous(), dim, _MODES[self.mode], full, False, self._scratch)
         return full, n_full
 
+    def _score_batched(self, terms, n0, dev):
+        """All members of the group through ops.group_score (two launches): the same per-member reductions and the same
+        member order as the loop below, hence the same bits.  Returns (score, members used) or None (not applicable)."""
+        members, idx_host, need = [], [], 0
+        for layer, kind, idxs in terms:
+            if len(idxs) != n0:             # importance.py:422-426: mis-sized members are dropped
+                continue
+            w, g = layer.weight.data, layer.weight.grad
+            if g is None:
+                raise RuntimeError('TaylorImportance needs accumulated gradients (run the sweep before pruner.step())')
+            g = g.data
+            if not (w.is_contiguous() and g.is_contiguous()) or w.device != dev:
+                return None
+            if kind == 'gn':
+                m = dict(R=w.shape[0], C=1, T=1, dim=0, mode=3)
+                n_full = w.shape[0]
+            else:
+                dim = 0 if kind == 'out' else 1
+                if getattr(layer, 'transposed', False):
+                    dim = 1 - dim
+                T = 1
+                for v in w.shape[2:]:
+                    T *= v
+                m = dict(R=w.shape[0], C=w.shape[1] if w.dim() > 1 else 1, T=T, dim=dim, mode=_MODES[self.mode])
+                n_full = w.shape[dim]
+            m.update(w=w, g=g, full_off=0, col_off=0, idx_off=-1)
+            if m['mode'] != 3 and m['dim'] == 1:
+                m['col_off'] = need
+                need += m['C'] * m['T']
+            else:
+                m['full_off'] = need
+                need += n_full
+            if not (n_full == n0 and idxs[0] == 0 and idxs[-1] == n0 - 1):
+                m['idx_off'] = len(idx_host)
+                idx_host.extend(idxs)
+            members.append(m)
+        if not members:
+            return None
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
+            self._scratch = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=dev)
+        idx_dev = torch.tensor(idx_host, dtype=torch.long, device=dev) if idx_host else None
+        score = torch.empty(n0, dtype=torch.float32, device=dev)
+        ops.group_score(members, n0, idx_dev, self._scratch, score)
+        return score, len(members)
+
     @torch.no_grad()
     def __call__(self, group, ch_groups=1):
         terms = []
@@ -394,9 +518,10 @@ class TaylorImportance(Importance):
             return None
         n0 = len(terms[0][2])
         dev = terms[0][0].weight.device
-        score = torch.zeros(n0, dtype=torch.float32, device=dev)
-        used = 0
-        for layer, kind, idxs in terms:
+        batched = self._score_batched(terms, n0, dev) if PRUNE_BATCH and hasattr(ops, 'group_score') else None      # None: member by member
+        score = torch.zeros(n0, dtype=torch.float32, device=dev) if batched is None else batched[0]
+        used = 0 if batched is None else batched[1]
+        for layer, kind, idxs in (terms if batched is None else ()):
             if len(idxs) != n0:             # importance.py:422-426: mis-sized members are dropped
                 continue
             full, n_full = self._member_score(layer, kind, idxs, n0)

@@ -250,6 +250,27 @@ int dp_wg_reduce(const float* w, const float* g, int R, int C, int T, int dim, i
 /* dst[i] += src[idx[i]], i < n : adds one member's channel sums into the group score (importance.py:427-428). */
 int dp_gather_add(const float* src, const int64_t* idx, int n, float* dst, void* stream);
 
+/* Batched forms for the prune tail (one launch pair per GROUP of coupled layers instead of two or three per member):
+ * dp_group_score = the dp_wg_reduce of every member + the dp_axpby / dp_gather_add chain that folds them into the group
+ * score (importance.py:375-434), same per-member arithmetic and member order, hence the same bits.  Member i views its
+ * weight / gradient as [R][C][T]; dim / mode as in dp_wg_reduce (mode 3 = GroupNorm member, R channels); its per-channel
+ * vector lives at scratch[full_off ...] (R or C floats), dim-1 members also need C*T floats at scratch[col_off ...];
+ * idx_off >= 0: score[j] += vector[idx[idx_off + j]], idx_off < 0: identity.  blk0 is filled by the launcher.
+ * dp_slice_batch = function.py:85-146,168-207,274-302 for every tensor of a group: dst = the kept channels (keep[keep_off ..
+ * keep_off + n_keep), ascending) of src along `dim` of its [R][C][T] view.  blk0 / nblk are filled by the launcher. */
+typedef struct dp_score_member {
+    const float* w; const float* g;
+    int R, C, T, dim, mode, blk0;
+    long long full_off, col_off, idx_off;
+} dp_score_member;
+int dp_group_score(const dp_score_member* members, int n, int n0, const int64_t* idx, float* scratch, float* score, void* stream);
+typedef struct dp_slice_item {
+    const float* src; float* dst;
+    int R, C, T, dim, n_keep, blk0, nblk, _pad;
+    long long keep_off;
+} dp_slice_item;
+int dp_slice_batch(const dp_slice_item* items, int n, const int64_t* keep, void* stream);
+
 /* Fused finetune update over flat buffers (ddpm_train.py:462-469, training_utils.py:201-216):
  *   g *= clip_coef (clip_coef read from device: min(1, max_norm/(norm+1e-6)));  Adam;  EMA with constant decay. */
 int dp_sumsq_partials(const float* x, long long n, float* partial, int nblocks, void* stream);

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 _real = None
+IS_MOCK = True
 
 
 def _spec_cls():
@@ -413,6 +414,31 @@ def wg_reduce(w, g, dim, mode, out, accumulate, scratch=None):
             v = q.abs().pow(2).sum(1) if mode == 0 else (q.abs().sum(1) if mode == 1 else q.sum(1).abs())
     out.copy_(out + v if accumulate else v)
     return out
+
+
+def group_score(members, n0, idx_dev, scratch, score):
+    """dp_group_score through the per-member stand-ins above, in member order."""
+    acc = torch.zeros(n0, dtype=torch.float32)
+    for m in members:
+        w, g = m['w'], m['g']
+        n_full = m['R'] if (m['mode'] == 3 or m['dim'] == 0) else m['C']
+        full = torch.zeros(n_full, dtype=torch.float32)
+        if m['mode'] == 3:
+            wg_reduce(w, g, 0, 3, full, False)
+        else:
+            wg_reduce(w.reshape(m['R'], m['C'], m['T']), g.reshape(m['R'], m['C'], m['T']), m['dim'], m['mode'], full, False)
+        if m['idx_off'] >= 0:
+            acc = acc + full[idx_dev[m['idx_off']:m['idx_off'] + n0]]
+        else:
+            acc = acc + full
+    score.copy_(acc)
+    return score
+
+
+def slice_batch(items, keep_dev):
+    for src, dst, R, C, T, dim, nk, off in items:
+        keep = keep_dev[off:off + nk]
+        dst.copy_(src.reshape(R, C, T).index_select(dim, keep).reshape(dst.shape))
 
 
 def gather_add(src, idx, dst):

@@ -1240,3 +1240,42 @@ def test_c2_cifar_batch256_1000_steps_as_written(report):
     assert len(pr_full.records) == len(pr_sum.records) == 50 and not mism
     assert margin > 2 * e_score                                               # the decisions are not within rounding of each other
     assert sum(p.numel() for p in m_full.parameters()) == sum(p.numel() for p in m1.parameters())
+
+
+def test_batched_prune_tail_equals_member_by_member(report, monkeypatch):
+    """The prune tail's batched kernels (dp_group_score: all member reductions of a group in one launch + one fold;
+    dp_slice_batch: every weight / bias / gradient of the group in one launch) against the member-by-member path they replace
+    (dp_wg_reduce + dp_axpby / dp_gather_add per member, index_select per tensor): scores, masks, sliced weights AND sliced
+    gradients bit-identical over the whole sequential prune of the CIFAR UNet (50 groups) and of the LDM UNet (109 groups)."""
+    import time
+    pruning, sweep, ldm = pkg('pruning'), pkg('sweep'), pkg('ldm')
+    out = {}
+
+    def cifar():
+        m = make_model(gc.CIFAR_CFG, 0)
+        clean, noise = _inputs(4, 32)
+        _run_sweep(m, clean, noise, 3)
+        return m, (lambda mm: sweep.prune_model(mm, 0.3))
+
+    def ldm_tiny():
+        m, _ = _ldm_model_with_grads()
+        return m, _ldm_masks
+
+    for name, build in (('cifar', cifar), ('ldm', ldm_tiny)):
+        res = {}
+        for batch in (True, False, True):
+            monkeypatch.setattr(pruning, 'PRUNE_BATCH', batch)
+            m, prune = build()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pr = prune(m)
+            torch.cuda.synchronize()
+            res[batch] = (pr, m, (time.perf_counter() - t0) * 1e3)
+        (pa, ma, ta), (pb, mb, tb) = res[True], res[False]
+        assert len(pa.records) == len(pb.records) == (50 if name == 'cifar' else 109)
+        for ra, rb in zip(pa.records, pb.records):
+            assert ra[0] == rb[0] and ra[3] == rb[3] and torch.equal(ra[2], rb[2]), ra[0]      # root, mask, score bits
+        for (n1, p1), (n2, p2) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert n1 == n2 and torch.equal(p1, p2) and torch.equal(p1.grad, p2.grad), n1
+        out[name] = dict(batched_ms=ta, member_by_member_ms=tb, groups=len(pa.records))
+    report['e2e/prune_tail_batched'] = out
