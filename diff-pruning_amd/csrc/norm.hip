@@ -4,6 +4,7 @@
 // three times (mean, variance, apply) with the re-reads served by L2.  Reductions: wave shuffles then
 // a fixed-order 4-way LDS combine, so results are run-to-run deterministic.
 // The input may be a *virtual concat* of two tensors along channels (up-block torch.cat, unet_2d_blocks.py:2035).
+#include <cstdlib>
 #include "dp_common.h"
 
 #define GN_CACHE 32          // elements per thread kept in registers (256 threads -> 8192 per chunk)
@@ -187,6 +188,76 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
     }
 }
 
+// One WAVEFRONT per (image, group) for groups of up to 2048 elements (the 16 x 16 / 8 x 8 / 4 x 4 layers of the CIFAR UNet): no
+// LDS, no barrier -- the reductions are wave shuffles -- and the four groups of a workgroup run independently, so a CU holds up
+// to 32 groups in different phases instead of 8 workgroups that each stall at two barriers.  [measured, round 3,
+// tools/bench_gn.py, B = 256: 256 ch @ 8x8 23.3 -> 13.0 us, 256 ch @ 4x4 18.9 -> 12.5 us forward; groups of 4096 elements are
+// FASTER on the workgroup kernel (54 vs 59 us) and stay there.]  Lane l holds float4 elements l, l + 64, ... of the group chunk
+// (coalesced 1 KB wave loads); same two-pass mean / variance as the workgroup kernels (shuffle tree instead of the LDS combine).
+#define GN_WAVE_NV 8
+__global__ __launch_bounds__(256) void gn_fwd_wave_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int C, int HW, int G, float eps,
+                                                          int silu, float* __restrict__ y, long long y_img_stride,
+                                                          float* __restrict__ stats, DpDrop drop, int NG) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= NG) return;
+    const int lane = threadIdx.x & 63;
+    const int n = wid / G;
+    const int g = wid - n * G;
+    const int cpg = C / G;
+    const int HW4 = HW / 4;
+    const int cnt4 = cpg * HW4;
+    const int c_base = g * cpg;
+    const long long didx0 = ((drop.n_off + n) * C + (long long)g * cpg) * HW;
+    float4 xr[GN_WAVE_NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_WAVE_NV; ++i) {
+        const int e = lane + 64 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < cnt4) {
+            const int cl = e / HW4;
+            v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
+        }
+        xr[i] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = dp_wave_sum(s) / (float)(cnt4 * 4);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_WAVE_NV; ++i) {
+        if (lane + 64 * i < cnt4) {
+            const float4 v = xr[i];
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = dp_wave_sum(q) / (float)(cnt4 * 4);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        stats[(long long)wid * 2 + 0] = mean;
+        stats[(long long)wid * 2 + 1] = rstd;
+    }
+    float4* yb = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c_base * HW);
+#pragma unroll
+    for (int i = 0; i < GN_WAVE_NV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < cnt4) {
+            const int c = c_base + e / HW4;
+            const float ga = gamma[c], be = beta[c];
+            const float4 v = xr[i];
+            float4 o;
+            o.x = (v.x - mean) * rstd * ga + be;
+            o.y = (v.y - mean) * rstd * ga + be;
+            o.z = (v.z - mean) * rstd * ga + be;
+            o.w = (v.w - mean) * rstd * ga + be;
+            if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+            if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * e); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+            yb[e] = o;
+        }
+    }
+}
+
 extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                      long long x2_img_stride, const float* gamma, const float* beta, int N, int C, int HW,
                                      int G, float eps, int silu, float* y, long long y_img_stride, float* stats,
@@ -197,7 +268,11 @@ extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_spl
     GnSrc s{x1, x2, x2 ? c_split : C, x1_img_stride, x2_img_stride};
     const bool vec4 = (HW % 4 == 0) && (x1_img_stride % 4 == 0) && (x2_img_stride % 4 == 0) && (y_img_stride % 4 == 0) &&
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0);
-    if (vec4)
+    static const bool no_wave = getenv("DP_NO_GN_WAVE") != nullptr;
+    if (vec4 && !no_wave && (long long)(C / G) * HW <= 256 * GN_WAVE_NV && N * G >= 1024)      // <= 512 float4 per group
+        DP_LAUNCH(gn_fwd_wave_kernel, dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
+                           silu, y, y_img_stride, stats, dd, N * G);
+    else if (vec4)
         DP_LAUNCH(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
                            silu, y, y_img_stride, stats, dd);
     else
@@ -407,6 +482,94 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
     }
 }
 
+// Backward, one wavefront per (image, group): HW / 4 is a power of two <= 64, so every wave-wide float4 step covers 64 / HW4
+// whole channels and the per-channel sums are segmented xor-shuffle reductions over HW4 lanes.  x-hat and dy stay in registers
+// between the two phases (the workgroup kernel re-reads them through L2 behind a barrier).  Fixed shuffle order: deterministic.
+__global__ __launch_bounds__(256) void gn_bwd_wave_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const float* __restrict__ dz, long long dz_img_stride, int C,
+                                                          int HW, int G, int silu, float* __restrict__ dx,
+                                                          long long dx_img_stride, const float* __restrict__ add1,
+                                                          long long add1_s, const float* __restrict__ add2, long long add2_s,
+                                                          float* __restrict__ pws, DpDrop drop, float* __restrict__ rows, int NG) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= NG) return;
+    const int lane = threadIdx.x & 63;
+    const int n = wid / G;
+    const int g = wid - n * G;
+    const int cpg = C / G;
+    const int HW4 = HW / 4;
+    const int cnt4 = cpg * HW4;
+    const int c_base = g * cpg;
+    const float mean = stats[(long long)wid * 2 + 0];
+    const float rstd = stats[(long long)wid * 2 + 1];
+    const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
+    const float4* dzc = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c_base * HW);
+    const bool leader = (lane & (HW4 - 1)) == 0;
+    float4 xh[GN_WAVE_NV], dv[GN_WAVE_NV];
+    float gam[GN_WAVE_NV];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_WAVE_NV; ++i) {
+        const int e = lane + 64 * i;
+        const bool live = e < cnt4;
+        const int cl = live ? e / HW4 : 0;
+        const int c = c_base + cl;
+        float4 xv = make_float4(mean, mean, mean, mean), d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            xv = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4];
+            d = dzc[e];
+        }
+        const float ga = gamma[c], be = beta[c];
+        float4 h;
+        h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+        if (drop.thr24 && live) { const float4 m = dp_drop4(drop, didx0 + 4ll * e); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+        if (silu) {
+            d.x *= dp_silu_grad(h.x * ga + be); d.y *= dp_silu_grad(h.y * ga + be);
+            d.z *= dp_silu_grad(h.z * ga + be); d.w *= dp_silu_grad(h.w * ga + be);
+        }
+        xh[i] = h; dv[i] = d; gam[i] = ga;
+        float s1 = (d.x + d.y) + (d.z + d.w);
+        float s2 = (d.x * h.x + d.y * h.y) + (d.z * h.z + d.w * h.w);
+        for (int o = HW4 >> 1; o > 0; o >>= 1) {                     // per-channel sums: segments of HW4 lanes
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if (live && leader) {
+            pws[((long long)n * C + c) * 2 + 0] = s1;
+            pws[((long long)n * C + c) * 2 + 1] = s2;
+            a += ga * s1;
+            b += ga * s2;
+        }
+    }
+    const float invM = 1.0f / (float)(cpg * HW);
+    a = dp_wave_sum(a) * invM;
+    b = dp_wave_sum(b) * invM;
+    float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
+    const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
+    const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < GN_WAVE_NV; ++i) {
+        const int e = lane + 64 * i;
+        const bool live = e < cnt4;
+        const float4 t1 = (a1b && live) ? a1b[e] : zero4, t2 = (a2b && live) ? a2b[e] : zero4;
+        const float ga = gam[i];
+        const float4 d = dv[i], h = xh[i];
+        float4 v;
+        v.x = rstd * (ga * d.x - a - h.x * b) + t1.x + t2.x;
+        v.y = rstd * (ga * d.y - a - h.y * b) + t1.y + t2.y;
+        v.z = rstd * (ga * d.z - a - h.z * b) + t1.z + t2.z;
+        v.w = rstd * (ga * d.w - a - h.w * b) + t1.w + t2.w;
+        if (live) dxb[e] = v;
+        if (rows) {
+            float r = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+            for (int o = HW4 >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            if (live && leader) rows[(long long)n * C + c_base + e / HW4] = r;
+        }
+    }
+}
+
 extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_split, long long x1_img_stride,
                                      long long x2_img_stride, const float* gamma, const float* beta, const float* stats,
                                      const float* dz, long long dz_img_stride, int N, int C, int HW, int G, int silu,
@@ -420,7 +583,14 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     const bool vec4 = (HW % 4 == 0) && ((x1_img_stride | x2_img_stride | dz_img_stride | dx_img_stride | add1_img_stride |
                                          add2_img_stride) % 4 == 0) &&
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dz | (uintptr_t)dx | (uintptr_t)add1 | (uintptr_t)add2) % 16 == 0);
-    if (vec4)
+    static const bool no_wave = getenv("DP_NO_GN_WAVE") != nullptr;
+    const int HW4 = HW / 4;
+    if (vec4 && !no_wave && HW4 >= 1 && HW4 <= 64 && (HW4 & (HW4 - 1)) == 0 && (long long)(C / G) * HW <= 256 * GN_WAVE_NV &&
+        N * G >= 1024)
+        DP_LAUNCH(gn_bwd_wave_kernel, dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                           dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
+                           pws, dd, rows, N * G);
+    else if (vec4)
         DP_LAUNCH(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
                            pws, dd, rows);
