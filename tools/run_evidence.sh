@@ -1,23 +1,36 @@
-# Round-2 evidence: GPU tests, bench line, rocprofv3 kernel summaries (default + serial), PMC traffic passes, secondary configs.
+# Round-3 evidence (one MI355X via gpurun).  usage: bash tools/run_evidence.sh tests|bench|profiles|pmc
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
-python -m pytest tests -m gpu -q --durations=8 > $O/round2_gpu_tests.log 2>&1; tail -14 $O/round2_gpu_tests.log
-python bench.py --steps 20 --warmup 5 > $O/round2_bench_line.json 2> $O/round2_bench_line.err; tail -c 600 $O/round2_bench_line.json
-stats() {  # name, env..., -- command
+R=round3
+stats() {  # name, -- command: rocprofv3 per-kernel summary of one bench.py configuration
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r2_prof_$name.log 2>&1
-  f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1); cp "$f" $O/round2_${name}_kernel_stats.csv 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r3_prof_$name.log 2>&1
+  f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1); cp "$f" $O/${R}_${name}_kernel_stats.csv 2>/dev/null
 }
-stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
-DP_NO_OVERLAP=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  DP_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r2_pmc_$ctr.log 2>&1
-done
-python tools/pmc_aggregate.py $O/round2_pmc_bench_traffic.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
-( python tools/bench_secondary.py; python tools/bench_bedroom.py 4; python tools/bench_ldm.py; python tools/bench_c1.py ) 2>&1 | grep -v amdgpu.ids > $O/round2_secondary_metrics.log
-cat $O/round2_secondary_metrics.log
-stats ldm python tools/bench_ldm.py
-stats c4_ddim python tools/bench_secondary.py
-stats bedroom python tools/bench_bedroom.py 4
-stats c1 python tools/bench_c1.py
+case "$1" in
+tests)
+  python -m pytest tests -m gpu -q --durations=10 > $O/${R}_gpu_tests.log 2>&1; tail -16 $O/${R}_gpu_tests.log
+  cp $O/test_report.json $O/${R}_test_report.json ;;
+bench)
+  python bench.py --steps 20 --warmup 5 > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 400 $O/${R}_bench_line.json
+  for c in bedroom256 c4_finetune ddim ldm; do
+    python bench.py --config $c > $O/${R}_bench_$c.json 2> $O/${R}_bench_$c.err; python -c "
+import json; d=json.load(open('$O/${R}_bench_$c.json')); r=d['roofline']
+print('$c', round(d['value'],2), d['unit'], round(d['ms_per_step'],2), 'ms/step; step_frac', round(r['step_frac'],3), 'ref-eq TF/s', round(r['step_tflops_reference_equivalent'],1), 'dominant', r['kernel'], round(r['achieved'],1))"
+  done
+  ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log ;;
+profiles)
+  stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
+  DP_NO_OVERLAP=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
+  stats c4_finetune python bench.py --config c4_finetune --no-roofline
+  stats ddim python bench.py --config ddim --no-roofline
+  stats ldm python bench.py --config ldm --no-roofline --steps 2 --warmup 1
+  stats bedroom256 python bench.py --config bedroom256 --no-roofline --no-cpu-baseline
+  ls -la $O/${R}_*kernel_stats.csv ;;
+pmc)
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    DP_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r3_pmc_$ctr.log 2>&1
+  done
+  python tools/pmc_aggregate.py $O/${R}_pmc_bench_traffic.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE ;;
+esac
