@@ -259,6 +259,8 @@ class FinetuneWorkload:
         return {'global_batch': self.env.world * self.B, 'image': '3x32x32', 'parallelism': 'dp%d (batch shards)' % self.env.world}
 
     def instrumented(self):
+        if self.env.world > 1:
+            return None            # the finetune step itself contains the gradient collectives: rank 0 cannot run one alone
         eng = self.model.engine()
         eng.overlap_wgrad = False
         ts = self._ts()
@@ -509,7 +511,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         # per-rank work of one step against this rank's kernels (weak scaling: 1/world of the units; ldm: this rank's latents)
         per_rank_units = units_per_step / world if wl.scaling == 'weak' else r['extra'].get('latents_this_rank', units_per_step)
-        roof = roofline(ops, wl.instrumented(), step_seconds, wl.flop_unit * per_rank_units)
+        one_step = wl.instrumented()
+        roof = roofline(ops, one_step, step_seconds, wl.flop_unit * per_rank_units) if one_step is not None else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.config)
