@@ -30,7 +30,8 @@ class ConvGemmParams(C.Structure):
                 ('alpha', C.c_float), ('post_scale', C.c_float),
                 ('bias', C.c_void_p), ('tadd', C.c_void_p), ('tadd_stride', LL),
                 ('res', C.c_void_p), ('r_img_stride', LL),
-                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('x_guard', C.c_int), ('act', C.c_int)]
+                ('accumulate', C.c_int), ('ksplit', C.c_int), ('ws', C.c_void_p), ('x_guard', C.c_int), ('act', C.c_int),
+                ('tile_counters', C.c_void_p)]
 
 
 class NtGemmParams(C.Structure):

@@ -237,6 +237,48 @@ extern "C" int dp_debug_read_clock(unsigned long long* out) {
 }
 #endif
 
+__device__ __forceinline__ float dp_splitk_sum(const float* __restrict__ ws, long long stride, int splits);
+
+// Split-K without a second launch: every workgroup stores its raw partial tile (conv_epilogue, ksplit branch), releases it
+// device-wide and takes a ticket from the tile's counter; the workgroup that draws the LAST ticket acquires, sums the ksplit
+// partials of the tile in ascending split order -- dp_splitk_sum, the order of conv_splitk_epilogue_kernel, so the result does
+// not depend on which workgroup happens to be last -- applies the epilogue and re-zeroes the counter for the next launch.
+// (The separate reduction launch was 4.5-9.5 % of the LDM / batch-4 steps: profiles/round2_{ldm,c1}_kernel_stats.csv.)
+template <int BM, int BN>
+__device__ __forceinline__ void conv_splitk_fold(const dp_conv_gemm_params& p, int m0, int n0) {
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // this thread's partial stores: visible to every XCD
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* c = p.tile_counters + ((unsigned)(m0 / BM) * gridDim.x + (unsigned)(n0 / BN));
+        const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned)p.ksplit - 1u) ? 1u : 0u;
+        if (s_last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const long long total = (long long)p.M * p.NPIX;
+    const int HoWo = p.g.Ho * p.g.Wo;
+    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+        const int r = e / BN, c = e - r * BN;
+        const int m = m0 + r, pix = n0 + c;
+        if (m >= p.M || pix >= p.NPIX) continue;
+        const float a = dp_splitk_sum(p.ws + ((long long)m * p.NPIX + pix), total, p.ksplit);
+        const int img = pix / HoWo;
+        const int r_in = pix - img * HoWo;
+        float v = p.alpha * a;
+        if (p.bias) v += p.bias[m];
+        if (p.tadd) v += p.tadd[(long long)img * p.tadd_stride + m];
+        if (p.res) v += p.res[(long long)img * p.r_img_stride + (long long)m * HoWo + r_in];
+        v *= p.post_scale;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        float* o = p.out + (long long)img * p.o_img_stride + (long long)m * HoWo + r_in;
+        if (p.accumulate) v += *o;
+        *o = v;
+    }
+}
+
 static unsigned dp_lds_pad() {
     static const unsigned pad = [] { const char* e = getenv("DP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
     return pad;
@@ -494,6 +536,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
     }
 #endif
     conv_epilogue<TM, TN, 32, 32>(p, acc, m0 + wm0, n0 + wn0, lane, z, ksplit);
+    if (ksplit && p.tile_counters) conv_splitk_fold<BM, BN>(p, m0, n0);
 }
 
 
@@ -824,6 +867,7 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
         }
     }
     conv_epilogue<TM, TN, TMS, TNS>(p, acc, m0 + wrow, n0 + wcol, lane, z, ksplit);
+    if (ksplit && p.tile_counters) conv_splitk_fold<BM, BN>(p, m0, n0);
 }
 
 static bool conv_fast_ok(const dp_conv_gemm_params& p) {
@@ -1011,7 +1055,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         case 2: e = launch_conv_gemm<64, 64>(p, st); break;
         default: return (int)hipErrorInvalidValue;
     }
-    if (e || p.ksplit <= 1) return e;
+    if (e || p.ksplit <= 1 || p.tile_counters) return e;
     long long nb = ((long long)p.M * p.NPIX + 255) / 256;
     if (nb > 8192) nb = 8192;
     DP_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);

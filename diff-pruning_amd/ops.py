@@ -169,6 +169,7 @@ def pick_tile(M, N, z=1):
 CONV_SPLITK_BLOCKS = int(os.environ.get('DP_CONV_SPLITK_BLOCKS', '512'))      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
 CONV_SPLITK_MID = not os.environ.get('DP_NO_SPLITK_MID')
 _n64 = os.environ.get('DP_CONV_N64', '0')         # default off: measured null (118.7 vs 124.4 TFLOP/s in isolation, 87.4 = 87.4 ms per step)
+CONV_N64_MAXK = int(os.environ.get('DP_CONV_N64_MAXK', '1000000'))      # ... and only K loops of at most this many K tiles
 CONV_N64_TILES = tuple(int(v) for v in _n64.split(',')) if _n64 not in ('0', '') else None      # [lo, hi) 128x128-tile counts run as 128x64
 
 
@@ -181,6 +182,7 @@ def _conv_ksplit(p, device):
     # the workgroups, so that the ramp / store burst of one round overlaps the K loop of the other.  Measured null: the
     # narrower tile loses in the K loop what the second round gains.
     if (CONV_N64_TILES and p.tile == 0 and p.batches <= 1 and CONV_N64_TILES[0] <= tiles < CONV_N64_TILES[1]
+            and p.ntaps * -(-p.C // 16) <= CONV_N64_MAXK
             and _conv_fast_ok(p) and _conv_x4_ok(p) and p.C % 16 == 0 and not (bool(p.X2) and p.g.c_split % 16)):
         p.tile = 4
         return
@@ -201,6 +203,26 @@ def _conv_ksplit(p, device):
             p.tile = 0 if p.M > 64 else 1
         p.ksplit = s
         p.ws = _p(_workspace(s * p.M * p.NPIX, device))
+        if SPLITK_FOLD:
+            bm, bn = (96, 128) if p.tile == 3 else _TILES[p.tile][:2]
+            p.tile_counters = _p(_tile_counters(-(-p.M // bm) * -(-p.NPIX // bn), device))
+
+
+SPLITK_FOLD = not os.environ.get('DP_NO_SPLITK_FOLD')     # split-K partials reduced by the last-arriving workgroup (no second launch)
+_tc_cache = {}
+
+
+def _tile_counters(n, device):
+    """Zeroed per-tile counters for dp_conv_gemm's in-kernel split-K reduction: one buffer per (device, stream) -- every
+    launch leaves them zero again, launches of one stream are ordered; a fresh one inside a stream capture (see _workspace)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
+    t = _tc_cache.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
+        _tc_cache[key] = t
+    return t
 
 
 def roundup4(n):

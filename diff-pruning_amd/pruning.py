@@ -16,6 +16,7 @@ import abc
 import os
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -336,15 +337,17 @@ def _prune_group_batched(items):
                 return False          # host-side structure edits (history replay on a CPU model) slice member by member
             seen.add((id(layer), nm))
         plan.append((layer, dim, names, attr, idxs))
-    keep_host, slices, assign = [], [], []
+    keep_host, slices, assign, off_next = [], [], [], 0
     for layer, dim, names, attr, idxs in plan:
         n = getattr(layer, attr)
-        drop = set(int(i) for i in idxs)
-        keep = [i for i in range(n) if i not in drop]
-        if not keep:
+        mask = np.ones(n, dtype=bool)
+        mask[np.asarray(idxs, dtype=np.int64)] = False
+        keep = np.nonzero(mask)[0]
+        if not len(keep):
             return False
-        off = len(keep_host)
-        keep_host.extend(keep)
+        off = off_next
+        off_next += len(keep)
+        keep_host.append(keep)
         for nm in names:
             p = getattr(layer, nm)
             d = dim if nm == 'weight' else 0
@@ -366,14 +369,14 @@ def _prune_group_batched(items):
                 outs.append(dst)
             assign.append((layer, nm, outs[0], outs[1]))
     dev = plan[0][0].weight.device
-    keep_dev = torch.tensor(keep_host, dtype=torch.long, device=dev)
+    keep_dev = torch.from_numpy(np.concatenate(keep_host)).to(dev)
     ops.slice_batch(slices, keep_dev)
     for layer, nm, w, g in assign:
         newp = nn.Parameter(w)
         newp.grad = g
-        setattr(layer, nm, newp)
+        layer._parameters[nm] = newp            # what Module.__setattr__ does for an existing parameter, minus its checks
     for layer, dim, names, attr, idxs in plan:
-        setattr(layer, attr, getattr(layer, attr) - len(set(idxs)))
+        object.__setattr__(layer, attr, getattr(layer, attr) - len(set(idxs)))
     return True
 
 
@@ -497,7 +500,7 @@ class TaylorImportance(Importance):
             return None
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
             self._scratch = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=dev)
-        idx_dev = torch.tensor(idx_host, dtype=torch.long, device=dev) if idx_host else None
+        idx_dev = torch.from_numpy(np.asarray(idx_host, dtype=np.int64)).to(dev) if idx_host else None
         score = torch.empty(n0, dtype=torch.float32, device=dev)
         ops.group_score(members, n0, idx_dev, self._scratch, score)
         return score, len(members)

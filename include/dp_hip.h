@@ -53,6 +53,11 @@ typedef struct dp_conv_gemm_params {
                                               loads of the stride-1 fast kernel read one element to the left of an image
                                               row for the shifted taps (overwritten with 0 in LDS); for the first row of the
                                               tensor that element lies in front of it.  0 = use the 4-byte loads. */
+    unsigned* tile_counters;               /* ksplit > 1, optional: one zero-initialised counter per output tile (grid x * grid y).
+                                              The LAST workgroup to deliver its partial tile sums the ksplit partials of that tile in
+                                              ascending split order (the same fixed order as the separate reduction kernel: same bits,
+                                              whoever arrives last), applies the epilogue and re-zeroes the counter; NULL = a second
+                                              launch does that. */
 } dp_conv_gemm_params;
 int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
 

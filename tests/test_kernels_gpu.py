@@ -863,3 +863,43 @@ def test_early_exit_ratio_state_machine(ops):
         st = state.cpu().tolist()
         assert int(st[2]) == len(want) and rec[:len(want)].cpu().tolist() == want and float(mx) == st[0]
         assert st[1] == (1.0 if len(want) < len(seq) else 0.0)
+
+
+@pytest.mark.parametrize('N,C1,C2,Cout,H,k', [(4, 200, 56, 256, 8, 3), (12, 960, 0, 960, 8, 1), (6, 576, 0, 576, 16, 3), (4, 192, 0, 192, 8, 3),
+                                               (3, 96, 0, 96, 4, 3), (2, 64, 64, 100, 4, 3)], ids=str)
+def test_conv_splitk_fold_equals_reduction_launch(ops, report, monkeypatch, N, C1, C2, Cout, H, k):
+    """Split-K partials reduced by the last-arriving workgroup (dp_conv_gemm_params.tile_counters) against the separate
+    reduction launch: same ascending-split summation whoever arrives last -> BIT-identical outputs, over 25 repetitions each
+    (the arrival order differs from run to run), with every epilogue operand (bias, per-image addend, residual, scale,
+    accumulate), for forward and input-gradient launches on the 128- and 96-row fast tiles and the general kernel."""
+    xa = rnd(N, C1, H, H, seed=1)
+    xb = rnd(N, C2, H, H, seed=2) if C2 else None
+    w = rnd(Cout, C1 + C2, k, k, seed=3, scale=0.02)
+    b, tadd, res = rnd(Cout, seed=4), rnd(N, Cout, seed=6), rnd(N, Cout, H, H, seed=7)
+    spec = ops.ConvSpec(k, 1, k // 2, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    wd, ldd = ops.pack_weight(w, 1)
+    dy = rnd(N, Cout, H, H, seed=5)
+    seen = []
+    real = ops._conv_ksplit
+    monkeypatch.setattr(ops, '_conv_ksplit', lambda p, d: (real(p, d), seen.append((p.ksplit, bool(p.tile_counters))))[0])
+
+    def run():
+        y = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7)
+        acc = res.clone()
+        ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc, accumulate=True)
+        d = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H), alpha=0.5)
+        return y.clone(), acc, d.clone()
+
+    monkeypatch.setattr(ops, 'SPLITK_FOLD', False)
+    ref = run()
+    assert seen and all(s[0] >= 2 and not s[1] for s in seen), seen
+    del seen[:]
+    monkeypatch.setattr(ops, 'SPLITK_FOLD', True)
+    n_bad = 0
+    for rep in range(25):
+        got = run()
+        n_bad += sum(0 if torch.equal(a, r) else 1 for a, r in zip(got, ref))
+    assert all(s[0] >= 2 and s[1] for s in seen), seen[:3]
+    report['conv/splitk_fold/%d_%d_%d_%d' % (C1 + C2, Cout, H, k)] = dict(ksplit=seen[0][0], mismatching_outputs_of_75=n_bad)
+    assert n_bad == 0
