@@ -208,7 +208,12 @@ def _conv_ksplit(p, device):
             p.tile_counters = _p(_tile_counters(-(-p.M // bm) * -(-p.NPIX // bn), device))
 
 
-SPLITK_FOLD = not os.environ.get('DP_NO_SPLITK_FOLD')     # split-K partials reduced by the last-arriving workgroup (no second launch)
+# Split-K partials reduced by the last-arriving workgroup instead of a second launch (dp_conv_gemm_params.tile_counters).
+# Bit-identical to the reduction launch (tests/test_kernels_gpu.py::test_conv_splitk_fold_equals_reduction_launch) and OFF:
+# [measured, round 3] the agent-scope release / acquire it needs compiles to a full L2 write-back + invalidate per wavefront
+# (buffer_wbl2 sc1 / buffer_inv sc1; 8 XCDs with private L2s) -- LDM CFG forward 27.6 -> 41.9 ms, CIFAR batch 4 11.0 -> 35.7 ms
+# per timestep.  The ~12 us reduction launches it would have removed (5.6 % of the LDM step) are the cheaper evil.
+SPLITK_FOLD = bool(os.environ.get('DP_SPLITK_FOLD'))
 _tc_cache = {}
 
 
