@@ -431,7 +431,8 @@ class UNetEngine:
         n1, st1 = ops.groupnorm_fwd(xa, xb, P[pre + nm['norm1'] + '.weight'], P[pre + nm['norm1'] + '.bias'], G, eps, True)
         if self._temb is not None:
             o, c = self._temb[1][pre]
-            tproj = self._temb[2][:, o:o + c]          # column slice of the batched projection (row stride = sum C)
+            tproj = self._temb[2][:xa.shape[0], o:o + c]   # column slice of the batched projection (row stride = sum C); the
+                                                           # rows of this block's images (LdmEngine: shared CFG stem)
         else:
             tproj = self._linear(pre + nm['temb'], semb)
         h = self._conv(pre + nm['conv1'], n1, None, _SPEC3, tadd=tproj)

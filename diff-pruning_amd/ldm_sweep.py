@@ -21,6 +21,7 @@ max-loss / threshold state lives on the device (`dp_early_exit_update_ratio`): t
 (`dp_zero_if_stopped`), the host reads the stop flag one step late from pinned memory, so no step waits for the host.
 """
 import contextlib
+import os
 import random
 
 import numpy as np
@@ -28,6 +29,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
+
+CFG_SHARED_STEM = not os.environ.get('DP_NO_CFG_SHARED_STEM')
 
 
 class LdmSchedule:
@@ -89,9 +92,13 @@ def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0
 
 
 def _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B):
+    pair = getattr(model, 'forward_cfg_pair', None) if CFG_SHARED_STEM else None
     for i in reversed(range(len(steps))):
-        t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
-        e = model(torch.cat([x, x]), t, context=ctx2)
+        if pair is not None:                 # [x; x] against [uncond; cond]: the context-free stem runs once (LdmEngine.forward)
+            e = pair(x, torch.full((B,), int(steps[i]), dtype=torch.long, device=x.device), ctx2)
+        else:
+            t = torch.full((2 * B,), int(steps[i]), dtype=torch.long, device=x.device)
+            e = model(torch.cat([x, x]), t, context=ctx2)
         e_t = ops.cfg_combine(e[:B], e[B:], scale)
         x = ops.ddim_step(x, e_t, float(a[i]), float(a_prev[i]), float(sig[i]), None, clip=False)
     return x
