@@ -463,6 +463,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the timestep from a captured hipGraph (sweep configs)')
+    ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' with ranks sharing a GPU is a logic check of the N > 1 path on a 1-GPU box, not a measurement")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = DEFAULT_STEPS[args.config][0]
@@ -481,8 +482,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group(args.backend)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
         world = dist.get_world_size()
     dev = torch.device('cuda', local_rank)
@@ -529,6 +534,8 @@ def main():
         out = {'metric': wl.metric, 'value': r['units'] / t_total, 'unit': wl.unit, 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': step_seconds * 1e3, 'higher_is_better': True, 'scaling': wl.scaling,
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': cfg, 'roofline': roof, 'cpu_baseline': cpu}
+        if args.backend != 'nccl':
+            out['config']['backend'] = args.backend + ' (logic check, not a measurement)'
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
