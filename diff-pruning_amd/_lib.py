@@ -62,6 +62,11 @@ class SliceItem(C.Structure):
                 ('n_keep', C.c_int), ('blk0', C.c_int), ('nblk', C.c_int), ('_pad', C.c_int), ('keep_off', LL)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('dst', C.c_void_p), ('Co', C.c_int), ('Ci', C.c_int), ('taps', C.c_int), ('mode', C.c_int),
+                ('ld', C.c_int), ('blk0', C.c_int), ('nblk', C.c_int), ('_pad', C.c_int)]
+
+
 class ColsumItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('wstride', C.c_int),
                 ('woff', C.c_int), ('accumulate', C.c_int), ('ld', C.c_int)]
@@ -78,6 +83,7 @@ SIGNATURES = {
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
     'dp_splitk_reduce_taps': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp],
     'dp_pack_weight': [_vp, _i, _i, _i, _i, _vp, _i, _vp],
+    'dp_pack_weight_batch': [C.POINTER(PackItem), _i, _vp],
     'dp_groupnorm_silu_fwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _ll, _vp, _dr, _vp],
     'dp_groupnorm_silu_bwd': [_vp, _vp, _i, _ll, _ll, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll,
                               _vp, _ll, _vp, _dr, _vp, _vp],

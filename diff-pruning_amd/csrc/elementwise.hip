@@ -939,3 +939,57 @@ extern "C" int dp_mse_per_image(const float* a, const float* b, int N, long long
     DP_LAUNCH(mse_per_image_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a, b, per, out);
     return DP_LAUNCH_CHECK();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// dp_pack_weight for MANY layers in one launch (same element map as pack_weight_kernel in gemm.hip): a finetune step re-packs
+// every convolution weight in both operand layouts after each optimizer update (~190 launches of ~6 us on the pruned CIFAR
+// UNet, ddpm_train.py:426-471); the packed operands are the "A" inputs of dp_conv_gemm (forward: [(tap, ci)][Cout], input
+// gradient: [(flipped tap, co)][Cin]).
+// ---------------------------------------------------------------------------------------------
+#define DP_PACK_BATCH 64
+struct PackBatch {
+    int n;
+    dp_pack_item it[DP_PACK_BATCH];
+};
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+    const dp_pack_item& it = b.it[i];
+    const int K = it.mode == 0 ? it.Ci : it.Co;
+    const int Mv = it.mode == 0 ? it.Co : it.Ci;
+    const long long total = (long long)it.taps * K * it.ld;
+    const long long step = (long long)it.nblk * 256;
+    for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
+        const int m = (int)(e % it.ld);
+        const long long rk = e / it.ld;
+        const int k = (int)(rk % K);
+        const int tap = (int)(rk / K);
+        float v = 0.f;
+        if (m < Mv) {
+            if (it.mode == 0) v = it.W[((long long)m * it.Ci + k) * it.taps + tap];
+            else              v = it.W[((long long)k * it.Ci + m) * it.taps + (it.taps - 1 - tap)];
+        }
+        it.dst[e] = v;
+    }
+}
+extern "C" int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stream) {
+    for (int lo = 0; lo < n; lo += DP_PACK_BATCH) {
+        PackBatch b;
+        b.n = (n - lo < DP_PACK_BATCH) ? n - lo : DP_PACK_BATCH;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.it[i] = items[lo + i];
+            dp_pack_item& it = b.it[i];
+            if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || (it.mode != 0 && it.mode != 1)) return (int)hipErrorInvalidValue;
+            const long long total = (long long)it.taps * (it.mode == 0 ? it.Ci : it.Co) * it.ld;
+            long long nb = (total + 1023) / 1024;
+            if (nb > 512) nb = 512;
+            it.blk0 = blocks;
+            it.nblk = (int)nb;
+            blocks += (int)nb;
+        }
+        DP_LAUNCH(pack_weight_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return DP_LAUNCH_CHECK();
+}

@@ -82,6 +82,13 @@ class _Packs:
         self._c[key] = (tag, buf, ld)
         return buf, ld
 
+    def has(self, name, w, mode):
+        hit = self._c.get((name, mode))
+        return hit is not None and hit[0] == (w.data_ptr(), w._version, tuple(w.shape))
+
+    def put(self, name, w, mode, buf, ld):
+        self._c[(name, mode)] = ((w.data_ptr(), w._version, tuple(w.shape)), buf, ld)
+
     def get_weff(self, name, w):
         """[4, Cout, Cin, 2, 2] class kernels of the upsample convolution `name` (ops.ups_weff), cached like the packs."""
         key = (name, 'weff')
@@ -284,11 +291,20 @@ class UNetEngine:
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
-        must not be recorded into the replayed graph)."""
+        must not be recorded into the replayed graph; and once per finetune step, whose optimizer update invalidates every
+        pack): all of them in a few batched launches (ops.pack_weight_batch)."""
+        todo = []
         for name, w in self.P.items():
             if name.endswith('.weight') and w.dim() >= 2:
-                self.packs.get(name[:-7], w, 0)
-                self.packs.get(name[:-7], w, 1)
+                for mode in (0, 1):
+                    if not self.packs.has(name[:-7], w, mode):
+                        todo.append((name[:-7], w, mode))
+        if hasattr(ops, 'pack_weight_batch') and todo and all(w.is_contiguous() for _, w, _ in todo):
+            for (name, w, mode), (buf, ld) in zip(todo, ops.pack_weight_batch([(w, mode) for _, w, mode in todo])):
+                self.packs.put(name, w, mode, buf, ld)
+        else:
+            for name, w, mode in todo:
+                self.packs.get(name, w, mode)
 
     def attn_scale(self, channels):
         hd = self.cfg.get('attention_head_dim')

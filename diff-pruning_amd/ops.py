@@ -246,6 +246,25 @@ def pack_weight(w, mode):
     return dst, ld
 
 
+def pack_weight_batch(ws_modes):
+    """pack_weight for a list of (weight, mode) in ceil(n / 64) launches; returns [(packed, ld), ...] in order."""
+    n = len(ws_modes)
+    arr = (L.PackItem * n)()
+    out = []
+    for a, (w, mode) in zip(arr, ws_modes):
+        assert w.is_cuda and w.dtype == _f32 and w.is_contiguous(), 'pack_weight_batch takes contiguous fp32 device weights'
+        Co, Ci = w.shape[0], w.shape[1]
+        taps = w[0, 0].numel() if w.dim() == 4 else 1
+        K = Ci if mode == 0 else Co
+        ld = roundup4(Co if mode == 0 else Ci)
+        dst = torch.empty(taps * K * ld, dtype=_f32, device=w.device)
+        a.W, a.dst, a.Co, a.Ci, a.taps, a.mode, a.ld = w.data_ptr(), dst.data_ptr(), Co, Ci, taps, mode, ld
+        out.append((dst, ld))
+    if n:
+        L.check(_lib().dp_pack_weight_batch(arr, n, _stream()), 'dp_pack_weight_batch')
+    return out
+
+
 def _geom(Ho, Wo, Hs, Ws, Hv, Wv, kw, stride, sden, pad_t, pad_l, ups, c_split, s1, s2):
     g = L.ConvGeom()
     g.Ho, g.Wo, g.Hs, g.Ws, g.Hv, g.Wv = Ho, Wo, Hs, Ws, Hv, Wv

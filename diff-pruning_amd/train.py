@@ -227,6 +227,8 @@ class FinetuneEngine:
         eng = model.engine()
         eng.bind({n: p.detach() for n, p in model.named_parameters()}, {n: p.grad for n, p in model.named_parameters()})
         eng.set_dropout(getattr(model, 'dropout_table', dict)(), self.dropout_seed, self.step_count + 1, image_offset)
+        if hasattr(ops, 'pack_weight_batch'):
+            eng.prepare_packs()          # the last optimizer step invalidated every packed operand: re-pack in a few launches
         # the batched time-embedding backward finalises the time_emb_proj gradients only at the END of the backward pass: it is
         # switched off when gradient buckets are all-reduced at the segment milestones
         eng.temb_batch = eng.temb_batch and not use_dist

@@ -349,6 +349,13 @@ int dp_replay_launch(void* handle, void* main_stream, void* side_stream);
 int dp_replay_info(void* handle, int* info8);
 int dp_replay_free(void* handle);
 
+/* dp_pack_weight for many layers in one launch (blk0 / nblk are filled by the launcher). */
+typedef struct dp_pack_item {
+    const float* W; float* dst;
+    int Co, Ci, taps, mode, ld, blk0, nblk, _pad;
+} dp_pack_item;
+int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stream);
+
 int dp_version(void);
 /* Number of kernel launches this library has issued since it was loaded (host counter; bench.py reports launches per step).
  * Returned in place of an error code. */

@@ -903,3 +903,14 @@ def test_conv_splitk_fold_equals_reduction_launch(ops, report, monkeypatch, N, C
     assert all(s[0] >= 2 and s[1] for s in seen), seen[:3]
     report['conv/splitk_fold/%d_%d_%d_%d' % (C1 + C2, Cout, H, k)] = dict(ksplit=seen[0][0], mismatching_outputs_of_75=n_bad)
     assert n_bad == 0
+
+
+def test_pack_weight_batch_equals_per_layer_pack(ops):
+    """dp_pack_weight_batch (every layer of a finetune step in a few launches) against dp_pack_weight, element for element:
+    3x3 / 1x1 convolutions and a Linear, both operand layouts, widths that need the ld padding (90 -> 92)."""
+    ws = [rnd(90, 45, 3, 3, seed=1), rnd(128, 256, 1, 1, seed=2), rnd(33, 70, seed=3), rnd(192, 192, 3, 3, seed=4), rnd(3, 96, 3, 3, seed=5)]
+    items = [(w, m) for w in ws for m in (0, 1)] * 9                       # > 64 items: more than one launch
+    got = ops.pack_weight_batch(items)
+    for (w, m), (buf, ld) in zip(items, got):
+        ref, ld0 = ops.pack_weight(w, m)
+        assert ld == ld0 and torch.equal(buf, ref)
