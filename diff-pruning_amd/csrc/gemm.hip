@@ -1042,8 +1042,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         case 3:                                                  // 96x128: fast kernel only, else the 128x128 path
             if (conv_fast_ok(p)) {
                 dim3 grid((p.NPIX + 127) / 128, (p.M + 95) / 96, p.ksplit > 1 ? p.ksplit : (p.batches > 0 ? p.batches : 1));
-                if (conv_fast_tails(p)) launch_conv_fast<96, true>(p, grid, st);
-                else                    launch_conv_fast<96, false>(p, grid, st);      // 96 / 192 / 384 ... channel layers: whole chunks
+                launch_conv_fast<96, true>(p, grid, st);
                 e = DP_LAUNCH_CHECK();
                 break;
             }

@@ -79,7 +79,7 @@ def _cg_name(p):
     if p.tile == 4 and _conv_fast_ok(p) and _conv_x4_ok(p) and p.C % 16 == 0 and not (bool(p.X2) and p.g.c_split % 16):
         return 'conv_gemm_fast_kernel<128, 64, false, true>'
     if p.tile in (0, 3, 4) and _conv_fast_ok(p):
-        tails = p.C % 16 != 0 or (bool(p.X2) and p.g.c_split % 16 != 0)
+        tails = p.tile == 3 or p.C % 16 != 0 or (bool(p.X2) and p.g.c_split % 16 != 0)
         return 'conv_gemm_fast_kernel<%s, %s, %s>' % ('128, 128' if p.tile != 3 else '96, 128', 'true' if tails else 'false',
                                                       'true' if _conv_x4_ok(p) else 'false')
     straddle = bool(p.X2) and (p.g.c_split % 16) != 0
