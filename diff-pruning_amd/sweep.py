@@ -275,7 +275,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         raise ValueError('use_graph replays forward + backward as one unit: not available with accumulate_breaking_step=False')
     on_device = (thr is not None and device_exit and (not use_graph or stop_state is not None)
                  and isinstance(step_fn, HipSweepStep) and hasattr(ops, 'early_exit_update')
-                 and clean_images.device.type == 'cuda')
+                 and (clean_images.device.type == 'cuda' or getattr(ops, 'IS_MOCK', False)))
     if on_device:
         # The early-exit state lives on the device: no host read of the loss per step.  Timesteps enqueued after the stop are
         # exact no-ops (dOut = 0), the host looks at the flag every `poll_every` steps, and the scalar-loss all-reduce of the

@@ -68,6 +68,12 @@ def main():
     # Diff-Pruning sweep with early exit: every rank must stop at the same step, grads summed once at the end
     res = pkg('sweep').taylor_sweep(model, sched, clean[sl], noise[sl], num_steps=50, thr=0.995)
     grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    # the same sweep with the loss read on the host after every step (the reference's own control flow) instead of the on-device
+    # early-exit state machine polled every 8 steps: same stop step, same losses, same gradients -- the steps the host had
+    # enqueued past the stop are exact no-ops
+    res_h = pkg('sweep').taylor_sweep(model, sched, clean[sl], noise[sl], num_steps=50, thr=0.995, device_exit=False)
+    assert res_h['steps'] == res['steps'] and res_h['losses'] == res['losses']
+    assert all(torch.equal(p.grad, grads[n]) for n, p in model.named_parameters())
     pr = pkg('sweep').prune_model(model, 0.3)
     masks = [r[3] for r in pr.records]
     # finetune (config C4): two optimizer steps on the pruned model with dropout 0.1 (scripts/finetune_ddpm_cifar10.sh:16)
