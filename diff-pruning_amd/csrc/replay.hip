@@ -142,7 +142,7 @@ extern "C" int dp_replay_build(void* graph_v, void** out) {
                 r.kind = KERNEL;
                 memset(&r.k, 0, sizeof(r.k));
                 RP_CHECK(hipGraphKernelNodeGetParams(gn[i], &r.k));
-                if (!r.k.func || (!r.k.kernelParams && !r.k.extra)) { err = (int)hipErrorInvalidValue; goto fail; }
+                if (!r.k.func || !r.k.kernelParams) { err = (int)hipErrorNotSupported; goto fail; }     // `extra`-style launches: not re-issued
                 ++rp->n_kernel;
             } else if (ty == hipGraphNodeTypeMemset) {
                 r.kind = MEMSET;

@@ -191,7 +191,10 @@ class HipSweepStep:
         self._graph = g
         self._replay = None
         if native:
-            self._replay = ops.ReplayList(g)               # raises when the graph holds a node it cannot re-issue
+            try:
+                self._replay = ops.ReplayList(g)
+            except Exception:                              # a node the list cannot re-issue: replay through hipGraphLaunch instead
+                g.instantiate()
         return self
 
     def __call__(self, k):
