@@ -450,7 +450,7 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step):
                 step_tflops_reference_equivalent=flop_reference_per_step / step_seconds / 1e12)
 
 
-DEFAULT_STEPS = {'cifar256': (20, 2), 'bedroom256': (8, 2), 'c4_finetune': (20, 3), 'ddim': (40, 5), 'ldm': (3, 1)}
+DEFAULT_STEPS = {'cifar256': (20, 2), 'bedroom256': (20, 2), 'c4_finetune': (20, 3), 'ddim': (40, 5), 'ldm': (4, 1)}
 
 
 def main():
