@@ -1634,3 +1634,24 @@ def _ranges(idxs):
         else:
             out.append([i, i + 1])
     return out
+
+
+def test_latent_shards_and_bench_configs():
+    """Host logic of round 3: the uneven latent shards of the data-parallel LDM pass (6 over 4 = 2, 2, 1, 1; every latent exactly
+    once, contiguous, no empty rank unless there are fewer latents than ranks) and the bench.py contract (every --config has
+    default step counts, the default is BASELINE configs[1])."""
+    sb = pkg('ldm_sweep').shard_bounds
+    assert [sb(6, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 6)]
+    for n in range(1, 13):
+        for w in range(1, 9):
+            parts = [sb(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    import ast
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read()
+    tree = ast.parse(src)
+    defaults = next(ast.literal_eval(n.value) for n in ast.walk(tree) if isinstance(n, ast.Assign)
+                    and getattr(n.targets[0], 'id', None) == 'DEFAULT_STEPS')
+    assert set(defaults) == {'cifar256', 'bedroom256', 'c4_finetune', 'ddim', 'ldm'} and all(k > 0 and w >= 0 for k, w in defaults.values())
+    assert "default='cifar256'" in src and 'configs[1]' in src

@@ -1279,3 +1279,31 @@ def test_batched_prune_tail_equals_member_by_member(report, monkeypatch):
             assert n1 == n2 and torch.equal(p1, p2) and torch.equal(p1.grad, p2.grad), n1
         out[name] = dict(batched_ms=ta, member_by_member_ms=tb, groups=len(pa.records))
     report['e2e/prune_tail_batched'] = out
+
+
+def test_rank_sharded_sampling_to_dir_and_fid_features(report, tmp_path):
+    """ddpm_sample.py:55-74 on the device: rank 1 of 2 samples total // (batch * world) batches into `process_1/` from the
+    generator seeded seed + 1 -- the PNGs are the pipeline's own images for that generator, and the FID features accumulated on
+    the fly (Inception on the HIP kernels, seeded weights) equal the features of the PNGs read back through the directory path."""
+    from PIL import Image
+    from helpers import inception_state_dict
+    diffusion, metrics = pkg('diffusion'), pkg('metrics')
+    model = make_model(gc.TINY_CFG, 5)
+    pipe = diffusion.DDIMPipeline(model, diffusion.DDIMScheduler())
+    net = metrics.InceptionV3([3], state_dict=inception_state_dict(3)).to(DEV)
+    stats = metrics.FeatureStats(2048, torch.device(DEV))
+    n = metrics.sample_to_dir(pipe, str(tmp_path), total_samples=8, batch_size=2, seed=3, rank=1, world=2, num_inference_steps=4,
+                              stats=stats, inception=net)
+    assert n == 4
+    files = sorted((tmp_path / 'process_1').iterdir(), key=lambda f: int(f.stem))
+    assert [f.name for f in files] == ['0.png', '1.png', '2.png', '3.png'] and not (tmp_path / 'process_0').exists()
+    gen = torch.Generator().manual_seed(3 + 1)
+    want = np.concatenate([pipe(batch_size=2, generator=gen, num_inference_steps=4, output_type='numpy').images for _ in range(2)])
+    got = np.stack([np.asarray(Image.open(f), dtype=np.uint8) for f in files])
+    assert np.array_equal(got, (want * 255).round().astype('uint8'))
+    mu, sigma = stats.finalize()
+    mu2, sigma2 = metrics.compute_statistics_of_path(str(tmp_path / 'process_1'), net, 2, 2048, DEV)
+    e_mu = float(np.abs(mu - mu2).max() / max(np.abs(mu2).max(), 1e-30))
+    e_sg = float(np.abs(sigma - sigma2).max() / max(np.abs(sigma2).max(), 1e-30))
+    report['e2e/sample_to_dir'] = dict(images=n, mu_rel=e_mu, sigma_rel=e_sg)
+    assert e_mu < 1e-5 and e_sg < 1e-4
