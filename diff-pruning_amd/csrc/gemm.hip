@@ -1262,17 +1262,7 @@ template <int NW, bool TWO>
 __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_gemm_params p) {
     constexpr int BM = 32 * NW, BN = 32 * NW, BK = 16;
     constexpr int TM = (NW == 4) ? 2 : 1, TN = (NW == 4) ? 2 : 3;
-#ifdef DP_NT_OLD_LDS
     constexpr int GRP = 4 * BK + 1;                 // dwords per 4-row group
-    constexpr int KST = 1;                          // dwords between consecutive pixels of a row in the LDS image
-#else
-    // [16 pixels][4 rows] + 4 pad dwords per group: a fragment read (lane li -> row li, fixed pixel) touches bank 4 * (li >> 2)
-    // + (li & 3) -- 32 distinct banks.  The row-major [4 rows][16 pixels] + 1 image put rows r and r + 2 of a group 32 dwords
-    // apart: 2-way conflicts on every fragment read on 32 banks (SQ_LDS_BANK_CONFLICT 1.6e7 cycles per launch against
-    // 1.7e6 in the convolution kernel, profiles/round3_pmc_mfma.md).
-    constexpr int GRP = 4 * BK + 4;
-    constexpr int KST = 4;
-#endif
     constexpr int OP_SZ = (BM / 4) * GRP;           // 2080 dwords per operand tile
     constexpr int STAGE = 2 * OP_SZ;
     __shared__ float smem[2 * STAGE];
@@ -1328,11 +1318,7 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
     const __amdgpu_buffer_rsrc_t rB2 = dp_rsrc((p.X2 ? p.X2 : p.X1) - shift, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)shift);
 
     // ---- per-lane constants: pixel lk of the K tile, row sub of each 4-row group; this wave owns groups wave*8 .. +7
-#ifdef DP_NT_OLD_LDS
     const int lk = lane & 15, sub = lane >> 4;
-#else
-    const int lk = lane >> 2, sub = lane & 3;      // the DMA writes lane l to dword l of the group: pixel-major [lk][sub]
-#endif
     const int dho = lk / g.Wo, wol = lk - dho * g.Wo;
     const int hc = dho + ky - g.pad_t;
     const int wc = wol + kx - g.pad_l;
@@ -1397,13 +1383,13 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int li = lane & 31, lkk = lane >> 5;
-    auto rowoff = [](int row) { return (row >> 2) * GRP + (row & 3) * (KST == 1 ? BK : 1); };
+    auto rowoff = [](int row) { return (row >> 2) * GRP + (row & 3) * BK; };
     const float* fragA[TM];
     const float* fragB[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) fragA[t] = smem + rowoff(wm0 + 32 * t + li) + KST * lkk;
+    for (int t = 0; t < TM; ++t) fragA[t] = smem + rowoff(wm0 + 32 * t + li) + lkk;
 #pragma unroll
-    for (int t = 0; t < TN; ++t) fragB[t] = smem + OP_SZ + rowoff(wn0 + 32 * t + li) + KST * lkk;
+    for (int t = 0; t < TN; ++t) fragB[t] = smem + OP_SZ + rowoff(wn0 + 32 * t + li) + lkk;
 
     if (nIter > 0) {
         dma_tile(0, 0);
@@ -1429,7 +1415,7 @@ __global__ __launch_bounds__(NW * 64, 4) void nt_gemm_fast_kernel(const dp_nt_ge
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int cur = ks & 1;
                 if (ks + 1 < BK / 2) {
-                    const int o = bo + KST * 2 * (ks + 1);
+                    const int o = bo + 2 * (ks + 1);
 #pragma unroll
                     for (int t = 0; t < TM; ++t) a[cur ^ 1][t] = fragA[t][o];
 #pragma unroll
