@@ -47,7 +47,8 @@ class HipSweepStep:
     _half = None
     stop_state = None          # device [loss_max, stopped, steps] of the on-device Diff-Pruning early exit (taylor_sweep)
 
-    def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None, halves=None):
+    def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None, halves=None,
+                 timestep_pipelines=None):
         if clean.device.type != 'cuda':
             raise RuntimeError('the sweep runs on the MI355X HIP kernels only (no CPU fallback)')
         self.model, self.scheduler = model, scheduler
@@ -77,6 +78,18 @@ class HipSweepStep:
             halves = int(os.environ.get('DP_HALVES', '1'))
         if halves == 2 and self.B >= 2 and isinstance(self.eng, UNetEngine) and type(self.eng) is UNetEngine:
             self._setup_second_half()
+        # Two TIMESTEPS in flight (plain Taylor only: no step depends on another).  Timesteps of odd position run through a second
+        # engine -- same parameters, own context, own flat gradient buffer, own stream -- at the FULL batch, so the kernels keep
+        # their size (the half-batch pipelines above lost to their smaller launches) and the two independent kernel streams fill
+        # each other's ramps, tails and HBM-bound phases.  No cross-stream edge between the pipelines until finish().
+        if timestep_pipelines is None:
+            timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', '1'))
+        self._tp = None
+        if timestep_pipelines == 2 and self._half is None and type(self.eng) is UNetEngine:
+            self._setup_second_half()
+            self._tp, self._half = self._half, None
+            self._tp['eng'].set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off)
+            self._tp_count, self._tp_synced = 0, False
 
     def _setup_second_half(self):
         dev = self.clean.device
@@ -96,13 +109,14 @@ class HipSweepStep:
 
     def finish(self):
         """Fold the second pipeline's gradients into the parameters' .grad buffers (once per sweep)."""
-        if self._half is not None:
+        second = self._half if self._half is not None else getattr(self, '_tp', None)
+        if second is not None:
             cur = torch.cuda.current_stream()
-            cur.wait_stream(self._half['stream'])
+            cur.wait_stream(second['stream'])
             for n, g in self._G.items():
-                g2 = self._half['G'][n]
+                g2 = second['G'][n]
                 ops.axpby(g2.reshape(-1), 1.0, g.reshape(-1), 1.0)
-            self._half['flat'].zero_()
+            second['flat'].zero_()
 
     def _step(self, t):
         if self._half is not None and self.micro is None:
@@ -197,7 +211,26 @@ class HipSweepStep:
                 g.instantiate()
         return self
 
+    def _second_pipeline_step(self, k):
+        """Timestep k on the second pipeline's stream and engine (full batch, own gradient buffer)."""
+        tp = self._tp
+        if not self._tp_synced:          # once: inputs, schedule table and every packed operand (also the ones the first timestep
+            tp['stream'].wait_stream(torch.cuda.current_stream())      # packed lazily on the main stream) are complete
+            self._tp_synced = True
+        with torch.cuda.stream(tp['stream']):
+            t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
+            eng = tp['eng']
+            noisy = ops.add_noise(self.clean, self.noise, self.acp, t)
+            out = eng.forward(noisy, t, save=True)
+            loss, dout = ops.mse_fwd_bwd(out, self.noise, self.gscale, self.lscale)
+            eng.backward(dout)
+        return loss
+
     def __call__(self, k):
+        if getattr(self, '_tp', None) is not None and self.stop_state is None and self._graph is None and self.micro is None:
+            self._tp_count += 1
+            if self._tp_count % 2 == 0:
+                return self._second_pipeline_step(k)
         if self._graph is not None:
             self._t.fill_(int(k))
             if self._replay is not None:

@@ -1307,3 +1307,37 @@ def test_rank_sharded_sampling_to_dir_and_fid_features(report, tmp_path):
     e_sg = float(np.abs(sigma - sigma2).max() / max(np.abs(sigma2).max(), 1e-30))
     report['e2e/sample_to_dir'] = dict(images=n, mu_rel=e_mu, sigma_rel=e_sg)
     assert e_mu < 1e-5 and e_sg < 1e-4
+
+
+def test_two_timesteps_in_flight_match_single_pipeline(report):
+    """Plain Taylor with two TIMESTEPS in flight (odd-position timesteps on a second engine / stream / gradient buffer at the full
+    batch, folded in once per sweep): run-to-run bit-identical, equal to the single pipeline up to fp32 re-association of the
+    per-timestep gradient sum, same prune masks; with a threshold (sequential early exit) the second pipeline is not used."""
+    cfg = gc.TINY_CFG
+    sweep, sched = pkg('sweep'), pkg('diffusion').DDPMScheduler()
+    B = 8
+    clean, noise = _inputs(B, 16, 7, 8)
+    clean, noise = clean.to(DEV), noise.to(DEV)
+
+    def run(pipes, thr=None, steps=7):
+        model = make_model(cfg, 5)
+        flat = sweep.flatten_grads(model)
+        step = sweep.HipSweepStep(model, sched, clean, noise, B * clean[0].numel(), 'mse', B, timestep_pipelines=pipes)
+        assert (step._tp is not None) == (pipes == 2)
+        res = sweep.taylor_sweep(model, sched, clean, noise, num_steps=steps, thr=thr, step_fn=step, flat_grads=flat, use_graph=False)
+        torch.cuda.synchronize()
+        return model, flat, res
+
+    m2, g2, r2 = run(2)
+    _, g2b, r2b = run(2)
+    m1, g1, r1 = run(1)
+    assert torch.equal(g2, g2b) and r2['losses'] == r2b['losses']
+    e_g = relerr(g2, g1)
+    assert r2['losses'] == r1['losses']                       # per-timestep losses: same kernels on the same inputs
+    pr2, pr1 = sweep.prune_model(m2, 0.3), sweep.prune_model(m1, 0.3)
+    mism = [a[0] for a, b in zip(pr2.records, pr1.records) if a[3] != b[3]]
+    _, ge2, e2 = run(2, thr=0.999, steps=40)
+    _, ge1, e1 = run(1, thr=0.999, steps=40)
+    report['e2e/two_timestep_pipelines'] = dict(grad_rel=e_g, mask_mismatches=mism, exit_steps=(e2['steps'], e1['steps']))
+    assert e_g < 2e-5 and not mism
+    assert e2['steps'] == e1['steps'] and e2['losses'] == e1['losses'] and torch.equal(ge2, ge1)
