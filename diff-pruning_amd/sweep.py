@@ -85,11 +85,15 @@ class HipSweepStep:
         if timestep_pipelines is None:
             timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', '1'))
         self._tp = None
-        if timestep_pipelines == 2 and self._half is None and type(self.eng) is UNetEngine:
-            self._setup_second_half()
-            self._tp, self._half = self._half, None
-            self._tp['eng'].set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off)
-            self._tp_count, self._tp_synced = 0, False
+        if timestep_pipelines >= 2 and self._half is None and type(self.eng) is UNetEngine:
+            self._tp = []
+            for _ in range(timestep_pipelines - 1):
+                self._setup_second_half()
+                tp, self._half = self._half, None
+                tp['eng'].set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off)
+                tp['synced'] = False
+                self._tp.append(tp)
+            self._tp_count = 0
 
     def _setup_second_half(self):
         dev = self.clean.device
@@ -109,8 +113,8 @@ class HipSweepStep:
 
     def finish(self):
         """Fold the second pipeline's gradients into the parameters' .grad buffers (once per sweep)."""
-        second = self._half if self._half is not None else getattr(self, '_tp', None)
-        if second is not None:
+        others = [self._half] if self._half is not None else (getattr(self, '_tp', None) or [])
+        for second in others:                                  # fixed order: deterministic sums
             cur = torch.cuda.current_stream()
             cur.wait_stream(second['stream'])
             for n, g in self._G.items():
@@ -211,12 +215,11 @@ class HipSweepStep:
                 g.instantiate()
         return self
 
-    def _second_pipeline_step(self, k):
-        """Timestep k on the second pipeline's stream and engine (full batch, own gradient buffer)."""
-        tp = self._tp
-        if not self._tp_synced:          # once: inputs, schedule table and every packed operand (also the ones the first timestep
+    def _second_pipeline_step(self, k, tp):
+        """Timestep k on another pipeline's stream and engine (full batch, own gradient buffer)."""
+        if not tp['synced']:             # once: inputs, schedule table and every packed operand (also the ones the first timestep
             tp['stream'].wait_stream(torch.cuda.current_stream())      # packed lazily on the main stream) are complete
-            self._tp_synced = True
+            tp['synced'] = True
         with torch.cuda.stream(tp['stream']):
             t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
             eng = tp['eng']
@@ -227,10 +230,11 @@ class HipSweepStep:
         return loss
 
     def __call__(self, k):
-        if getattr(self, '_tp', None) is not None and self.stop_state is None and self._graph is None and self.micro is None:
+        if getattr(self, '_tp', None) and self.stop_state is None and self._graph is None and self.micro is None:
+            i = self._tp_count % (len(self._tp) + 1)           # round-robin: main pipeline first
             self._tp_count += 1
-            if self._tp_count % 2 == 0:
-                return self._second_pipeline_step(k)
+            if i:
+                return self._second_pipeline_step(k, self._tp[i - 1])
         if self._graph is not None:
             self._t.fill_(int(k))
             if self._replay is not None:

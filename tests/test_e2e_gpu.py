@@ -1323,7 +1323,7 @@ def test_two_timesteps_in_flight_match_single_pipeline(report):
         model = make_model(cfg, 5)
         flat = sweep.flatten_grads(model)
         step = sweep.HipSweepStep(model, sched, clean, noise, B * clean[0].numel(), 'mse', B, timestep_pipelines=pipes)
-        assert (step._tp is not None) == (pipes == 2)
+        assert bool(step._tp) == (pipes == 2)
         res = sweep.taylor_sweep(model, sched, clean, noise, num_steps=steps, thr=thr, step_fn=step, flat_grads=flat, use_graph=False)
         torch.cuda.synchronize()
         return model, flat, res
