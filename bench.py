@@ -156,9 +156,10 @@ class SweepWorkload:
         gc.det_init_(m, 0)
         return m.to(self.env.dev).eval()
 
-    def _step(self, model):
+    def _step(self, model, pipelines=None):
         n = self.env.world * self.B
-        return pkg('sweep').HipSweepStep(model, self.sched, self.clean, self.noise, n * self.clean[0].numel(), 'mse', n)
+        return pkg('sweep').HipSweepStep(model, self.sched, self.clean, self.noise, n * self.clean[0].numel(), 'mse', n,
+                                         timestep_pipelines=pipelines)
 
     def warmup(self, W):
         for k in range(W):
@@ -189,6 +190,7 @@ class SweepWorkload:
                            'kernel_launches_per_step': launches / res['steps'],
                            'grad_allreduce_ms': tm.get('allreduce_s', 0.0) * 1e3,
                            'wgrad_stream_overlap': bool(self.step.eng._overlap_now), 'hipgraph': bool(self.env.args.graph),
+                           'timestep_pipelines': 1 + len(getattr(self.step, '_tp', None) or []) if self.thr is None else 1,
                            'diff_pruning_threshold': self.thr,
                            'pruned_groups': len(pr.records), 'params_after': sum(p.numel() for p in self.model.parameters()),
                            'loss_first_last': [res['losses'][0], res['losses'][-1]]})
@@ -204,7 +206,7 @@ class SweepWorkload:
     def instrumented(self):
         model2 = self._model()
         pkg('sweep').flatten_grads(model2)
-        step2 = self._step(model2)
+        step2 = self._step(model2, pipelines=1)
         step2.eng.overlap_wgrad = False      # per-kernel durations: one kernel on the GPU at a time, at the shapes of the
         if step2._half is not None:          # timed region
             step2._half['serial'] = True

@@ -20,6 +20,9 @@ from .engine import UNetEngine
 
 
 GRAPH_AUTO_PIXELS = 8192        # taylor_sweep(use_graph=None): shards up to this many pixels (CIFAR: batch <= 8) ...
+# [measured, round 3, CIFAR UNet batch 256, one box] ms per timestep with 1 / 2 / 3 / 4 timestep pipelines: 78.8 / 76.9 / 77.5 / 76.7
+# (without the weight-gradient side streams: 79.1 with two).  Two is the default for plain Taylor sweeps.
+TIMESTEP_PIPELINES = 2
 GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay one captured timestep (native replay list)
 
 
@@ -83,7 +86,7 @@ class HipSweepStep:
         # their size (the half-batch pipelines above lost to their smaller launches) and the two independent kernel streams fill
         # each other's ramps, tails and HBM-bound phases.  No cross-stream edge between the pipelines until finish().
         if timestep_pipelines is None:
-            timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', '1'))
+            timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', str(TIMESTEP_PIPELINES)))
         self._tp = None
         if timestep_pipelines >= 2 and self._half is None and type(self.eng) is UNetEngine:
             self._tp = []
