@@ -86,7 +86,12 @@ class HipSweepStep:
         # their size (the half-batch pipelines above lost to their smaller launches) and the two independent kernel streams fill
         # each other's ramps, tails and HBM-bound phases.  No cross-stream edge between the pipelines until finish().
         if timestep_pipelines is None:
-            timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', str(TIMESTEP_PIPELINES)))
+            # small shards are bound by the host's launch rate, not by the GPU (batch 4: 10.90 vs 10.96 ms): one pipeline, which
+            # also keeps them bit-identical to the replayed form
+            from .engine import OVERLAP_MIN_WORK
+            width = self.eng.cfg.get('block_out_channels', [self.eng.cfg.get('model_channels', 128)])[0]
+            big = clean.shape[0] * clean.shape[2] * clean.shape[3] * width >= OVERLAP_MIN_WORK
+            timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', str(TIMESTEP_PIPELINES if big else 1)))
         self._tp = None
         if timestep_pipelines >= 2 and self._half is None and type(self.eng) is UNetEngine:
             self._tp = []
