@@ -123,12 +123,32 @@ class HipSweepStep:
         """Fold the second pipeline's gradients into the parameters' .grad buffers (once per sweep)."""
         others = [self._half] if self._half is not None else (getattr(self, '_tp', None) or [])
         for second in others:                                  # fixed order: deterministic sums
+            if second.get('synced') is False:
+                continue                                       # a timestep pipeline that never ran (sweep with a threshold)
             cur = torch.cuda.current_stream()
             cur.wait_stream(second['stream'])
-            for n, g in self._G.items():
-                g2 = second['G'][n]
-                ops.axpby(g2.reshape(-1), 1.0, g.reshape(-1), 1.0)
+            flat = self._flat_of_grads()
+            if flat is not None:                               # .grad buffers are consecutive views of one flat buffer: one launch
+                ops.axpby(second['flat'], 1.0, flat, 1.0)
+            else:
+                for n, g in self._G.items():
+                    g2 = second['G'][n]
+                    ops.axpby(g2.reshape(-1), 1.0, g.reshape(-1), 1.0)
             second['flat'].zero_()
+
+    def _flat_of_grads(self):
+        """The flat buffer behind the parameters' .grad views (flatten_grads), when they tile it in order; else None."""
+        gs = list(self._G.values())
+        base = getattr(gs[0], '_base', None)
+        total = sum(g.numel() for g in gs)
+        if base is None or base.dim() != 1 or base.numel() != total or not base.is_contiguous():
+            return None
+        off = base.data_ptr()
+        for g in gs:
+            if g.data_ptr() != off or not g.is_contiguous():
+                return None
+            off += g.numel() * 4
+        return base
 
     def _step(self, t):
         if self._half is not None and self.micro is None:
