@@ -22,7 +22,7 @@ print('$c', round(d['value'],2), d['unit'], round(d['ms_per_step'],2), 'ms/step;
   ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log ;;
 profiles)
   stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
-  DP_NO_OVERLAP=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
+  DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
   stats c4_finetune python bench.py --config c4_finetune --no-roofline
   stats ddim python bench.py --config ddim --no-roofline
   stats ldm python bench.py --config ldm --no-roofline --steps 2 --warmup 1
@@ -30,7 +30,7 @@ profiles)
   ls -la $O/${R}_*kernel_stats.csv ;;
 pmc)
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    DP_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r3_pmc_$ctr.log 2>&1
+    DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r3_pmc_$ctr.log 2>&1
   done
   python tools/pmc_aggregate.py $O/${R}_pmc_bench_traffic.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE ;;
 esac
