@@ -75,14 +75,19 @@ class ClassEmbedder(nn.Module):
 
 
 @torch.no_grad()
-def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0):
-    """DDIMSampler.sample + p_sample_ddim with classifier-free guidance (eta = 0)."""
+def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0, engine=None):
+    """DDIMSampler.sample + p_sample_ddim with classifier-free guidance (eta = 0).
+    `engine`: run the forwards on this engine (a second importance-step pipeline, see ldm_importance_sweep) instead of the
+    model's own; the caller holds `model.pin_weights()` and has bound the engine."""
     if eta != 0.0:
         raise NotImplementedError('prune_ldm.py samples with ddim_eta = 0')
     steps, a, a_prev, sig = schedule.ddim(S, eta)
     x = x_T.contiguous()
     B = x.shape[0]
     ctx2 = torch.cat([uncond, cond]).contiguous()
+    if engine is not None:
+        with engine.context_cache(ctx2):
+            return _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B, engine)
     with model.pin_weights() as pinned:          # 2 * S forwards over frozen weights: pack the operands once
         eng = getattr(pinned, '_engine', None)
         cache = eng.context_cache(ctx2) if hasattr(eng, 'context_cache') else contextlib.nullcontext()
@@ -91,8 +96,11 @@ def ddim_sample_cfg(model, schedule, x_T, cond, uncond, S=20, scale=3.0, eta=0.0
     return x
 
 
-def _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B):
+def _ddim_loop(model, x, ctx2, steps, a, a_prev, sig, scale, B, engine=None):
     pair = getattr(model, 'forward_cfg_pair', None) if CFG_SHARED_STEM else None
+    if engine is not None:
+        def pair(x_, t_, c_):
+            return engine.forward(x_.to(torch.float32), t_, c_, save=False, cfg_pair=True)
     for i in reversed(range(len(steps))):
         if pair is not None:                 # [x; x] against [uncond; cond]: the context-free stem runs once (LdmEngine.forward)
             e = pair(x, torch.full((B,), int(steps[i]), dtype=torch.long, device=x.device), ctx2)
@@ -109,19 +117,21 @@ class LdmSweepStep:
     `global_numel`: elements of the GLOBAL latent batch (mean_B mean_CHW == mean over every element of it); a rank's loss
     and gradient are its share of that mean."""
 
-    def __init__(self, model, schedule, global_numel=None):
+    def __init__(self, model, schedule, global_numel=None, engine=None, grads=None):
         self.model, self.schedule = model, schedule
         self.global_numel = global_numel
-        self.eng = model.engine()
+        self.eng = engine if engine is not None else model.engine()
         self._P = {n: p.detach() for n, p in model.named_parameters()}
-        self._G = {n: p.grad for n, p in model.named_parameters()}
+        self._G = grads if grads is not None else {n: p.grad for n, p in model.named_parameters()}
 
-    def loss(self, x_start, t, context, noise, stop_state=None):
+    def loss(self, x_start, t, context, noise, stop_state=None, before_loss=None):
         self.eng.bind(self._P, self._G)          # model(...) calls of the sampler re-bind the engine without gradients
         sa, sb = self.schedule.tables(x_start.device)
         x_noisy = ops.q_sample(x_start.contiguous(), noise.contiguous(), sa, sb, t)
         out = self.eng.forward(x_noisy, t, context, save=True)
         n = self.global_numel or out.numel()     # mean_B(mean_CHW) == mean over every element
+        if before_loss is not None:              # the first read of `stop_state` (another pipeline's update precedes it)
+            before_loss()
         loss, dout = ops.mse_fwd_bwd(out, noise.contiguous(), 2.0 / n, 1.0 / n, stop_state=stop_state)
         self._dout = dout
         return loss
@@ -203,12 +213,81 @@ class _LaggedFlag:
         return stopped
 
 
+LDM_PIPELINES = 1            # importance steps in flight (ldm_importance_sweep, pipelines=); env DP_LDM_PIPELINES
+
+
+class _Pipe:
+    """One importance-step pipeline: engine, gradient buffer, HIP stream.  The first one is the model's own engine on the
+    caller's stream; `another()` builds a further one over the same parameters and packed operands.  `updated` orders the ONE
+    sequential piece of the pass across pipelines -- the loss test: the state update of step t is enqueued behind that of
+    step t - 1 (wait_updated / mark_updated), and `seen` is the state as it stood right after this pipeline's own update,
+    so a later step's update on the other stream cannot cancel this step's gradient."""
+
+    def __init__(self, dev, step, stream, flat=None):
+        self.dev, self.step, self.stream, self.flat = dev, step, stream, flat
+        self.sample_engine = None if stream is None and flat is None else step.eng
+        self.on = dev.type == 'cuda'
+        self.updated = torch.cuda.Event() if self.on else None
+        self.seen = None
+        self.started = False
+        if stream is not None:                           # what exists now: uncond embedding, state, schedule tables, warm packs
+            self.born = torch.cuda.Event()
+            self.born.record()
+            self.packed = len(step.eng.packs._c)
+
+    @classmethod
+    def another(cls, model, schedule, first_step, dev):
+        eng = type(first_step.eng)(model.config)
+        eng.packs = first_step.eng.packs                 # frozen weights (pin_weights): one set of packed operands
+        total = sum(g.numel() for g in first_step._G.values())
+        flat2 = torch.zeros(total, dtype=torch.float32, device=dev)
+        G2, off = {}, 0
+        for n, g in first_step._G.items():
+            G2[n] = flat2[off:off + g.numel()].view_as(g)
+            off += g.numel()
+        eng.bind(first_step._P, G2)
+        stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        return cls(dev, LdmSweepStep(model, schedule, first_step.global_numel, engine=eng, grads=G2), stream, flat2)
+
+    @contextlib.contextmanager
+    def scope(self, first):
+        if self.stream is None:
+            yield
+            return
+        if not self.started:                             # once: every operand the first step packed lazily on the caller's
+            if len(self.step.eng.packs._c) != self.packed:             # stream is complete -- the whole first step when it packed
+                self.stream.wait_stream(torch.cuda.current_stream())   # something, else only what preceded it
+            else:
+                self.stream.wait_event(self.born)
+            self.started = True
+        with torch.cuda.stream(self.stream):
+            yield
+
+    def wait_updated(self):
+        if self.on:
+            torch.cuda.current_stream().wait_event(self.updated)
+
+    def mark_updated(self, state):
+        if self.seen is None:
+            self.seen = torch.empty_like(state)
+        self.seen.copy_(state)
+        if self.on:
+            self.updated.record()
+        return self.seen
+
+    def fold_into(self, flat):
+        if self.stream is not None and self.started:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.flat is not None and (self.started or self.stream is None):
+            ops.axpby(self.flat, 1.0, flat, 1.0)
+
+
 X_T_STREAM, NOISE_STREAM = 0x7854, 0x6e73          # Philox stream ids of the two draws of a step ('xT', 'ns')
 
 
 def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1, n_samples=6, ddim_steps=20, scale=3.0,
                          latent_shape=(3, 64, 64), uncond_class=1000, class_rng=None, generator=None, draws=None,
-                         group=None, seed=0, device_exit=True, reduce_grads=True, shard=None):
+                         group=None, seed=0, device_exit=True, reduce_grads=True, shard=None, pipelines=None):
     """prune_ldm.py:101-131.  thr=None -> plain Taylor over `num_steps` (thres 0.0 in the reference).
 
     Draws of step t, always those of the GLOBAL batch of `n_samples` latents (every rank makes the same draws and keeps its
@@ -217,7 +296,12 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
     `class_rng` (random.Random; the script's `random.sample(range(1000), n)`).
     `group`: torch.distributed process group (None = default group when initialised).  device_exit=False reads the loss on
     the host after every step, as the script does.  `shard=(rank, world)` computes that rank's share in THIS process without
-    any collective (what one rank of a `world`-rank job contributes; the linearity tests sum such shares).  Returns dict(losses [global], steps, accumulated, flat_grads, shard)."""
+    any collective (what one rank of a `world`-rank job contributes; the linearity tests sum such shares).
+    pipelines=2 (device_exit only): importance steps of odd position run on a second engine / stream / gradient buffer.  The CFG
+    sampling of a step -- 93 % of it -- depends on nothing a previous step computes, so two steps are in flight; only the loss
+    test is sequential: each pipeline's loss / state update waits (one event per step) for the other's previous update, so losses,
+    stop step and cancelled gradients are those of the sequential loop; the accumulated gradient is the same sum re-associated
+    (even + odd steps).  Returns dict(losses [global], steps, accumulated, flat_grads, shard)."""
     import torch.distributed as dist
     from .sweep import flatten_grads
     dev = next(model.parameters()).device
@@ -248,31 +332,46 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
         losses_dev = torch.zeros(num_steps, dtype=torch.float32, device=dev)
         flag = _LaggedFlag(dev)
     losses, max_loss, accumulated = [], -1.0, 0
+    if pipelines is None:
+        pipelines = int(os.environ.get('DP_LDM_PIPELINES', str(LDM_PIPELINES)))
+    pipes = [_Pipe(dev, step, None)]
+    if pipelines >= 2 and on_device:
+        schedule.tables(dev)                         # on the device before a second stream is born (it waits for that moment)
+        pipes += [_Pipe.another(model, schedule, step, dev) for _ in range(pipelines - 1)]
+
+    def draw(t):
+        if draws is not None:
+            xc, x_T, noise = draws(t)
+            return stage(xc[lo:hi]), stage(x_T[lo:hi]), stage(noise[lo:hi])
+        xc = stage(torch.tensor(class_rng.sample(range(1000), n_samples)[lo:hi]))
+        if generator is not None:
+            x_T = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
+            noise = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
+        else:
+            x_T = ops.randn_philox(shape_loc, seed, X_T_STREAM, t, idx0=lo * per, device=dev)
+            noise = ops.randn_philox(shape_loc, seed, NOISE_STREAM, t, idx0=lo * per, device=dev)
+        return xc, x_T, noise
+
     with model.pin_weights():                    # the importance pass never writes weights: pack the operands once
         for t in range(num_steps):
-            if draws is not None:
-                xc, x_T, noise = draws(t)
-                xc, x_T, noise = stage(xc[lo:hi]), stage(x_T[lo:hi]), stage(noise[lo:hi])
-            else:
-                xc = stage(torch.tensor(class_rng.sample(range(1000), n_samples)[lo:hi]))
-                if generator is not None:
-                    x_T = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
-                    noise = stage(torch.randn((n_samples,) + tuple(latent_shape), generator=generator)[lo:hi])
-                else:
-                    x_T = ops.randn_philox(shape_loc, seed, X_T_STREAM, t, idx0=lo * per, device=dev)
-                    noise = ops.randn_philox(shape_loc, seed, NOISE_STREAM, t, idx0=lo * per, device=dev)
-            c = embedder(xc)
-            samples = ddim_sample_cfg(model, schedule, x_T, c, uc, S=ddim_steps, scale=scale)
-            tt = torch.full((n_loc,), t, dtype=torch.long, device=dev)
-            if on_device:
-                loss = step.loss(samples, tt, c, noise, stop_state=state)
-                if use_dist:
-                    dist.all_reduce(loss, group=group)       # stream-ordered under RCCL: the host does not wait
-                ops.early_exit_update_ratio(loss, -1.0 if thr is None else thr, state, losses_dev)
-                step.backward(cancel_if_stopped=state)       # the breaking step (and any step enqueued after it) adds 0
-                if flag.push(state):
-                    break
-                continue
+            pipe = pipes[t % len(pipes)]
+            with pipe.scope(pipes[0]):
+                xc, x_T, noise = draw(t)
+                c = embedder(xc)
+                samples = ddim_sample_cfg(model, schedule, x_T, c, uc, S=ddim_steps, scale=scale, engine=pipe.sample_engine)
+                tt = torch.full((n_loc,), t, dtype=torch.long, device=dev)
+                if on_device:
+                    before = pipes[(t - 1) % len(pipes)] if (len(pipes) > 1 and t > 0) else None
+                    loss = pipe.step.loss(samples, tt, c, noise, stop_state=state,
+                                          before_loss=None if before is None else before.wait_updated)
+                    if use_dist:
+                        dist.all_reduce(loss, group=group)       # stream-ordered under RCCL: the host does not wait
+                    ops.early_exit_update_ratio(loss, -1.0 if thr is None else thr, state, losses_dev)
+                    seen = pipe.mark_updated(state) if len(pipes) > 1 else state
+                    pipe.step.backward(cancel_if_stopped=seen)   # the breaking step (and any step enqueued after it) adds 0
+                    if flag.push(seen):
+                        break
+                    continue
             loss = step.loss(samples, tt, c, noise)
             if use_dist:
                 dist.all_reduce(loss, group=group)
@@ -285,6 +384,8 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
                 break
             step.backward()
             accumulated += 1
+    for pipe in pipes[1:]:                           # fixed order: deterministic sums
+        pipe.fold_into(flat)
     if on_device:
         st = [float(v) for v in state.cpu()]
         steps = int(st[2])

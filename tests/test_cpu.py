@@ -926,14 +926,15 @@ def test_ldm_importance_sweep_control_flow_matches_oracle(mocked, monkeypatch):
     monkeypatch.setattr(ldm.UNetModel, 'engine', cpu_engine)
     cfg = gc.LDM_TINY_CFG
     emb_w, draws = _ldm_sweep_fixture()
-    for thr, expect_steps in ((None, 3), (1.5, 1)):        # thr 1.5: loss/max_loss = 1 < 1.5 at t = 0 -> break, nothing accumulated
+    # thr 1.5: loss/max_loss = 1 < 1.5 at t = 0 -> break, nothing accumulated; pipelines 2: odd steps on a second engine + buffer
+    for thr, expect_steps, pipelines in ((None, 3, 1), (1.5, 1, 1), (None, 3, 2), (1.5, 1, 2)):
         model = ldm.UNetModel(**cfg)
         gc.det_init_(model, 9)
         embedder = ldm_sweep.ClassEmbedder(16, 1001)
         with torch.no_grad():
             embedder.embedding.weight.copy_(emb_w)
-        res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=3, thr=thr, n_samples=2, ddim_steps=4,
-                                             latent_shape=(3, 16, 16), draws=lambda t: draws[t])
+        res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=3, thr=thr, n_samples=2, ddim_steps=4, pipelines=pipelines,
+                                             latent_shape=(3, 16, 16), draws=lambda t: draws[min(t, 2)])
         P, losses = _ldm_oracle_sweep(cfg, emb_w, draws, 4, thr)
         assert res['steps'] == len(losses) == expect_steps
         assert np.allclose(res['losses'], losses, rtol=2e-5)
@@ -1492,13 +1493,15 @@ def test_ldm_driver_loop_matches_the_reference_script(mocked, monkeypatch):
     # device_exit=True: the max-loss / threshold state machine of dp_early_exit_update_ratio (mocked), the breaking step's dOut
     # cancelled, the host reading the flag one step late -- so ONE more step is enqueued after the break (it re-uses the last
     # draws here) and must leave losses, step count and gradients untouched.  device_exit=False: the script's host-side test.
-    for device_exit in (True, False):
+    # pipelines 2: step 1 runs on the second engine into the second gradient buffer; the break at t = 2 (first pipeline) and the
+    # step enqueued after it (second pipeline) add nothing, step 1's gradient is kept.
+    for device_exit, pipelines in ((True, 1), (False, 1), (True, 2)):
         for p_ in model_b.parameters():
             p_.grad = None
         asked = []
         res = ldm_sweep.ldm_importance_sweep(model_b, embedder, num_steps=10, thr=fx['thr'], n_samples=n, ddim_steps=S,
                                              scale=fx['scale'], latent_shape=(3, 64, 64), device_exit=device_exit,
-                                             draws=lambda t: (asked.append(t), draws_b[min(t, 2)])[1])
+                                             pipelines=pipelines, draws=lambda t: (asked.append(t), draws_b[min(t, 2)])[1])
         assert asked == ([0, 1, 2, 3] if device_exit else [0, 1, 2])
         assert res['steps'] == 3 and res['accumulated'] == 2
         assert np.allclose(res['losses'], bc['printed_losses'] + [bc['breaking_loss']], rtol=2e-5)

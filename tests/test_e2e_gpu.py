@@ -490,6 +490,37 @@ def test_ldm_importance_sweep_matches_oracle(report):
     assert res['steps'] == 3 and e_l < 1e-4 and worst < 2e-4
 
 
+def test_ldm_two_importance_steps_in_flight(report):
+    """ldm_importance_sweep(pipelines=2): odd steps on a second engine / stream / gradient buffer.  Losses and the stop step are
+    those of the sequential loop bit for bit (the loss test is ordered across the pipelines); the gradient is the same sum
+    re-associated (even steps + odd steps).  Case 2 breaks in the middle (threshold 0.995 on a loss sequence that is not
+    monotone): the breaking step and the one enqueued behind it add nothing, the steps before it are kept."""
+    ldm, ldm_sweep = pkg('ldm'), pkg('ldm_sweep')
+    cfg = gc.LDM_TINY_CFG
+    emb_w = torch.from_numpy(gc.det_noise((1001, 16), 77))
+    out = {}
+    for thr in (None, 0.995):
+        for pipelines in (1, 2):
+            model = ldm.UNetModel(**cfg)
+            gc.det_init_(model, 9)
+            model = model.to(DEV).eval()
+            embedder = ldm_sweep.ClassEmbedder(16, 1001)
+            with torch.no_grad():
+                embedder.embedding.weight.copy_(emb_w)
+            embedder = embedder.to(DEV)
+            res = ldm_sweep.ldm_importance_sweep(model, embedder, num_steps=7, thr=thr, n_samples=2, ddim_steps=4, seed=3,
+                                                 latent_shape=(3, 16, 16), pipelines=pipelines)
+            torch.cuda.synchronize()
+            out[thr, pipelines] = (res['losses'], res['steps'], res['accumulated'], res['flat_grads'].clone())
+        a, b = out[thr, 1], out[thr, 2]
+        assert a[0] == b[0] and a[1:3] == b[1:3], (thr, a[:3], b[:3])
+        assert relerr(b[3], a[3]) < 1e-5, thr
+    assert out[None, 1][1] == 7
+    assert 1 < out[0.995, 1][1] < 7, out[0.995, 1][:3]            # the break is in the middle, on either pipeline
+    report['e2e/ldm_pipelines'] = dict(steps_full=out[None, 2][1], steps_thr=out[0.995, 2][1],
+                                       grad_rel=relerr(out[None, 2][3], out[None, 1][3]))
+
+
 def test_hipgraph_sweep_matches_eager(report):
     """One captured timestep replayed per t gives bit-identical losses and gradients to the eager launch sequence."""
     import time
