@@ -47,6 +47,13 @@ class NtGemmParams(C.Structure):
                 ('o_tap_stride', LL), ('o_col_stride', C.c_int), ('xcd', C.c_int), ('col_bias', C.c_void_p)]
 
 
+class AttentionParams(C.Structure):
+    _fields_ = [('q', C.c_void_p), ('k', C.c_void_p), ('v', C.c_void_p), ('o', C.c_void_p),
+                ('q_bs', LL), ('k_bs', LL), ('v_bs', LL), ('o_bs', LL),
+                ('N', C.c_int), ('heads', C.c_int), ('d', C.c_int), ('dv', C.c_int), ('T', C.c_int), ('scale', C.c_float),
+                ('variant', C.c_int), ('_pad', C.c_int)]
+
+
 class Dropout(C.Structure):
     _fields_ = [('thr24', C.c_uint), ('scale', C.c_float), ('seed', C.c_ulonglong), ('site', C.c_uint), ('step', C.c_uint),
                 ('n_off', LL)]
@@ -98,6 +105,8 @@ SIGNATURES = {
     'dp_silu_bwd': [_vp, _vp, _vp, _ll, _i, _vp],
     'dp_axpby': [_vp, _f, _vp, _f, _ll, _vp],
     'dp_copy_strided': [_vp, _ll, _vp, _ll, _i, _ll, _i, _vp],
+    'dp_attention_fwd': [C.POINTER(AttentionParams), _vp],
+    'dp_attention_fwd_supported': [_i, _i, _i],
     'dp_softmax_fwd': [_vp, _vp, _ll, _i, _vp],
     'dp_softmax_bwd': [_vp, _vp, _vp, _ll, _i, _f, _vp],
     'dp_timestep_embedding': [_vp, _i, _i, _i, _f, _f, _vp, _vp],

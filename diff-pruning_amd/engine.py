@@ -525,10 +525,14 @@ class UNetEngine:
         # heads: channel-major tokens make head_to_batch_dim (attention_processor.py:283-305) a view: head h owns the
         # contiguous channel rows [h*d, (h+1)*d) of every image -> batch index n*heads + h
         Z, d = N * heads, inner // heads
-        s = ops.bmm_tn(q.view(Z, d, T), k.view(Z, d, T), alpha=scale)
-        p = ops.softmax_fwd(s, out=s)
         vd = v.shape[1] // heads                      # the value width may differ from the query / key width after pruning
-        o = ops.bmm_nt(v.view(Z, vd, T), p)
+        if save is None and getattr(ops, 'FUSED_ATTN', False) and ops.attention_fused_ok(T, d, vd):
+            p = None                                  # sampling forward: one kernel, no [T, T] scores (csrc/attention.hip)
+            o = ops.attention_fwd(q, k, v, heads, scale)
+        else:
+            s = ops.bmm_tn(q.view(Z, d, T), k.view(Z, d, T), alpha=scale)
+            p = ops.softmax_fwd(s, out=s)
+            o = ops.bmm_nt(v.view(Z, vd, T), p)
         drop = self._drop(pre + '.to_out.1')
         if drop is None:
             out = self._conv(pre + '.to_out.0', o.view(N, vd * heads, H, W), None, _SPEC1, res=x, post_scale=1.0 / rescale)

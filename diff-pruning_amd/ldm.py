@@ -231,9 +231,13 @@ class LdmEngine(UNetEngine):
             k = self._conv(tb + '.attn1.to_k', l1, None, _SPEC1)
             v = self._conv(tb + '.attn1.to_v', l1, None, _SPEC1)
         ai = q.shape[1]
-        s = ops.bmm_tn(q.view(N, ai, T), k.view(N, ai, T), alpha=scale)
-        p = ops.softmax_fwd(s, out=s)
-        o = ops.bmm_nt(v.view(N, ai, T), p)
+        if save is None and getattr(ops, 'FUSED_ATTN', False) and ops.attention_fused_ok(T, ai, ai):
+            p = None                                  # sampling forward: one kernel, no [T, T] scores (csrc/attention.hip)
+            o = ops.attention_fwd(q, k, v, 1, scale)
+        else:
+            s = ops.bmm_tn(q.view(N, ai, T), k.view(N, ai, T), alpha=scale)
+            p = ops.softmax_fwd(s, out=s)
+            o = ops.bmm_nt(v.view(N, ai, T), p)
         h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, ai, H, W), None, _SPEC1, res=h)
         # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
         hit = self._ctx_cache.get(pre) if self._ctx_cache is not None else None

@@ -932,6 +932,37 @@ def softmax_fwd(s, out=None):
     return out
 
 
+# One fused attention kernel (csrc/attention.hip) for the forwards that keep nothing for a backward.  OFF by default this round
+# (DP_FUSED_ATTN=1 turns it on): parity-tested (tests/test_kernels_gpu.py::test_fused_attention_*), not yet timed end to end.
+FUSED_ATTN = bool(os.environ.get('DP_FUSED_ATTN'))
+
+
+def attention_fused_ok(T, d, dv):
+    """Shapes dp_attention_fwd takes (tokens in whole 32-blocks, head widths <= 640); others keep the three launches."""
+    return bool(_lib().dp_attention_fwd_supported(int(T), int(d), int(dv)))
+
+
+def attention_fwd(q, k, v, heads, scale, out=None, variant=0):
+    """o[n, h*dv + c, i] = sum_j v[n, h*dv + c, j] softmax_j(scale * sum_c' q[n, h*d + c', i] k[n, h*d + c', j]).
+    q, k: [N, heads*d, H, W], v: [N, heads*dv, H, W] channel-major activations (channel slices of one QKV tensor are fine);
+    returns [N, heads*dv, H, W].  No score tensor is materialised; nothing is kept for a backward."""
+    sq, sk, sv = _chk_act(q), _chk_act(k), _chk_act(v)
+    N, Cq, H, W = q.shape
+    T = H * W
+    assert k.shape == q.shape and v.shape[0] == N and v.shape[2:] == q.shape[2:] and Cq % heads == 0 and v.shape[1] % heads == 0
+    d, dv = Cq // heads, v.shape[1] // heads
+    if out is None:
+        out = empty_act((N, heads * dv, H, W), q.device)
+    so = _chk_act(out)
+    p = L.AttentionParams()
+    p.q, p.k, p.v, p.o = _p(q), _p(k), _p(v), _p(out)
+    p.q_bs, p.k_bs, p.v_bs, p.o_bs = sq, sk, sv, so
+    p.N, p.heads, p.d, p.dv, p.T, p.scale, p.variant = N, heads, d, dv, T, float(scale), int(variant)
+    flops = 2.0 * N * heads * T * T * (d + dv)
+    L.check(_run(lambda: _lib().dp_attention_fwd(C.byref(p), _stream()), 'attn_fwd_fused_kernel', flops), 'dp_attention_fwd')
+    return out
+
+
 def softmax_bwd(p_, dp_, scale, out=None):
     cols = p_.shape[-1]
     rows = p_.numel() // cols

@@ -186,6 +186,25 @@ int dp_copy_strided(const float* src, long long s_stride, float* dst, long long 
 
 /* Row softmax over the last dim (in place allowed).  attention_processor.py:350-353. */
 int dp_softmax_fwd(const float* s, float* p, long long rows, int cols, void* stream);
+/* Fused attention forward (no score tensor): for every image n < N and head h < heads
+ *   o[n][h*dv + c][i] = sum_j v[n][h*dv + c][j] * softmax_j(scale * sum_c' q[n][h*d + c'][i] * k[n][h*d + c'][j]),  i, j < T.
+ * Replaces get_attention_scores (baddbmm + softmax) + bmm of attention_processor.py:415-470 / the einsum-softmax-einsum of
+ * ldm/modules/attention.py:168-193 for forwards that keep nothing for a backward (sampling).  Tensors are channel-major
+ * ([N, C, T], tokens contiguous; head h = channel rows [h*d, (h+1)*d) -- head_to_batch_dim as a view); *_bs = elements between
+ * consecutive images (q / k / v may be channel slices of one fused QKV tensor).  d = query / key width per head, dv = value
+ * width per head (they differ after pruning), any d, dv >= 1 with dp_attention_fwd_supported(T, d, dv) != 0 (T a multiple of 32,
+ * max(d, dv) <= 640); other shapes return hipErrorInvalidValue -- the caller keeps the three-launch path for those. */
+typedef struct dp_attention_params {
+    const float* q; const float* k; const float* v; float* o;
+    long long q_bs, k_bs, v_bs, o_bs;
+    int N, heads, d, dv, T;
+    float scale;
+    int variant;                           /* 0 = library's choice; 1 / 2 / 3 force the rolling / whole-block operand prefetch /
+                                              the software-pipelined schedule (same arithmetic, different instruction order) */
+    int _pad;
+} dp_attention_params;
+int dp_attention_fwd(const dp_attention_params* p, void* stream);
+int dp_attention_fwd_supported(int T, int d, int dv);
 /* ds = scale * p * (dp - sum_j p_j dp_j)   (SoftmaxBackward followed by the baddbmm alpha) */
 int dp_softmax_bwd(const float* p, const float* dp, float* ds, long long rows, int cols, float scale, void* stream);
 

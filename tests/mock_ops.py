@@ -281,6 +281,24 @@ def softmax_fwd(s, out=None):
     return p
 
 
+FUSED_ATTN = False
+
+
+def attention_fused_ok(T, d, dv):
+    return T >= 32 and T % 32 == 0 and max(d, dv) <= 640
+
+
+def attention_fwd(q, k, v, heads, scale, out=None):
+    N, Cq, H, W = q.shape
+    T, d, dv = H * W, Cq // heads, v.shape[1] // heads
+    s = scale * torch.bmm(q.reshape(N * heads, d, T).transpose(1, 2), k.reshape(N * heads, d, T))
+    o = torch.bmm(v.reshape(N * heads, dv, T), s.softmax(-1).transpose(1, 2)).reshape(N, heads * dv, H, W)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
 def softmax_bwd(p, dp, scale, out=None):
     ds = scale * p * (dp - (p * dp).sum(-1, keepdim=True))
     if out is not None:

@@ -429,6 +429,41 @@ def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkey
             assert relerr(p.grad, P[n].grad) < 5e-5, n
 
 
+def test_fused_attention_wiring_on_mocked_kernels(mocked, monkeypatch):
+    """Engine wiring of the fused attention forward (ops.FUSED_ATTN): taken by forwards that keep nothing for a backward, with
+    the head / value-width arguments the three-launch path uses (multi-head UNet at T = 64, LDM transformer block at T = 64 /
+    256); the saving forward of a sweep step never takes it (its backward reads the materialised probabilities)."""
+    cfg = dict(load_json('groups_more.json')['heads8_4lvl']['cfg'])
+    model = _cpu_model(cfg, 4)
+    x = torch.from_numpy(gc.det_clean((2, 3, 32, 32), 81))
+    t = torch.tensor([3, 500])
+    calls = []
+    real = mocked.attention_fwd
+    monkeypatch.setattr(mocked, 'attention_fwd', lambda *a, **kw: (calls.append(a[3]), real(*a, **kw))[1])
+    with torch.no_grad():
+        y0 = model.engine().forward(x, t, save=False)
+        assert not calls
+        monkeypatch.setattr(mocked, 'FUSED_ATTN', True)
+        y1 = model.engine().forward(x, t, save=False)
+    assert calls and all(h > 1 for h in calls) and relerr(y1, y0) < 1e-5
+    n_fwd = len(calls)
+    model.engine().forward(x, t, save=True)
+    assert len(calls) == n_fwd                          # the saving forward keeps the three launches
+    ldm = pkg('ldm')
+    monkeypatch.setattr(ldm, 'ops', mocked)
+    m2 = ldm.UNetModel(**dict(gc.LDM_TINY_CFG))
+    gc.det_init_(m2, 9)
+    eng = ldm.LdmEngine(m2.config)
+    eng.bind({n: p.detach() for n, p in m2.named_parameters()}, None)
+    xl = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 5))
+    ctx = torch.from_numpy(gc.det_noise((2, 1, 16), 6))
+    with torch.no_grad():
+        z1 = eng.forward(xl, t, ctx, save=False)
+        monkeypatch.setattr(mocked, 'FUSED_ATTN', False)
+        z0 = eng.forward(xl, t, ctx, save=False)
+    assert len(calls) > n_fwd and relerr(z1, z0) < 1e-5
+
+
 def test_multi_head_unet_needs_the_gpu_like_any_other():
     """Multi-head models run on the HIP engine since round 2 (tests/test_e2e_gpu.py::test_multi_head_*); on a CPU tensor the
     refusal is the generic no-CPU-fallback one."""

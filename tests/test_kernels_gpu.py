@@ -252,6 +252,78 @@ def test_groupnorm(ops, report, N, C1, C2, H, G, silu):
     assert max(e_f, e_dx, e_g, e_b) < 2e-5
 
 
+ATTN_CASES = [
+    # N, heads, d, dv, H (T = H * H), qkv-sliced, score scale-up
+    (3, 1, 256, 256, 16, True, 1.0),       # CIFAR / bedroom attention at 16 x 16
+    (2, 1, 512, 512, 16, True, 1.0),       # bedroom mid block
+    (2, 1, 384, 384, 32, True, 1.0),       # LDM ds = 2: T = 1024
+    (2, 1, 576, 576, 16, False, 1.0),      # LDM ds = 4: 18 channel tiles over 4 wavefronts (5 / 5 / 4 / 4)
+    (2, 1, 179, 133, 8, False, 1.0),       # pruned widths: ragged channel tiles, value width != key width
+    (2, 4, 8, 8, 8, False, 1.0),           # attention_head_dim 8: 4 heads of 8 channels
+    (1, 6, 24, 24, 16, True, 1.0),
+    (2, 1, 64, 64, 16, False, 40.0),       # peaked softmax: the running max keeps moving, rows dominated by a few keys
+    (1, 1, 640, 640, 8, False, 1.0),       # the widest head the kernel takes
+]
+
+
+@pytest.mark.parametrize('N,heads,d,dv,H,sliced,gain', ATTN_CASES)
+def test_fused_attention_matches_fp64_sdpa(ops, report, N, heads, d, dv, H, sliced, gain):
+    """dp_attention_fwd (QK^T -> online softmax -> P.V in one kernel, csrc/attention.hip) vs fp64 softmax attention and vs the
+    three-launch path it replaces in sampling forwards; twice: bit-identical."""
+    T = H * H
+    if sliced and d == dv:                              # channel slices of one fused QKV activation (engine.attn_fwd)
+        qkv = rnd(N, 3 * heads * d, H, H, seed=1)
+        q, k, v = qkv[:, :heads * d], qkv[:, heads * d:2 * heads * d], qkv[:, 2 * heads * d:]
+    else:
+        q, k, v = rnd(N, heads * d, H, H, seed=1), rnd(N, heads * d, H, H, seed=2), rnd(N, heads * dv, H, H, seed=3)
+    q = q * gain if not sliced else q
+    scale = float(d) ** -0.5
+    assert ops.attention_fused_ok(T, d, dv)
+    o = ops.attention_fwd(q, k, v, heads, scale)
+    o2 = ops.attention_fwd(q, k, v, heads, scale)
+    assert torch.equal(o, o2)
+    for variant in (1, 2, 3):                           # rolling / whole-block prefetch / software-pipelined schedules
+        assert relerr(ops.attention_fwd(q, k, v, heads, scale, variant=variant), o) < 1e-6, variant
+    Z = N * heads
+    qd, kd, vd = (t.double().cpu().reshape(Z, -1, T) for t in (q, k, v))
+    pr = (scale * torch.bmm(qd.transpose(1, 2), kd)).softmax(-1)
+    ref = torch.bmm(vd, pr.transpose(1, 2)).reshape(N, heads * dv, H, H)
+    e = relerr(o, ref)
+    s = ops.bmm_tn(q.contiguous().view(Z, d, T), k.contiguous().view(Z, d, T), alpha=scale)
+    o3 = ops.bmm_nt(v.contiguous().view(Z, dv, T), ops.softmax_fwd(s, out=s)).view(N, heads * dv, H, H)
+    e3 = relerr(o3, ref)
+    report['attention_fused/%d_%d_%d_%d_%d' % (N, heads, d, dv, T)] = dict(fused=e, three_launch=e3)
+    assert e < 1e-5 and e3 < 1e-5
+    assert not ops.attention_fused_ok(48, 64, 64) and not ops.attention_fused_ok(64, 960, 960)
+
+
+def test_fused_attention_in_the_sampling_forward(ops, report, monkeypatch):
+    """UNetEngine / LdmEngine no-grad forwards with ops.FUSED_ATTN on vs the three-launch path (same weights, same inputs)."""
+    import golden_common as gc
+    from helpers import make_model, pkg
+    model = make_model(gc.CIFAR_CFG, 0)
+    x = rnd(4, 3, 32, 32, seed=5)
+    t = torch.tensor([10, 400, 700, 999], device=DEV)
+    with torch.no_grad():
+        y0 = model(x, t).sample
+        monkeypatch.setattr(ops, 'FUSED_ATTN', True)
+        y1 = model(x, t).sample
+    e = relerr(y1, y0)
+    ldm = pkg('ldm')
+    m2 = ldm.UNetModel(**gc.LDM_TINY_CFG)
+    gc.det_init_(m2, 9)
+    m2 = m2.to(DEV).eval()
+    xl, ctx = rnd(2, 3, 16, 16, seed=6), rnd(2, 1, 16, seed=7)
+    tl = torch.tensor([3, 500], device=DEV)
+    with torch.no_grad():
+        z1 = m2(xl, tl, context=ctx)
+        monkeypatch.setattr(ops, 'FUSED_ATTN', False)
+        z0 = m2(xl, tl, context=ctx)
+    e2 = relerr(z1, z0)
+    report['attention_fused/engines'] = dict(cifar_unet=e, ldm_tiny=e2)
+    assert 0 < e < 1e-5 and e2 < 1e-5                  # e > 0: the fused path was taken (different rounding), and it agrees
+
+
 def test_softmax_silu_misc(ops, report):
     s = rnd(6, 256, 256, seed=1, scale=3.0)
     p = ops.softmax_fwd(s)
