@@ -41,116 +41,149 @@ __device__ __forceinline__ f32x4 at_load4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 
-// DEEP: every K tile of key block j + 1 is in flight while block j's softmax and P.V run, every V tile of block j while its
-// S^T runs (16 * NT + 16 * NT operand registers); else a rolling pair of tile buffers, one tile (16 MFMAs) ahead.
-template <int NT, bool DEEP>
-__global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const dp_attention_params p) {
-    __shared__ f32x4 xch[2][4][4][64];                   // [buffer][wave][register quad][lane]: 32 KB
-    const int lane = threadIdx.x & 63;
-    const int li = lane & 31, half = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int T = p.T, d = p.d, dv = p.dv;
-    const int nqb = T >> 5;
+// What both schedules share: workgroup -> (image, head, query block), the three operand slabs, this wave's lane offsets.
+struct AtCtx {
+    int lane, li, half, w, T, d, dv, nqb, i0;
+    __amdgpu_buffer_rsrc_t qr, kr, vr;
+    float* __restrict__ ob;
+    unsigned klane, vlane;       // per-lane byte offsets of the K (= Q) and V operand loads inside a 32-key block
+    float c2;                    // scale * log2 e: softmax in base 2 (v_exp_f32)
+};
+
+__device__ __forceinline__ AtCtx at_setup(const dp_attention_params& p) {
+    AtCtx c;
+    c.lane = threadIdx.x & 63;
+    c.li = c.lane & 31;
+    c.half = c.lane >> 5;
+    c.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    c.T = p.T;
+    c.d = p.d;
+    c.dv = p.dv;
+    c.nqb = p.T >> 5;
     // XCD-aware order: workgroup b runs on XCD b % 8; the query blocks of one (image, head) re-read the same K and V slabs,
     // so they go to ONE XCD (one L2) -- XCD x takes the logical blocks [x * n / 8, (x + 1) * n / 8)
     unsigned L = blockIdx.x;
     if ((gridDim.x & 7u) == 0) L = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int z = (int)(L / (unsigned)nqb);
-    const int i0 = ((int)L - z * nqb) * 32;
+    const int z = (int)(L / (unsigned)c.nqb);
+    c.i0 = ((int)L - z * c.nqb) * 32;
     const int n = z / p.heads, h = z - n * p.heads;
-    const __amdgpu_buffer_rsrc_t qr = at_rsrc(p.q + n * p.q_bs + (long long)h * d * T, (unsigned)d * T * 4u);
-    const __amdgpu_buffer_rsrc_t kr = at_rsrc(p.k + n * p.k_bs + (long long)h * d * T, (unsigned)d * T * 4u);
-    const __amdgpu_buffer_rsrc_t vr = at_rsrc(p.v + n * p.v_bs + (long long)h * dv * T, (unsigned)dv * T * 4u);
-    float* __restrict__ ob = p.o + n * p.o_bs + (long long)h * dv * T;
+    c.qr = at_rsrc(p.q + n * p.q_bs + (long long)h * c.d * c.T, (unsigned)c.d * c.T * 4u);
+    c.kr = at_rsrc(p.k + n * p.k_bs + (long long)h * c.d * c.T, (unsigned)c.d * c.T * 4u);
+    c.vr = at_rsrc(p.v + n * p.v_bs + (long long)h * c.dv * c.T, (unsigned)c.dv * c.T * 4u);
+    c.ob = p.o + n * p.o_bs + (long long)h * c.dv * c.T;
+    // byte offset of a load = per-lane part (one VGPR, advanced per key block) + wave-uniform part (scalar registers); the
+    // callers make the per-block value opaque (empty asm) so that hipcc does not hoist one offset VGPR per load out of the
+    // key loop (16 * NT + 4 * NT registers, an occupancy step)
+    c.klane = (unsigned)(c.half * c.T + c.li) * 4u;
+    c.vlane = (unsigned)(c.li * c.T + 4 * c.half) * 4u;
+    c.c2 = p.scale * 1.44269504088896340736f;
+    return c;
+}
 
-    // this wave's share of Q (constant over the key blocks): channel tiles w, w + 4, ...
-    float qreg[NT][16];
+// this wave's share of Q (constant over the key blocks): channel tiles w, w + 4, ...
+template <int NT>
+__device__ __forceinline__ void at_load_q(const AtCtx& c, float (&qreg)[NT][16]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            qreg[t][s] = at_load(qr, (unsigned)((32 * (w + 4 * t) + 2 * s + half) * T + i0 + li) * 4u);
+            qreg[t][s] = at_load(c.qr, (unsigned)((32 * (c.w + 4 * t) + 2 * s + c.half) * c.T + c.i0 + c.li) * 4u);
+}
+// K operand of channel tile t for the 32 keys at lane offset kj; V operand likewise (four 16-byte loads)
+__device__ __forceinline__ void at_load_k(const AtCtx& c, float (&dst)[16], int t, unsigned kj) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dst[s] = at_load(c.kr, kj + (unsigned)((32 * (c.w + 4 * t) + 2 * s) * c.T) * 4u);
+}
+__device__ __forceinline__ void at_load_v(const AtCtx& c, f32x4 (&dst)[4], int t, unsigned vj) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[g] = at_load4(c.vr, vj + (unsigned)(32 * (c.w + 4 * t) * c.T + 8 * g) * 4u);
+}
+// O^T tile += V tile * P^T: MFMA step r = 4 g + e multiplies component e of the g-th 16-byte V load with probability register r
+__device__ __forceinline__ void at_pv_tile(f32x16& oacc, const f32x4 (&vt)[4], const float (&sc)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 vv = vt[g];
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, sc[4 * g], oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, sc[4 * g + 1], oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, sc[4 * g + 2], oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, sc[4 * g + 3], oacc, 0, 0, 0);
+    }
+}
+// partial S^T tile of this wave -> its slot of the exchange buffer
+__device__ __forceinline__ void at_publish(f32x4 (&slot)[4][64], const f32x16& sacc, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 q4;
+        q4.x = sacc[4 * g]; q4.y = sacc[4 * g + 1]; q4.z = sacc[4 * g + 2]; q4.w = sacc[4 * g + 3];
+        slot[g][lane] = q4;
+    }
+}
+// O = accumulator / (sum of both lane halves' exponentials)
+template <int NT>
+__device__ __forceinline__ void at_store(const AtCtx& c, const f32x16 (&oacc)[NT], float lrun) {
+    const float inv = 1.0f / (lrun + __shfl_xor(lrun, 32, 64));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c0 = 32 * (c.w + 4 * t);
+        if (c0 < c.dv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = c0 + (r & 3) + 8 * (r >> 2) + 4 * c.half;
+                if (ch < c.dv) c.ob[(long long)ch * c.T + c.i0 + c.li] = oacc[t][r] * inv;
+            }
+        }
+    }
+}
 
+// Plain schedule: S^T -> exchange -> softmax -> P.V per key block, a rolling pair of operand buffers one channel tile (16 MFMAs)
+// ahead.  Taken for heads wider than 256 channels, where the pipelined form below needs more than 256 registers.
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const dp_attention_params p) {
+    __shared__ f32x4 xch[2][4][4][64];                   // [buffer][wave][register quad][lane]: 32 KB
+    const AtCtx c = at_setup(p);
+    float qreg[NT][16];
+    at_load_q<NT>(c, qreg);
     f32x16 oacc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
+    float kb[2][16];
+    f32x4 vb[2][4];
 
-    constexpr int NB = DEEP ? NT : 2;
-    float kb[NB][16];
-    f32x4 vb[NB][4];
-    // byte offset = per-lane part (one VGPR, advanced per key block) + wave-uniform part (scalar registers): the empty asm keeps
-    // hipcc from hoisting one offset VGPR per load out of the key loop (16 * NT + 4 * NT registers, an occupancy step)
-    const unsigned klane = (unsigned)(half * T + li) * 4u;
-    const unsigned vlane = (unsigned)(li * T + 4 * half) * 4u;
-    auto load_k = [&](float (&dst)[16], int t, unsigned kj) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            dst[s] = at_load(kr, kj + (unsigned)((32 * (w + 4 * t) + 2 * s) * T) * 4u);
-    };
-    auto load_v = [&](f32x4 (&dst)[4], int t, unsigned vj) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            dst[g] = at_load4(vr, vj + (unsigned)(32 * (w + 4 * t) * T + 8 * g) * 4u);
-    };
-    const float c2 = p.scale * 1.44269504088896340736f;              // softmax in base 2: exp(x) = exp2(x * log2 e)
-
-    if (DEEP) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) load_k(kb[t], t, klane);
-    } else {
-        load_k(kb[0], 0, klane);
-    }
-    for (int jb = 0; jb < nqb; ++jb) {
-        unsigned kj = klane + (unsigned)jb * 128u, vj = vlane + (unsigned)jb * 128u;
+    at_load_k(c, kb[0], 0, c.klane);
+    for (int jb = 0; jb < c.nqb; ++jb) {
+        unsigned kj = c.klane + (unsigned)jb * 128u, vj = c.vlane + (unsigned)jb * 128u;
         asm volatile("" : "+v"(kj), "+v"(vj));
         // ---- partial S^T over this wave's channels ----------------------------------------------------------------
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        if (DEEP) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) load_v(vb[t], t, vj);       // this block's V under its S^T, exchange and softmax
-        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (!DEEP) {
-                if (t + 1 < NT) load_k(kb[(t + 1) & 1], t + 1, kj);  // next tile's K under this tile's MFMAs
-                else load_v(vb[0], 0, vj);                           // first V tile under the exchange + softmax
-            }
-            if (32 * (w + 4 * t) < d) {
+            if (t + 1 < NT) at_load_k(c, kb[(t + 1) & 1], t + 1, kj);      // next tile's K under this tile's MFMAs
+            else at_load_v(c, vb[0], 0, vj);                               // first V tile under the exchange + softmax
+            if (32 * (c.w + 4 * t) < c.d) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[DEEP ? t : (t & 1)][s], qreg[t][s], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t & 1][s], qreg[t][s], sacc, 0, 0, 0);
             }
         }
         // ---- exchange: every wave ends up with the same full tile ---------------------------------------------------
         const int xb = jb & 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 q4;
-            q4.x = sacc[4 * g]; q4.y = sacc[4 * g + 1]; q4.z = sacc[4 * g + 2]; q4.w = sacc[4 * g + 3];
-            xch[xb][w][g][lane] = q4;
-        }
+        at_publish(xch[xb][c.w], sacc, c.lane);
         __syncthreads();
-        if (jb + 1 < nqb) {                                          // next key block's K (its registers are free now)
-            if (DEEP) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) load_k(kb[t], t, kj + 128u);
-            } else {
-                load_k(kb[0], 0, kj + 128u);
-            }
-        }
+        if (jb + 1 < c.nqb) at_load_k(c, kb[0], 0, kj + 128u);             // next key block's first K tile (kb[0] is free)
         float sc[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = xch[xb][0][g][lane], a1 = xch[xb][1][g][lane], a2 = xch[xb][2][g][lane], a3 = xch[xb][3][g][lane];
-            sc[4 * g] = (((a0.x + a1.x) + a2.x) + a3.x) * c2;
-            sc[4 * g + 1] = (((a0.y + a1.y) + a2.y) + a3.y) * c2;
-            sc[4 * g + 2] = (((a0.z + a1.z) + a2.z) + a3.z) * c2;
-            sc[4 * g + 3] = (((a0.w + a1.w) + a2.w) + a3.w) * c2;
+            const f32x4 a0 = xch[xb][0][g][c.lane], a1 = xch[xb][1][g][c.lane], a2 = xch[xb][2][g][c.lane],
+                        a3 = xch[xb][3][g][c.lane];
+            sc[4 * g] = (((a0.x + a1.x) + a2.x) + a3.x) * c.c2;
+            sc[4 * g + 1] = (((a0.y + a1.y) + a2.y) + a3.y) * c.c2;
+            sc[4 * g + 2] = (((a0.z + a1.z) + a2.z) + a3.z) * c.c2;
+            sc[4 * g + 3] = (((a0.w + a1.w) + a2.w) + a3.w) * c.c2;
         }
         // ---- online softmax for query lane&31 (the two halves of the wave hold 16 keys each) ---------------------------
         float bm = sc[0];
@@ -162,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const dp_attention_
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sc[r] = __builtin_amdgcn_exp2f(sc[r] - mnew);            // arguments <= 0: v_exp_f32 is exact to ~1 ulp there
+            sc[r] = __builtin_amdgcn_exp2f(sc[r] - mnew);            // arguments <= 0: v_exp_f32 is good to ~1 ulp there
             ps += sc[r];
         }
         lrun = lrun * alpha + ps;                                    // this half's keys; the halves are added once, at the end
@@ -173,102 +206,44 @@ __global__ __launch_bounds__(256) void attn_fwd_fused_kernel(const dp_attention_
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);       // one tile at a time: the accumulators of the other tiles stay where they are
-            if (!DEEP && t + 1 < NT) load_v(vb[(t + 1) & 1], t + 1, vj);
-            if (32 * (w + 4 * t) < dv) {
+            if (t + 1 < NT) at_load_v(c, vb[(t + 1) & 1], t + 1, vj);
+            if (32 * (c.w + 4 * t) < c.dv) {
                 if (rescale) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
                 }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 vv = vb[DEEP ? t : (t & 1)][g];
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, sc[4 * g], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, sc[4 * g + 1], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, sc[4 * g + 2], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, sc[4 * g + 3], oacc[t], 0, 0, 0);
-                }
+                at_pv_tile(oacc[t], vb[t & 1], sc);
             }
         }
     }
-    const float inv = 1.0f / (lrun + __shfl_xor(lrun, 32, 64));
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int c0 = 32 * (w + 4 * t);
-        if (c0 < dv) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (c < dv) ob[(long long)c * T + i0 + li] = oacc[t][r] * inv;
-            }
-        }
-    }
+    at_store<NT>(c, oacc, lrun);
 }
 
-// Software-pipelined form.  In the kernel above a wavefront alternates between matrix work (S^T, P.V) and ~230 vector
+// Software-pipelined schedule.  In the plain one a wavefront alternates between matrix work (S^T, P.V) and ~230 vector
 // instructions of exchange + softmax during which ITS share of the matrix pipe idles.  Here the S^T MFMAs of key block j + 1 are
 // issued BETWEEN the softmax stages of block j (ten stages, pinned with sched_barrier): an MFMA runs 64 cycles in the matrix
-// pipe after it issues, the vector instructions of the stage issue behind it meanwhile.  Operand registers as in DEEP: K of block
-// j + 2 is requested when block j + 1's S^T has issued, V of block j + 1 when block j's P.V has issued.  Same arithmetic in the
-// same order as the plain form.
+// pipe after it issues, the vector instructions of the stage issue behind it meanwhile.  Whole-block operand registers: K of
+// block j + 2 is requested when block j + 1's S^T has issued, V of block j + 1 when block j's P.V has issued.  Same arithmetic
+// in the same order as the plain schedule (channel tiles past d read zeros here instead of being skipped).
 template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_pipe_kernel(const dp_attention_params p) {
     __shared__ f32x4 xch[2][4][4][64];
-    const int lane = threadIdx.x & 63;
-    const int li = lane & 31, half = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int T = p.T, d = p.d, dv = p.dv;
-    const int nqb = T >> 5;
-    unsigned L = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) L = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int z = (int)(L / (unsigned)nqb);
-    const int i0 = ((int)L - z * nqb) * 32;
-    const int n = z / p.heads, h = z - n * p.heads;
-    const __amdgpu_buffer_rsrc_t qr = at_rsrc(p.q + n * p.q_bs + (long long)h * d * T, (unsigned)d * T * 4u);
-    const __amdgpu_buffer_rsrc_t kr = at_rsrc(p.k + n * p.k_bs + (long long)h * d * T, (unsigned)d * T * 4u);
-    const __amdgpu_buffer_rsrc_t vr = at_rsrc(p.v + n * p.v_bs + (long long)h * dv * T, (unsigned)dv * T * 4u);
-    float* __restrict__ ob = p.o + n * p.o_bs + (long long)h * dv * T;
-
+    const AtCtx c = at_setup(p);
     float qreg[NT][16];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            qreg[t][s] = at_load(qr, (unsigned)((32 * (w + 4 * t) + 2 * s + half) * T + i0 + li) * 4u);
+    at_load_q<NT>(c, qreg);
     f32x16 oacc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
-
     float kb[NT][16];
     f32x4 vb[NT][4];
-    const unsigned klane = (unsigned)(half * T + li) * 4u;
-    const unsigned vlane = (unsigned)(li * T + 4 * half) * 4u;
-    auto load_k = [&](float (&dst)[16], int t, unsigned kj) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            dst[s] = at_load(kr, kj + (unsigned)((32 * (w + 4 * t) + 2 * s) * T) * 4u);
-    };
-    auto load_v = [&](f32x4 (&dst)[4], int t, unsigned vj) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            dst[g] = at_load4(vr, vj + (unsigned)(32 * (w + 4 * t) * T + 8 * g) * 4u);
-    };
-    auto publish = [&](const f32x16& sacc, int xb) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 q4;
-            q4.x = sacc[4 * g]; q4.y = sacc[4 * g + 1]; q4.z = sacc[4 * g + 2]; q4.w = sacc[4 * g + 3];
-            xch[xb][w][g][lane] = q4;
-        }
-    };
-    const float c2 = p.scale * 1.44269504088896340736f;
 
-    // prologue: S^T of key block 0 (channel tiles past d read zeros: their MFMAs add nothing)
+    // prologue: S^T of key block 0
     {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) load_k(kb[t], t, klane);
+        for (int t = 0; t < NT; ++t) at_load_k(c, kb[t], t, c.klane);
         f32x16 s0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s0[r] = 0.f;
@@ -276,19 +251,19 @@ __global__ __launch_bounds__(256) void attn_fwd_pipe_kernel(const dp_attention_p
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 16; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[t][s], qreg[t][s], s0, 0, 0, 0);
-        const unsigned k1 = klane + (nqb > 1 ? 128u : 0u);
+        const unsigned k1 = c.klane + (c.nqb > 1 ? 128u : 0u);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) load_k(kb[t], t, k1);
+        for (int t = 0; t < NT; ++t) at_load_k(c, kb[t], t, k1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) load_v(vb[t], t, vlane);
-        publish(s0, 0);
+        for (int t = 0; t < NT; ++t) at_load_v(c, vb[t], t, c.vlane);
+        at_publish(xch[0][c.w], s0, c.lane);
         __syncthreads();
     }
 
     auto block = [&](int jb, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int xb = jb & 1;
-        unsigned kj2 = klane + (unsigned)(jb + 2) * 128u, vj1 = vlane + (unsigned)(jb + 1) * 128u;
+        unsigned kj2 = c.klane + (unsigned)(jb + 2) * 128u, vj1 = c.vlane + (unsigned)(jb + 1) * 128u;
         asm volatile("" : "+v"(kj2), "+v"(vj1));
         // ---- softmax of block jb, with the S^T MFMAs of block jb + 1 issued between its stages -------------------------
         f32x16 snext;
@@ -296,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_fwd_pipe_kernel(const dp_attention_p
         for (int r = 0; r < 16; ++r) snext[r] = 0.f;
         f32x4 part[2][4];
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) part[0][ww] = xch[xb][ww][0][lane];
+        for (int ww = 0; ww < 4; ++ww) part[0][ww] = xch[xb][ww][0][c.lane];
         float sc[16];
         float bm = 0.f, mnew = 0.f, alpha = 0.f, ps = 0.f;
         constexpr int M = LAST ? 0 : NT * 16;
@@ -309,13 +284,13 @@ __global__ __launch_bounds__(256) void attn_fwd_pipe_kernel(const dp_attention_p
             if (k < 4) {
                 if (k < 3) {
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) part[(k + 1) & 1][ww] = xch[xb][ww][k + 1][lane];
+                    for (int ww = 0; ww < 4; ++ww) part[(k + 1) & 1][ww] = xch[xb][ww][k + 1][c.lane];
                 }
                 const f32x4 a0 = part[k & 1][0], a1 = part[k & 1][1], a2 = part[k & 1][2], a3 = part[k & 1][3];
-                sc[4 * k] = (((a0.x + a1.x) + a2.x) + a3.x) * c2;
-                sc[4 * k + 1] = (((a0.y + a1.y) + a2.y) + a3.y) * c2;
-                sc[4 * k + 2] = (((a0.z + a1.z) + a2.z) + a3.z) * c2;
-                sc[4 * k + 3] = (((a0.w + a1.w) + a2.w) + a3.w) * c2;
+                sc[4 * k] = (((a0.x + a1.x) + a2.x) + a3.x) * c.c2;
+                sc[4 * k + 1] = (((a0.y + a1.y) + a2.y) + a3.y) * c.c2;
+                sc[4 * k + 2] = (((a0.z + a1.z) + a2.z) + a3.z) * c.c2;
+                sc[4 * k + 3] = (((a0.w + a1.w) + a2.w) + a3.w) * c.c2;
                 // the empty asm statements pin each stage's results HERE: hipcc otherwise sinks the whole softmax below the
                 // last MFMA (its results are first used by the P.V products)
                 asm volatile("" : "+v"(sc[4 * k]), "+v"(sc[4 * k + 1]), "+v"(sc[4 * k + 2]), "+v"(sc[4 * k + 3]));
@@ -342,53 +317,34 @@ __global__ __launch_bounds__(256) void attn_fwd_pipe_kernel(const dp_attention_p
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
-        if (!LAST && jb + 2 < nqb) {                                 // K registers are free: block jb + 2
+        if (!LAST && jb + 2 < c.nqb) {                               // K registers are free: block jb + 2
 #pragma unroll
-            for (int t = 0; t < NT; ++t) load_k(kb[t], t, kj2);
+            for (int t = 0; t < NT; ++t) at_load_k(c, kb[t], t, kj2);
         }
         // ---- O^T += V P^T ---------------------------------------------------------------------------------------------
         const bool rescale = __any(alpha != 1.0f);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
-            if (32 * (w + 4 * t) < dv) {
+            if (32 * (c.w + 4 * t) < c.dv) {
                 if (rescale) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
                 }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 vv = vb[t][g];
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, sc[4 * g], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, sc[4 * g + 1], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, sc[4 * g + 2], oacc[t], 0, 0, 0);
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, sc[4 * g + 3], oacc[t], 0, 0, 0);
-                }
+                at_pv_tile(oacc[t], vb[t], sc);
             }
         }
         if (!LAST) {                                                 // V registers are free: block jb + 1; publish its S^T
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) load_v(vb[t], t, vj1);
-            publish(snext, xb ^ 1);
+            for (int t = 0; t < NT; ++t) at_load_v(c, vb[t], t, vj1);
+            at_publish(xch[xb ^ 1][c.w], snext, c.lane);
             __syncthreads();
         }
     };
-    for (int jb = 0; jb + 1 < nqb; ++jb) block(jb, std::false_type{});
-    block(nqb - 1, std::true_type{});
-
-    const float inv = 1.0f / (lrun + __shfl_xor(lrun, 32, 64));
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int c0 = 32 * (w + 4 * t);
-        if (c0 < dv) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (c < dv) ob[(long long)c * T + i0 + li] = oacc[t][r] * inv;
-            }
-        }
-    }
+    for (int jb = 0; jb + 1 < c.nqb; ++jb) block(jb, std::false_type{});
+    block(c.nqb - 1, std::true_type{});
+    at_store<NT>(c, oacc, lrun);
 }
 
 // 1 = the shapes the fused kernel takes: tokens in whole 32-blocks, head widths up to 640 channels (5 tiles per wavefront)
@@ -405,22 +361,12 @@ extern "C" int dp_attention_fwd(const dp_attention_params* p, void* stream) {
     const int nt = (tiles + 3) / 4;
     const dim3 grid((unsigned)((long long)p->N * p->heads * (p->T / 32)));
     hipStream_t st = (hipStream_t)stream;
-    const int deep = p->variant == 2;
-#define AT_GO(NT_) do { if (deep) DP_LAUNCH((attn_fwd_fused_kernel<NT_, true>), grid, dim3(256), 0, st, *p); \
-                        else DP_LAUNCH((attn_fwd_fused_kernel<NT_, false>), grid, dim3(256), 0, st, *p); } while (0)
-    // variant: 1 = rolling tile buffers, 2 = whole-block prefetch, 3 = software-pipelined, 0 = the library's choice per width
+    // variant: 1 = plain schedule (rolling operand buffers), 2 = software-pipelined, 0 = the library's choice per width
     // [measured, tools/bench_attention.py]: the pipelined form wins for heads of <= 256 channels (2 tiles per wavefront, two
-    // workgroups per CU), the rolling buffers above that (the other two need > 256 registers there: one workgroup per CU)
-    if (p->variant == 3 || (p->variant == 0 && nt <= 2)) {
-        switch (nt) {
-            case 1: DP_LAUNCH(attn_fwd_pipe_kernel<1>, grid, dim3(256), 0, st, *p); break;
-            case 2: DP_LAUNCH(attn_fwd_pipe_kernel<2>, grid, dim3(256), 0, st, *p); break;
-            case 3: DP_LAUNCH(attn_fwd_pipe_kernel<3>, grid, dim3(256), 0, st, *p); break;
-            case 4: DP_LAUNCH(attn_fwd_pipe_kernel<4>, grid, dim3(256), 0, st, *p); break;
-            default: DP_LAUNCH(attn_fwd_pipe_kernel<5>, grid, dim3(256), 0, st, *p); break;
-        }
-        return DP_LAUNCH_CHECK();
-    }
+    // workgroups per CU); above that it needs > 256 registers (one workgroup per CU) and the plain one wins
+    const bool pipe = p->variant == 2 || (p->variant == 0 && nt <= 2);
+#define AT_GO(NT_) do { if (pipe) DP_LAUNCH(attn_fwd_pipe_kernel<NT_>, grid, dim3(256), 0, st, *p); \
+                        else DP_LAUNCH(attn_fwd_fused_kernel<NT_>, grid, dim3(256), 0, st, *p); } while (0)
     switch (nt) {
         case 1: AT_GO(1); break;
         case 2: AT_GO(2); break;

@@ -199,8 +199,8 @@ typedef struct dp_attention_params {
     long long q_bs, k_bs, v_bs, o_bs;
     int N, heads, d, dv, T;
     float scale;
-    int variant;                           /* 0 = library's choice; 1 / 2 / 3 force the rolling / whole-block operand prefetch /
-                                              the software-pipelined schedule (same arithmetic, different instruction order) */
+    int variant;                           /* 0 = library's choice; 1 / 2 force the plain / the software-pipelined schedule
+                                              (same arithmetic, different instruction order) */
     int _pad;
 } dp_attention_params;
 int dp_attention_fwd(const dp_attention_params* p, void* stream);
