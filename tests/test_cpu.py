@@ -429,6 +429,80 @@ def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkey
             assert relerr(p.grad, P[n].grad) < 5e-5, n
 
 
+def test_fused_attention_lane_maps_restated_in_numpy():
+    """The register-level algorithm of csrc/attention.hip restated lane by lane (host logic, no GPU): with the MFMA operand map
+    a = A[lane & 31][lane >> 5], b = B[lane >> 5][lane & 31] and accumulator register r of a lane = D[(r & 3) + 8 (r >> 2) +
+    4 (lane >> 5)][lane & 31] (csrc/gemm.hip), (1) S^T = K^T Q puts 16 keys of ONE query in each lane, (2) accumulator register
+    r of the two lane halves is exactly the key pair MFMA step r of O^T += V P^T consumes, with V as component r & 3 of a 4-wide
+    load -- so P never leaves the registers -- and (3) splitting the CHANNELS over four wavefronts (tiles w, w + 4, ...; zero
+    fill past a ragged width, value width != key width) with the partial S^T tiles added in fixed order gives softmax attention.
+    Pins the index arithmetic of the kernel's comments; the kernel itself is tested on the GPU (test_fused_attention_*)."""
+    lane = np.arange(64)
+    li, half = lane & 31, lane >> 5
+    rowmap = np.array([[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for r in range(16)] for l in range(64)])
+
+    def mfma(a, b, acc):
+        D = np.stack([a[:32], a[32:]], 1) @ np.stack([b[:32], b[32:]], 0)
+        out = acc.copy()
+        for r in range(16):
+            out[:, r] += D[rowmap[:, r], li]
+        return out
+
+    def ld(x, c, j):                                     # raw buffer load: a channel past the slab reads 0
+        c = np.asarray(c)
+        return np.where(c < x.shape[0], x[np.minimum(c, x.shape[0] - 1), j], 0.0)
+
+    def fused(q, k, v, scale):
+        d, T = q.shape
+        dv = v.shape[0]
+        NT = -(-max(-(-d // 32), -(-dv // 32)) // 4)
+        o = np.zeros((dv, T))
+        for i0 in range(0, T, 32):
+            m = np.full(64, -np.inf)
+            l = np.zeros(64)
+            oacc = [[np.zeros((64, 16)) for _ in range(NT)] for _ in range(4)]
+            for j0 in range(0, T, 32):
+                part = []
+                for w in range(4):
+                    sacc = np.zeros((64, 16))
+                    for t in range(NT):
+                        c0 = 32 * (w + 4 * t)
+                        for s_ in range(16):
+                            sacc = mfma(ld(k, c0 + 2 * s_ + half, j0 + li), ld(q, c0 + 2 * s_ + half, i0 + li), sacc)
+                    part.append(sacc)
+                sc = (((part[0] + part[1]) + part[2]) + part[3]) * scale
+                bm = sc.max(1)
+                bm = np.maximum(bm, bm[lane ^ 32])
+                mn = np.maximum(m, bm)
+                alpha = np.exp(m - mn)
+                p = np.exp(sc - mn[:, None])
+                l = l * alpha + p.sum(1)
+                m = mn
+                for w in range(4):
+                    for t in range(NT):
+                        oacc[w][t] *= alpha[:, None]
+                        for g in range(4):
+                            for e in range(4):           # component e of the 16-byte load at key 8 g + 4 half
+                                vv = ld(v, 32 * (w + 4 * t) + li, j0 + 8 * g + 4 * half + e)
+                                oacc[w][t] = mfma(vv, p[:, 4 * g + e], oacc[w][t])
+            lt = l + l[lane ^ 32]
+            for w in range(4):
+                for t in range(NT):
+                    for r in range(16):
+                        c = 32 * (w + 4 * t) + rowmap[:, r]
+                        ok = c < dv
+                        o[c[ok], i0 + li[ok]] = (oacc[w][t][:, r] / lt)[ok]
+        return o
+
+    rng = np.random.default_rng(0)
+    for d, dv, T in ((64, 64, 64), (179, 133, 64), (256, 256, 96)):
+        q, k, v = rng.standard_normal((d, T)), rng.standard_normal((d, T)), rng.standard_normal((dv, T))
+        s = d ** -0.5 * (q.T @ k)
+        p = np.exp(s - s.max(1, keepdims=True))
+        ref = v @ (p / p.sum(1, keepdims=True)).T
+        assert np.abs(fused(q, k, v, d ** -0.5) - ref).max() < 1e-12, (d, dv, T)
+
+
 def test_fused_attention_wiring_on_mocked_kernels(mocked, monkeypatch):
     """Engine wiring of the fused attention forward (ops.FUSED_ATTN): taken by forwards that keep nothing for a backward, with
     the head / value-width arguments the three-launch path uses (multi-head UNet at T = 64, LDM transformer block at T = 64 /
