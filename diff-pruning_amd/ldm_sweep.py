@@ -250,7 +250,7 @@ class _Pipe:
         return cls(dev, LdmSweepStep(model, schedule, first_step.global_numel, engine=eng, grads=G2), stream, flat2)
 
     @contextlib.contextmanager
-    def scope(self, first):
+    def scope(self):
         if self.stream is None:
             yield
             return
@@ -355,7 +355,7 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
     with model.pin_weights():                    # the importance pass never writes weights: pack the operands once
         for t in range(num_steps):
             pipe = pipes[t % len(pipes)]
-            with pipe.scope(pipes[0]):
+            with pipe.scope():
                 xc, x_T, noise = draw(t)
                 c = embedder(xc)
                 samples = ddim_sample_cfg(model, schedule, x_T, c, uc, S=ddim_steps, scale=scale, engine=pipe.sample_engine)
