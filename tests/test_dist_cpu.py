@@ -52,10 +52,11 @@ def test_two_rank_sweep_equals_single_process(tmp_path):
         assert float((r0['ft_params'][n] - p).abs().max()) <= 2e-4 * float(p.abs().max()) + 1e-7, n
 
 
-def _run_ldm(world, outdir, thr):
+def _run_ldm(world, outdir, thr, pipelines=None):
     port = str(_free_port())
+    env = dict(os.environ, **({'DP_LDM_PIPELINES': str(pipelines)} if pipelines else {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, '_dist_worker_ldm.py'), str(r), str(world), port, outdir,
-                               str(thr)]) for r in range(world)]
+                               str(thr)], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=900) == 0
 
@@ -100,6 +101,21 @@ def test_two_rank_ldm_importance_pass_equals_single_process(tmp_path):
         if scale > 1e-7:
             assert float((a['grads'][n] - g).abs().max()) <= 5e-5 * scale, n
     assert len(u1['masks']) == 109 and a['masks'] == b['masks'] == u1['masks']
+    # (3) the same two-rank job with two importance steps in flight per rank (odd steps on a second engine and gradient buffer,
+    #     the loss all-reduce + state update ordered across the pipelines): same losses, stop step, masks
+    out2 = os.path.join(out, 'pipes2')
+    os.makedirs(out2)
+    _run_ldm(2, out2, 0.97, pipelines=2)
+    p0, p1 = torch.load(os.path.join(out2, 'ldm_r0_w2.pt')), torch.load(os.path.join(out2, 'ldm_r1_w2.pt'))
+    for key in ('driver', 'break', 'uneven'):
+        assert p0[key]['losses'] == r0[key]['losses'] and p0[key]['steps'] == r0[key]['steps']
+        assert p0[key]['accumulated'] == r0[key]['accumulated'] and p1[key]['losses'] == p0[key]['losses']
+    for n, g in a['grads'].items():
+        scale = float(g.abs().max())
+        assert torch.equal(p0['uneven']['grads'][n], p1['uneven']['grads'][n])
+        if scale > 1e-7:
+            assert float((p0['uneven']['grads'][n] - g).abs().max()) <= 1e-5 * scale, n
+    assert p0['uneven']['masks'] == a['masks']
 
 
 def test_rank_sharded_sampling_feeds_one_allreduce_fid_statistics(tmp_path):
