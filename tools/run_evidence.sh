@@ -19,7 +19,10 @@ bench)
 import json; d=json.load(open('$O/${R}_bench_$c.json')); r=d['roofline']
 print('$c', round(d['value'],2), d['unit'], round(d['ms_per_step'],2), 'ms/step; step_frac', round(r['step_frac'],3), 'ref-eq TF/s', round(r['step_tflops_reference_equivalent'],1), 'dominant', r['kernel'], round(r['achieved'],1))"
   done
-  ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log ;;
+  ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log
+  python tools/bench_attention.py 2>&1 | grep -v amdgpu.ids > $O/${R}_attention_fused.txt; cat $O/${R}_attention_fused.txt
+  python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_three_launch.json
+  DP_FUSED_ATTN=1 python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_fused_attn.json ;;
 profiles)
   stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
   DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
