@@ -6,6 +6,9 @@ per-pixel work on the device.
   utils.py:31-58     get_dataset: CIFAR-10 = RandomHorizontalFlip + ToTensor + Normalize(0.5, 0.5);
                      image folders = Resize(256) + RandomCrop(256) + the same three
   ddpm_exp/datasets/__init__.py:30-60,176-192   Resize + flip + ToTensor, then data_transform (uniform dequantization, 2x - 1)
+  ddpm_exp/datasets/__init__.py:60-152, celeba.py:50-139   config-driven datasets -> dataset_from_config (CIFAR10, CELEBA: split
+                     file, 128 x 128 crop window, resize; LSUN / FFHQ are LMDB databases: refused, lmdb is not in this environment)
+  utils.py:41-49     CIFAR-100              -> Cifar100Batches
   ddpm_train.py:313-318   DataLoader(shuffle=True)  -> DeviceLoader
 
 Host side (decode, resize, crop, shuffle) stays on the CPU like torchvision's PIL transforms; the device receives uint8 pixels
@@ -73,6 +76,53 @@ class Cifar10Batches:
 
     def __getitem__(self, idx):
         return self.data[idx]
+
+
+class Cifar100Batches(Cifar10Batches):
+    """utils.py:41-49 (`torchvision.datasets.CIFAR100`): `cifar-100-python/train` / `test`, same record layout as CIFAR-10."""
+
+    def __init__(self, root, train=True):
+        with open(os.path.join(root, 'cifar-100-python', 'train' if train else 'test'), 'rb') as f:
+            entry = pickle.load(f, encoding='latin1')
+        self.data = np.asarray(entry['data'], dtype=np.uint8).reshape(-1, 3, 32, 32)
+
+
+CELEBA_WINDOW = (25, 57, 153, 185)      # PIL box (left, upper, right, lower) of Crop(x1=57, x2=185, y1=25, y2=153)
+
+
+class CelebAAligned:
+    """ddpm_exp/datasets/celeba.py:50-107,137-139 with the transform of ddpm_exp/datasets/__init__.py:60-93: the aligned
+    178 x 218 JPEGs `root/Img/img_align_celeba/<name>` of one split of `root/Eval/list_eval_partition.txt` (`<name> <0|1|2>`
+    per line: train / valid / test), each cut to the 128 x 128 window around (cx, cy) = (89, 121) -- `Crop(x1, x2, y1, y2)`
+    calls `F.crop(img, top=x1, left=y1, height=x2 - x1, width=y2 - y1)`, i.e. rows 57..184 and columns 25..152 -- and
+    resized to `image_size` (bilinear, as transforms.Resize on a PIL image).  Attributes / identities / landmarks, which the
+    class also parses, are not read: the diffusion runners discard the target (`for i, (x, y) in enumerate(train_loader)`)."""
+    _SPLITS = {'train': 0, 'valid': 1, 'test': 2}
+
+    def __init__(self, root, split='train', image_size=64):
+        if split.lower() not in self._SPLITS:
+            raise ValueError('Wrong split entered! Please use split="train" or split="valid" or split="test"')
+        want = self._SPLITS[split.lower()]
+        self.root, self.image_size = root, int(image_size)
+        self.files = []
+        with open(os.path.join(root, 'Eval', 'list_eval_partition.txt')) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 2 and int(parts[1]) == want:
+                    self.files.append(parts[0])
+        if not self.files:
+            raise FileNotFoundError('split %r of %s lists no image' % (split, os.path.join(root, 'Eval', 'list_eval_partition.txt')))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        img = Image.open(os.path.join(self.root, 'Img', 'img_align_celeba', self.files[idx])).convert('RGB')
+        img = img.crop(CELEBA_WINDOW)
+        if img.size != (self.image_size, self.image_size):
+            img = img.resize((self.image_size, self.image_size), Image.BILINEAR)
+        return np.asarray(img, dtype=np.uint8)
 
 
 class ArrayDataset:
@@ -186,9 +236,45 @@ class DeviceLoader:
 
 
 def get_dataset(name_or_path, root='./data'):
-    """utils.py:31-58 (the transforms live in DeviceLoader / the device kernel): 'cifar10' or an image directory."""
+    """utils.py:31-58 (the transforms live in DeviceLoader / the device kernel): 'cifar10', 'cifar100' or an image directory."""
     if name_or_path.lower() == 'cifar10':
         return Cifar10Batches(os.path.join(root)), dict(crop=None)
+    if name_or_path.lower() == 'cifar100':
+        return Cifar100Batches(os.path.join(root)), dict(crop=None)
     if os.path.isdir(name_or_path):
         return UnlabeledImageFolder(name_or_path, transform=resize_shorter_side(256)), dict(crop=256)
     raise ValueError('unknown dataset %r' % (name_or_path,))
+
+
+
+def dataset_from_config(data, root='data', train=True):
+    """ddpm_exp/datasets/__init__.py:30-152 for the `data:` block of a ddpm_exp config (dict): returns (dataset, DeviceLoader
+    keywords).  The host side produces uint8 images of `image_size`; flip (`random_flip`), ToTensor, `uniform_dequantization` and
+    `rescaled` (2x - 1) are the device kernel's job (data_transform, :160-174).  CIFAR10 and CELEBA read the files torchvision
+    reads; LSUN and FFHQ are LMDB databases and `lmdb` is not part of this environment: they raise instead of guessing --
+    export them to an image folder and use UnlabeledImageFolder."""
+    name = str(data['dataset']).upper()
+    size = int(data.get('image_size', 32))
+    if data.get('gaussian_dequantization') or data.get('logit_transform'):
+        raise NotImplementedError('gaussian_dequantization / logit_transform: no shipped config enables them')
+    kw = dict(mode=RESCALE if data.get('rescaled', True) else RAW, flip_p=0.5 if (train and data.get('random_flip', True)) else 0.0,
+              dequant=bool(data.get('uniform_dequantization', False)), crop=None)
+    if name == 'CIFAR10':
+        ds = Cifar10Batches(os.path.join(root, 'cifar10'), train=train)
+        if size != 32:
+            raise NotImplementedError('CIFAR10 at image_size %d: the shipped configs use 32' % size)
+        return ds, kw
+    if name == 'CELEBA':
+        return CelebAAligned(os.path.join(root, 'celeba'), 'train' if train else 'test', size), kw
+    if name in ('LSUN', 'FFHQ'):
+        raise NotImplementedError('%s is an LMDB database (ddpm_exp/datasets/lsun.py, ffhq.py); the lmdb module is not available '
+                                  'here -- export the images to a folder and pass it to UnlabeledImageFolder' % name)
+    raise ValueError('unknown dataset %r' % (data['dataset'],))
+
+
+def inverse_data_transform(x, rescaled=True):
+    """ddpm_exp/datasets/__init__.py:177-186 for the shipped configs (no image_mean, no logit transform): samples in [-1, 1]
+    -> [0, 1], clamped.  A few elementwise torch ops on the sampler's OUTPUT (image saving), not part of the timed path."""
+    if rescaled:
+        x = (x + 1.0) / 2.0
+    return torch.clamp(x, 0.0, 1.0)

@@ -429,6 +429,54 @@ def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkey
             assert relerr(p.grad, P[n].grad) < 5e-5, n
 
 
+def test_celeba_cifar100_and_config_datasets(tmp_path):
+    """SURVEY §8(f) rank 4, host side: the CelebA split file + crop window + resize of ddpm_exp/datasets (celeba.py:50-107,
+    __init__.py:60-93), CIFAR-100's pickle (utils.py:41-49) and the `data:` block dispatch; LSUN / FFHQ (LMDB) refuse."""
+    import pickle
+    from PIL import Image
+    data = pkg('data')
+    root = tmp_path / 'celeba'
+    (root / 'Img' / 'img_align_celeba').mkdir(parents=True)
+    (root / 'Eval').mkdir()
+    rng = np.random.default_rng(0)
+    names, arrs = [], {}
+    for i in range(5):
+        nm = '%06d.png' % (i + 1)                      # lossless stand-ins for the JPEGs: pixel values must survive
+        arr = rng.integers(0, 256, size=(218, 178, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(root / 'Img' / 'img_align_celeba' / nm)
+        names.append(nm)
+        arrs[nm] = arr
+    (root / 'Eval' / 'list_eval_partition.txt').write_text(''.join('%s %d\n' % (nm, sp) for nm, sp in zip(names, (0, 0, 1, 2, 0))))
+    ds = data.CelebAAligned(str(root), 'train', image_size=128)
+    assert len(ds) == 3 and ds.files == [names[0], names[1], names[4]]
+    # Crop(x1=57, x2=185, y1=25, y2=153) -> F.crop(img, top=57, left=25, 128, 128): rows 57..184, columns 25..152
+    assert np.array_equal(ds[2], arrs[names[4]][57:185, 25:153])
+    assert len(data.CelebAAligned(str(root), 'test', 64)) == 1 and data.CelebAAligned(str(root), 'valid', 64)[0].shape == (64, 64, 3)
+    small = data.CelebAAligned(str(root), 'train', image_size=64)[0]
+    want = np.asarray(Image.fromarray(arrs[names[0]][57:185, 25:153]).resize((64, 64), Image.BILINEAR))
+    assert np.array_equal(small, want)
+    with pytest.raises(ValueError, match='Wrong split'):
+        data.CelebAAligned(str(root), 'training')
+    c100 = tmp_path / 'cifar-100-python'
+    c100.mkdir()
+    px = rng.integers(0, 256, size=(7, 3072), dtype=np.uint8)
+    with open(c100 / 'train', 'wb') as f:
+        pickle.dump({'data': px, 'fine_labels': list(range(7))}, f)
+    d100, kw = data.get_dataset('CIFAR100', root=str(tmp_path))
+    assert len(d100) == 7 and d100.hwc is False and np.array_equal(d100[3], px[3].reshape(3, 32, 32)) and kw == dict(crop=None)
+    cfg = dict(dataset='CELEBA', image_size=64, random_flip=True, rescaled=True, uniform_dequantization=False,
+               gaussian_dequantization=False, logit_transform=False)
+    dsc, kw = data.dataset_from_config(cfg, root=str(tmp_path))
+    assert isinstance(dsc, data.CelebAAligned) and len(dsc) == 3
+    assert kw == dict(mode=data.RESCALE, flip_p=0.5, dequant=False, crop=None)
+    assert data.dataset_from_config(cfg, root=str(tmp_path), train=False)[1]['flip_p'] == 0.0
+    for name in ('LSUN', 'FFHQ'):
+        with pytest.raises(NotImplementedError, match='LMDB'):
+            data.dataset_from_config(dict(cfg, dataset=name), root=str(tmp_path))
+    x = torch.tensor([-1.5, -1.0, 0.0, 1.0, 2.0])
+    assert torch.equal(data.inverse_data_transform(x), torch.tensor([0.0, 0.0, 0.5, 1.0, 1.0]))
+
+
 def test_fused_attention_lane_maps_restated_in_numpy():
     """The register-level algorithm of csrc/attention.hip restated lane by lane (host logic, no GPU): with the MFMA operand map
     a = A[lane & 31][lane >> 5], b = B[lane >> 5][lane & 31] and accumulator register r of a lane = D[(r & 3) + 8 (r >> 2) +
