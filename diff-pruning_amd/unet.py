@@ -225,8 +225,8 @@ class UNet2DModel(nn.Module):
         only: the HIP engine (packed operands, streams) is rebuilt on first use after loading."""
         state = dict(self.__dict__)
         state['_engine'] = None
-        state.pop('_leaf_cache', None)
-        state.pop('_structure_mode', None)
+        for k in ('_leaf_cache', '_structure_tracing', '_hook_warned'):
+            state.pop(k, None)
         return state
 
     # ------------------------------------------------------------------------------------------
@@ -283,31 +283,71 @@ class UNet2DModel(nn.Module):
         t = t.to(sample.device)
         return t * torch.ones(sample.shape[0], dtype=t.dtype, device=sample.device)
 
-    # ---- structure-only forward for autograd tracers (boundary B2, ddpm_prune.py:79-87) -------------------------------------
-    # `tp.pruner.MagnitudePruner(model, example_inputs, ...)` builds its DependencyGraph by registering forward hooks on the
-    # Conv2d / Linear / GroupNorm leaves, calling `model(**example_inputs)` and walking the `grad_fn`s of the result
-    # (ddpm_exp/torch_pruning/dependency.py:631-690).  The HIP engine never calls the holder modules and is ONE autograd
-    # node, so a hooked model takes this path instead: the reference's layer sequence (unet_2d.py:219-316, resnet.py:589-639,
-    # attention_processor.py:870-935) over the holder modules on a batch of ZERO images -- every leaf is called once, per-layer
-    # `grad_fn`s exist, shapes propagate, and there are NO VALUES: it cannot serve as a numerics path.
-    def _leaf_hooked(self):
-        leaves = self.__dict__.get('_leaf_cache')
-        if leaves is None:
+    # ---- forward hooks on the holder leaves (boundary B2, ddpm_prune.py:79-89) --------------------------------------------
+    # The HIP engine never calls the Conv2d / Linear / GroupNorm holder modules and is ONE autograd node, so hooks registered on
+    # them cannot fire from the numerics path.  What a hooked forward does is decided by WHO owns the hooks -- never silently:
+    #   * an autograd tracer (`tp.pruner.MagnitudePruner(model, example_inputs, ...)` builds its DependencyGraph by hooking the
+    #     leaves, calling `model(**example_inputs)` and walking the `grad_fn`s of the result, ddpm_exp/torch_pruning/
+    #     dependency.py:631-690; this package's trace.py does the same) or an explicit `with model.structure_tracing():`
+    #     -> `structure_forward`: the reference's layer sequence (unet_2d.py:219-316, resnet.py:589-639,
+    #     attention_processor.py:870-935) over the holder modules on a batch of ZERO images: every leaf is called once, per-layer
+    #     `grad_fn`s exist, shapes propagate, there are NO VALUES (a tracer never reads any).  One warning per model.
+    #   * any other hook (a MAC counter such as `tp.utils.count_ops_and_params`, ddpm_prune.py:89,118; a profiler; a debugging
+    #     hook): the same layer sequence runs at the CALLER'S batch under FakeTensorMode -- hooks fire once per leaf and see
+    #     shape-correct FakeTensors (reading a value out of one raises) -- and the returned sample is then computed by the HIP
+    #     engine as in an un-hooked call: `-> FloatTensor[B, C, H, W]` always holds.  One warning per model.
+    TRACER_HOOK_MODULES = ('torch_pruning.dependency',)      # suffixes of `hook.__module__` that identify an autograd tracer
+
+    def _leaf_hook_dicts(self):
+        dicts = self.__dict__.get('_leaf_cache')
+        if dicts is None:        # the holder leaves are fixed at construction (pruning slices parameters, never swaps modules)
             leaves = [m for m in self.modules() if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm))]
-            self.__dict__['_leaf_cache'] = leaves
-        return any(m._forward_hooks or m._forward_pre_hooks for m in leaves)
+            dicts = [m._forward_hooks for m in leaves] + [m._forward_pre_hooks for m in leaves]
+            self.__dict__['_leaf_cache'] = dicts
+        return dicts
+
+    def _leaf_hook_owner(self):
+        """None (no hook on any holder leaf), 'tracer' (every hook belongs to an autograd tracer) or 'other'."""
+        dicts = self._leaf_hook_dicts()
+        if not any(dicts):
+            return None
+        own = __name__.rsplit('.', 1)[0] + '.trace'
+        for d in dicts:
+            for fn in d.values():
+                fn = getattr(fn, 'func', fn)                                  # functools.partial
+                mod = getattr(getattr(fn, '__func__', fn), '__module__', None) or ''
+                if not (mod == own or any(mod == s or mod.endswith('.' + s) for s in self.TRACER_HOOK_MODULES)):
+                    return 'other'
+        return 'tracer'
+
+    def _warn_once(self, key, msg):
+        import warnings
+        seen = self.__dict__.setdefault('_hook_warned', set())
+        if key not in seen:
+            seen.add(key)
+            warnings.warn(msg, stacklevel=4)
+
+    def structure_tracing(self):
+        """Context manager: every forward inside the block is the zero-image `structure_forward` (for autograd tracers this
+        package does not recognise by their hooks' module)."""
+        return _StructureTracing(self)
 
     def structure_forward(self, sample, timestep):
         """Forward through the holder modules on a batch of ZERO images: every leaf runs once with the real ATen autograd
         nodes behind it (the same graph the reference's model produces), shapes propagate, and not one value is computed."""
         dev = self.conv_in.weight.device
         x = torch.empty((0,) + tuple(sample.shape[1:]), dtype=torch.float32, device=dev)
-        self.__dict__['_structure_mode'] = True
-        try:
-            with torch.enable_grad():
-                return self.forward(x, None)
-        finally:
-            self.__dict__['_structure_mode'] = False
+        with torch.enable_grad():
+            return UNet2DOutput(sample=self._structure_layers(x))
+
+    def shape_forward(self, sample):
+        """The layer sequence at the caller's batch under FakeTensorMode: leaf hooks fire with shape-correct FakeTensors, no
+        kernel of any backend runs.  Returns the output shape."""
+        from torch._subclasses.fake_tensor import FakeTensorMode
+        dev = self.conv_in.weight.device
+        with FakeTensorMode(allow_non_fake_inputs=True), torch.no_grad():
+            x = torch.empty(tuple(sample.shape), dtype=torch.float32, device=dev)
+            return tuple(self._structure_layers(x).shape)
 
     def _structure_layers(self, x):
         F = torch.nn.functional
@@ -363,12 +403,22 @@ class UNet2DModel(nn.Module):
     def forward(self, sample, timestep, class_labels=None, return_dict=True):
         if class_labels is not None:
             raise ValueError('class conditioning is not part of this model')
-        if self.__dict__.get('_structure_mode'):
-            out = self._structure_layers(sample)
-            return UNet2DOutput(sample=out) if return_dict else (out,)
-        if self._leaf_hooked():
+        if self.__dict__.get('_structure_tracing'):
             out = self.structure_forward(sample, timestep)
             return out if return_dict else out.to_tuple()
+        owner = self._leaf_hook_owner()
+        if owner == 'tracer':
+            self._warn_once('tracer', 'UNet2DModel: the forward hooks on its Conv2d / Linear / GroupNorm leaves belong to an '
+                            'autograd tracer -> structure-only forward on a batch of ZERO images (per-layer grad_fns and '
+                            'shapes, no values); the returned sample has no elements')
+            out = self.structure_forward(sample, timestep)
+            return out if return_dict else out.to_tuple()
+        if owner == 'other':
+            self._warn_once('other', 'UNet2DModel: the HIP engine does not call the Conv2d / Linear / GroupNorm holder modules; '
+                            'forward hooks on them fire once per layer in a shape-only pass at the caller\'s batch '
+                            '(FakeTensors: shapes and dtypes, no values) and the returned sample is computed by the engine. '
+                            'Use `with model.structure_tracing():` for an autograd tracer.')
+            self.shape_forward(sample)
         t = self._timesteps(sample, timestep)
         if self.training:
             self._dropout_step = getattr(self, '_dropout_step', 0) + 1       # a fresh mask per training-mode forward
@@ -381,6 +431,20 @@ class UNet2DModel(nn.Module):
         if not return_dict:
             return (out,)
         return UNet2DOutput(sample=out)
+
+
+class _StructureTracing:
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        self.prev = self.model.__dict__.get('_structure_tracing', False)
+        self.model.__dict__['_structure_tracing'] = True
+        return self.model
+
+    def __exit__(self, *exc):
+        self.model.__dict__['_structure_tracing'] = self.prev
+        return False
 
 
 class _UNetFunction(torch.autograd.Function):

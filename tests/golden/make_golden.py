@@ -864,6 +864,39 @@ def do_b2():
     res['c1_reference_pruner_on_product_model'] = dict(pruned_groups=len(rec), masks_equal=True, shapes_equal=True,
                                                         params_after=int(n_after))
     print('b2 C1: the reference pruner pruned the product model to', n_after, 'parameters, masks equal')
+    # ddpm_prune.py:89,118: `tp.utils.count_ops_and_params(model, example_inputs)` -- the reference's hook-based MAC counter --
+    # on the product model (hooks fire in its shape-only pass; the sample itself comes from the engine, whose kernels are the
+    # CPU stand-ins of tests/mock_ops.py in this GPU-less container) against the same call on the reference's own model,
+    # before the prune and after it.
+    sys.path.insert(0, os.path.dirname(HERE))
+    import mock_ops
+    own_engine = importlib.import_module('diff-pruning_amd.engine')
+    own_engine.ops = mock_ops
+
+    def _cpu_engine(self):
+        if self._engine is None:
+            self._engine = own_engine.UNetEngine(self.config)
+        self._engine.packs.rebind()
+        self._engine.bind({n: p.detach() for n, p in self.named_parameters()}, None)
+        self._engine.set_dropout(None, 0, 0)
+        return self._engine
+    own_unet.UNet2DModel.engine = _cpu_engine
+    ex = {'sample': torch.randn(1, 3, 32, 32), 'timestep': torch.ones((1,)).long()}
+    fresh = own_unet.UNet2DModel(**cfg).eval()
+    gc.det_init_(fresh, 0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        base_own = tp.utils.count_ops_and_params(fresh, ex)
+        after_own = tp.utils.count_ops_and_params(own, ex)
+        out = fresh(**ex).sample
+    base_ref = tp.utils.count_ops_and_params(build_ref_unet(cfg, 0), ex)
+    assert tuple(out.shape) == (1, 3, 32, 32)
+    assert tuple(base_own) == tuple(base_ref) == (c1['base_macs'], c1['base_params']), (base_own, base_ref)
+    assert tuple(after_own) == (c1['macs_after'], c1['params_after']), after_own
+    res['count_ops_and_params'] = dict(count_ops_equal=True, base_macs=float(base_own[0]), base_params=int(base_own[1]),
+                                       macs_after=float(after_own[0]), params_after=int(after_own[1]))
+    print('b2 count_ops_and_params (reference counter on the product model):', base_own, '->', after_own)
     json.dump(res, open(os.path.join(HERE, 'b2_reference_pruner_on_product_model.json'), 'w'))
 
 

@@ -1756,13 +1756,19 @@ def test_reference_pruner_traces_and_prunes_the_product_model():
     assert fx['tiny']['equal_to_reference_model'] is True
     c1 = fx['c1_reference_pruner_on_product_model']
     assert c1['masks_equal'] and c1['shapes_equal'] and c1['params_after'] == 19851157 == load_json('cifar_c1.json')['params_after']
+    # the reference's hook-based MAC counter (ddpm_prune.py:89,118) on the product model == on the reference's own model
+    co, fx1 = fx['count_ops_and_params'], load_json('cifar_c1.json')
+    assert co['count_ops_equal'] is True
+    assert (co['base_macs'], co['base_params']) == (fx1['base_macs'], fx1['base_params']) == (6064135040.0, 35746307)
+    assert (co['macs_after'], co['params_after']) == (fx1['macs_after'], fx1['params_after'])
 
 
 def test_hooked_model_runs_the_structure_only_forward():
-    """What that fixture rests on, checked without the reference: a model whose leaves carry forward hooks (how an autograd tracer
-    observes it) runs the layer sequence through its holder modules on a batch of ZERO images -- every Conv2d / Linear / GroupNorm
-    is called exactly once with a grad_fn behind its output, the result has no elements (it cannot serve as a numerics path), and
-    THIS repository's generic tracer, walking that graph, enumerates the reference's group tables (groups.json)."""
+    """What that fixture rests on, checked without the reference: inside `with model.structure_tracing():` -- and automatically
+    when every leaf hook belongs to an autograd tracer (this package's trace.py here; `torch_pruning.dependency` in the fixture) --
+    the layer sequence runs through the holder modules on a batch of ZERO images: every Conv2d / Linear / GroupNorm is called
+    exactly once with a grad_fn behind its output, the result has no elements (it cannot serve as a numerics path), and THIS
+    repository's generic tracer, walking that graph, enumerates the reference's group tables (groups.json)."""
     unet, trace, graph, pruning = pkg('unet'), pkg('trace'), pkg('graph'), pkg('pruning')
     fx = load_json('groups.json')
     cfgb = dict(gc.BEDROOM_CFG, block_out_channels=[32, 32, 64, 64, 128, 128], sample_size=64)
@@ -1772,18 +1778,86 @@ def test_hooked_model_runs_the_structure_only_forward():
         calls = {}
         hooks = [m.register_forward_hook(lambda m, i, o: calls.__setitem__(m, calls.get(m, 0) + (o.grad_fn is not None)))
                  for m in leaves]
-        out = model(sample=torch.randn(1, 3, H, H), timestep=torch.ones((1,)).long())
+        with model.structure_tracing():
+            out = model(sample=torch.randn(1, 3, H, H), timestep=torch.ones((1,)).long())
         for h in hooks:
             h.remove()
         assert out.sample.shape == (0, 3, H, H) and out.sample.grad_fn is not None and out[0] is out.sample
         assert len(calls) == len(leaves) and set(calls.values()) == {1}
         with pytest.raises(RuntimeError):                            # un-hooked: the HIP engine, which has no CPU path
             model(torch.randn(1, 3, H, H), torch.ones((1,)).long())
-        tg = trace.TracedGraph(model, {'sample': torch.randn(1, 3, H, H), 'timestep': torch.ones((1,)).long()})
+        with pytest.warns(UserWarning, match='autograd tracer'):     # the tracer's own hooks select the path by themselves
+            tg = trace.TracedGraph(model, {'sample': torch.randn(1, 3, H, H), 'timestep': torch.ones((1,)).long()})
         n2m = dict(model.named_modules())
         chan = graph.ChannelView(lambda name: pruning._out_channels(n2m[name]))
         mine = [[[m.name, m.kind, _ranges(m.idxs)] for m in members] for _, members in graph.all_groups(tg, lambda: chan, ('conv_out',))]
         assert mine == [t['members'] for t in fx[key]], key
+
+
+def _hook_macs(model, B, H):
+    """A hook-based MAC counter with the conventions of tp.utils.count_ops_and_params (op_counter.py:53-100: convolutions and
+    linears with their bias adds, 2 x elements for an affine GroupNorm), written here from scratch."""
+    tot = [0]
+
+    def conv(m, i, o):
+        pos = o.shape[0] * o.shape[2] * o.shape[3]
+        tot[0] += (m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels + (m.out_channels if m.bias is not None else 0)) * pos
+
+    def lin(m, i, o):
+        tot[0] += int(np.prod(i[0].shape)) * o.shape[-1] + (o.shape[-1] if m.bias is not None else 0)
+
+    def gn(m, i, o):
+        tot[0] += 2 * int(np.prod(i[0].shape))
+
+    hs = [m.register_forward_hook({torch.nn.Conv2d: conv, torch.nn.Linear: lin, torch.nn.GroupNorm: gn}[type(m)])
+          for m in model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.GroupNorm))]
+    return tot, hs
+
+
+def test_user_hooks_never_switch_the_model_to_a_zero_image_forward(mocked):
+    """Round-3 verdict, boundary B2: a forward hook on a holder leaf that does NOT belong to a tracer (a MAC counter -- the
+    reference script's own next line, ddpm_prune.py:89 --, a profiler, a debugging hook) must not change what `model(x, t)`
+    returns.  Hooks fire once per leaf in a shape-only pass at the CALLER'S batch; the sample comes from the engine (mocked
+    kernels here), shape [B, C, H, W]; a hook-based MAC counter sees exactly the MACs of the analytic count, i.e. the
+    reference's 6 064 135 040 per image (cifar_c1.json `base_macs`)."""
+    unet, pruning = pkg('unet'), pkg('pruning')
+    fx = load_json('cifar_c1.json')
+    model = _cpu_model(gc.CIFAR_CFG, 0)
+    x, t = torch.from_numpy(gc.det_clean((2, 3, 32, 32), 1)), torch.tensor([3, 500])
+    with torch.no_grad():
+        want = model(x, t).sample
+    seen = []
+    h = model.conv_in.register_forward_hook(lambda m, i, o: seen.append((tuple(i[0].shape), tuple(o.shape))))
+    with torch.no_grad(), pytest.warns(UserWarning, match='shape-only pass'):
+        got = model(x, t).sample
+    h.remove()
+    assert tuple(got.shape) == (2, 3, 32, 32) and torch.equal(got, want)              # values from the engine, not from the hooks' pass
+    assert seen == [((2, 3, 32, 32), (2, 128, 32, 32))]
+    for B in (1, 3):
+        tot, hs = _hook_macs(model, B, 32)
+        with torch.no_grad():
+            out = model(sample=torch.randn(B, 3, 32, 32), timestep=torch.ones((B,)).long()).sample
+        for hh in hs:
+            hh.remove()
+        assert tuple(out.shape) == (B, 3, 32, 32)
+        lin_bias = sum(m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))   # counted per CALL, not per image
+        assert fx['base_macs'] == pruning.utils.count_ops_and_params(model, None)[0]
+        assert tot[0] == B * fx['base_macs'] - (B - 1) * lin_bias
+    # a hook that reads VALUES out of the shape-only pass fails loudly instead of seeing garbage
+    h = model.conv_in.register_forward_hook(lambda m, i, o: float(o.sum()))
+    from torch._subclasses.fake_tensor import DataDependentOutputException
+    with pytest.raises(DataDependentOutputException):
+        model(x, t)
+    h.remove()
+
+
+def test_user_hook_on_a_cpu_model_raises_instead_of_returning_an_empty_tensor():
+    """No mocked engine: the hooked forward of a CPU-resident model ends where the un-hooked one does (RuntimeError: HIP only),
+    never in a [0, C, H, W] tensor."""
+    model = _cpu_model(gc.TINY_CFG, 0)
+    model.conv_in.register_forward_hook(lambda *a: None)
+    with pytest.raises(RuntimeError, match='HIP'), pytest.warns(UserWarning):
+        model(torch.randn(2, 3, 16, 16), torch.ones((2,)).long())
 
 
 def _ranges(idxs):
