@@ -41,10 +41,10 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+for _p in (ROOT,):
     if _p not in sys.path:
         sys.path.insert(0, _p)
-import golden_common as gc       # noqa: E402  (configs + deterministic init; reference-free)
+gc = importlib.import_module('diff-pruning_amd.synthetic')      # configs + seeded init
 
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 # the reference's own arithmetic per unit: forward + backward unless noted

@@ -159,7 +159,7 @@ _lib = None
 
 
 class DpHipError(RuntimeError):
-    pass
+    code = None              # the hipError_t a library call returned (None: the library itself is missing)
 
 
 def load():
@@ -181,4 +181,6 @@ def load():
 
 def check(err, what):
     if err != 0:
-        raise DpHipError('%s failed with hipError %d' % (what, err))
+        e = DpHipError('%s failed with hipError %d' % (what, err))
+        e.code = int(err)
+        raise e

@@ -143,6 +143,16 @@ extern "C" int dp_replay_build(void* graph_v, void** out) {
                 memset(&r.k, 0, sizeof(r.k));
                 RP_CHECK(hipGraphKernelNodeGetParams(gn[i], &r.k));
                 if (!r.k.func || !r.k.kernelParams) { err = (int)hipErrorNotSupported; goto fail; }     // `extra`-style launches: not re-issued
+                {   // a node captured from hipModuleLaunchKernel carries a hipFunction_t, which hipLaunchKernel cannot launch: such
+                    // a failure would surface part-way through a re-issued timestep (gradients half accumulated).  Only host-side
+                    // kernel symbols resolve here, so refuse the list now.
+                    hipFuncAttributes fa;
+                    if (hipFuncGetAttributes(&fa, r.k.func) != hipSuccess) {
+                        (void)hipGetLastError();
+                        err = (int)hipErrorNotSupported;
+                        goto fail;
+                    }
+                }
                 ++rp->n_kernel;
             } else if (ty == hipGraphNodeTypeMemset) {
                 r.kind = MEMSET;

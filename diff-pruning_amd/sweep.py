@@ -49,6 +49,10 @@ class HipSweepStep:
     micro = None
     _half = None
     stop_state = None          # device [loss_max, stopped, steps] of the on-device Diff-Pruning early exit (taylor_sweep)
+    _tp = None
+    _tp_want = 1
+    _tp_count = 0
+    sequential = False         # True: the caller reads every step's loss before the next (host-side threshold test): one pipeline
 
     def __init__(self, model, scheduler, clean, noise, global_numel, loss_kind='mse', global_batch=None, halves=None,
                  timestep_pipelines=None):
@@ -92,16 +96,27 @@ class HipSweepStep:
             width = self.eng.cfg.get('block_out_channels', [self.eng.cfg.get('model_channels', 128)])[0]
             big = clean.shape[0] * clean.shape[2] * clean.shape[3] * width >= OVERLAP_MIN_WORK
             timestep_pipelines = int(os.environ.get('DP_TIMESTEP_PIPELINES', str(TIMESTEP_PIPELINES if big else 1)))
+        # created lazily by the first call that can use them (never with a threshold, micro-batches or a captured step), so a
+        # sweep that cannot run two timesteps at once pays neither the second activation context nor the gradient buffer
         self._tp = None
-        if timestep_pipelines >= 2 and self._half is None and type(self.eng) is UNetEngine:
-            self._tp = []
-            for _ in range(timestep_pipelines - 1):
+        self._tp_want = timestep_pipelines if (self._half is None and type(self.eng) is UNetEngine) else 1
+        self._tp_count = 0
+
+    def _make_timestep_pipelines(self):
+        """The extra pipelines of `timestep_pipelines` >= 2; on an allocation failure the sweep stays on one pipeline."""
+        self._tp = []
+        try:
+            for _ in range(self._tp_want - 1):
                 self._setup_second_half()
                 tp, self._half = self._half, None
                 tp['eng'].set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off)
                 tp['synced'] = False
                 self._tp.append(tp)
-            self._tp_count = 0
+        except torch.cuda.OutOfMemoryError:
+            import warnings
+            warnings.warn('no memory for a second timestep pipeline (gradient buffer): sweeping with one')
+            self._half, self._tp = None, []
+        return self._tp
 
     def _setup_second_half(self):
         dev = self.clean.device
@@ -231,15 +246,29 @@ class HipSweepStep:
         self._step(self._t)
         self.stop_state = real_state
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph(keep_graph=True) if native else torch.cuda.CUDAGraph()
+        if native:
+            try:
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+            except TypeError:                              # a torch without keep_graph: no raw graph to read back
+                import warnings
+                warnings.warn('torch.cuda.CUDAGraph has no keep_graph: the captured timestep replays through hipGraphLaunch')
+                native, g = False, torch.cuda.CUDAGraph()
+        else:
+            g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._loss = self._step(self._t)
         self._graph = g
         self._replay = None
         if native:
+            from ._lib import DpHipError
             try:
                 self._replay = ops.ReplayList(g)
-            except Exception:                              # a node the list cannot re-issue: replay through hipGraphLaunch instead
+            except DpHipError as e:
+                if e.code != 801:                          # anything but hipErrorNotSupported is a real error of the build
+                    raise
+                import warnings                            # a node the list cannot re-issue: replay through hipGraphLaunch instead
+                warnings.warn('native replay refused the captured timestep (a node it cannot re-issue): falling back to '
+                              'hipGraphLaunch, measured ~3x slower per timestep')
                 g.instantiate()
         return self
 
@@ -258,11 +287,12 @@ class HipSweepStep:
         return loss
 
     def __call__(self, k):
-        if getattr(self, '_tp', None) and self.stop_state is None and self._graph is None and self.micro is None:
-            i = self._tp_count % (len(self._tp) + 1)           # round-robin: main pipeline first
+        if self._tp_want >= 2 and self.stop_state is None and self._graph is None and self.micro is None and not self.sequential:
+            tps = self._tp if self._tp is not None else self._make_timestep_pipelines()
+            i = self._tp_count % (len(tps) + 1)                # round-robin: main pipeline first
             self._tp_count += 1
             if i:
-                return self._second_pipeline_step(k, self._tp[i - 1])
+                return self._second_pipeline_step(k, tps[i - 1])
         if self._graph is not None:
             self._t.fill_(int(k))
             if self._replay is not None:
@@ -307,6 +337,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     import time
     import torch.distributed as dist
     t_start = time.perf_counter()
+    poll_wait = 0.0
     use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     B_local = clean_images.shape[0]
     per_img = clean_images[0].numel()
@@ -328,6 +359,10 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     if own_step:
         step_fn = HipSweepStep(model, scheduler, clean_images, noise, B_global * per_img, loss_kind, B_global)
         step_fn.micro = micro_batch
+    # a threshold makes the steps sequential (the loss of step k decides whether step k + 1 runs, on the device or on the
+    # host): timesteps of odd position must not run on another stream, whose loss the main stream's reads would not wait for
+    if isinstance(step_fn, HipSweepStep):
+        step_fn.sequential = thr is not None
         if use_graph:
             if thr is not None and device_exit and not two_phase:
                 # the captured loss kernel reads the early-exit state: it has to exist before the capture
@@ -363,7 +398,10 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
                 step_fn.backward_pending(cancel_if_stopped=True)
             k += 1
             if k % poll_every == 0 or k == num_steps:
-                if float(state[1]) != 0.0:                  # one host sync per poll_every timesteps
+                t_poll = time.perf_counter()
+                stopped = float(state[1]) != 0.0            # one host sync per poll_every timesteps
+                poll_wait += time.perf_counter() - t_poll
+                if stopped:
                     break
         step_fn.stop_state = None
         steps = int(float(state[2]))
@@ -397,7 +435,10 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
         else:
             pending.append(l)
     if timings is not None:
-        timings['enqueue_s'] = time.perf_counter() - t_start
+        # host time spent ENQUEUEING: the waits inside the polls of the on-device early exit (which drain the queue) are not part
+        # of it -- with them the figure is just the step time (bedroom-256: 58.07 of a 58.08 ms step in round 3)
+        timings['enqueue_s'] = time.perf_counter() - t_start - poll_wait
+        timings['poll_wait_s'] = poll_wait
     if hasattr(step_fn, 'finish'):
         step_fn.finish()
     if pending:

@@ -3,8 +3,8 @@
 import importlib, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
-import golden_common as gc
+sys.path[:0] = [ROOT]
+gc = importlib.import_module('diff-pruning_amd.synthetic')
 unet = importlib.import_module('diff-pruning_amd.unet'); sweep = importlib.import_module('diff-pruning_amd.sweep')
 diffusion = importlib.import_module('diff-pruning_amd.diffusion')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4

@@ -3,8 +3,8 @@
 import importlib, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
-import golden_common as gc
+sys.path[:0] = [ROOT]
+gc = importlib.import_module('diff-pruning_amd.synthetic')
 ldm = importlib.import_module('diff-pruning_amd.ldm'); ops = importlib.import_module('diff-pruning_amd.ops')
 m = ldm.UNetModel(**gc.LDM_CIN256_CFG); gc.det_init_(m, 1); m = m.cuda().eval()
 eng = m.engine(); grads = {n: torch.zeros_like(p) for n, p in m.named_parameters()}; eng.bind(eng.P, grads)

@@ -4,8 +4,8 @@ image-steps/s (ddpm_sample.py shape: batch 256, pruned UNet, forward only).  Syn
 import importlib, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests', 'golden')]
-import golden_common as gc
+sys.path[:0] = [ROOT]
+gc = importlib.import_module('diff-pruning_amd.synthetic')
 unet = importlib.import_module('diff-pruning_amd.unet'); sweep = importlib.import_module('diff-pruning_amd.sweep')
 diffusion = importlib.import_module('diff-pruning_amd.diffusion'); train = importlib.import_module('diff-pruning_amd.train')
 

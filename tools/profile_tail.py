@@ -10,9 +10,9 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+for p in (ROOT,):
     sys.path.insert(0, p)
-import golden_common as gc  # noqa: E402
+gc = importlib.import_module('diff-pruning_amd.synthetic')      # configs + seeded init
 
 unet = importlib.import_module('diff-pruning_amd.unet')
 sweep = importlib.import_module('diff-pruning_amd.sweep')
