@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .sweep import dist_active
 
 CFG_SHARED_STEM = not os.environ.get('DP_NO_CFG_SHARED_STEM')
 
@@ -305,7 +306,7 @@ def ldm_importance_sweep(model, embedder, schedule=None, num_steps=1000, thr=0.1
     import torch.distributed as dist
     from .sweep import flatten_grads
     dev = next(model.parameters()).device
-    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    use_dist = dist_active(group)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if use_dist else (0, 1)
     if shard is not None:
         if use_dist:

@@ -315,7 +315,8 @@ class FeatureStats:
         three quantities are summed over the ranks (ONE all-reduce of 1 + dims + dims^2 doubles: 33.6 MB for dims 2048).
         Afterwards finalize() returns the same (mu, sigma) on every rank.  A no-op outside a process group."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        from .sweep import dist_active
+        if not dist_active(group):
             return self
         n, k_r, s1, s2 = self._host_sums()
         dev = self.s1.device if dist.get_backend(group) == 'nccl' else torch.device('cpu')

@@ -26,6 +26,16 @@ TIMESTEP_PIPELINES = 2
 GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay one captured timestep (native replay list)
 
 
+def dist_active(group=None):
+    """True when the exchange steps of the data-parallel path run: an initialised process group of more than one rank -- or of
+    ONE rank under DP_FORCE_DIST=1, which is how the `-m gpu` suite drives every collective of the path (scalar-loss all-reduce,
+    flat-gradient all-reduce, finetune buckets, FID statistics) through RCCL on the single GPU of the test box."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('DP_FORCE_DIST') == '1'
+
+
 def flatten_grads(model):
     """Point every parameter's .grad at a slice of one zero-initialised flat fp32 buffer; returns the buffer."""
     params = [p for p in model.parameters()]
@@ -338,7 +348,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     import torch.distributed as dist
     t_start = time.perf_counter()
     poll_wait = 0.0
-    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    use_dist = dist_active(group)
     B_local = clean_images.shape[0]
     per_img = clean_images[0].numel()
     if use_dist:

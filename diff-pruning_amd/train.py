@@ -16,6 +16,7 @@ import math
 import torch
 
 from . import ops
+from .sweep import dist_active
 
 
 def antithetic_timesteps(bsz, num_train_timesteps, generator=None):
@@ -214,7 +215,7 @@ class FinetuneEngine:
         image_offset: global index of this rank's first image (default rank * B): the dropout masks are functions of the
         GLOBAL element index, so a sharded step draws the masks of the un-sharded one."""
         import torch.distributed as dist
-        use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        use_dist = dist_active(self.group)
         B = clean.shape[0]
         gb = global_batch if global_batch is not None else (B * dist.get_world_size(self.group) if use_dist else B)
         if image_offset is None:
