@@ -90,7 +90,7 @@ def run_all(forced):
         emb.embedding.weight.copy_(torch.from_numpy(gc.det_noise((1001, 16), 77)))
     emb = emb.to(DEV)
     import random
-    res = ldm_sweep.ldm_importance_sweep(lm, emb, num_steps=4, thr=0.5, n_samples=3, ddim_steps=3, latent_shape=(3, 16, 16),
+    res = ldm_sweep.ldm_importance_sweep(lm, emb, num_steps=4, thr=0.5, n_samples=3, ddim_steps=4, latent_shape=(3, 16, 16),
                                          class_rng=random.Random(3), seed=11)
     torch.cuda.synchronize()
     out['ldm'] = dict(steps=res['steps'], accumulated=res['accumulated'], losses=res['losses'], grads=res['flat_grads'].clone())
