@@ -239,44 +239,97 @@ extern "C" int dp_debug_read_clock(unsigned long long* out) {
 
 __device__ __forceinline__ float dp_splitk_sum(const float* __restrict__ ws, long long stride, int splits);
 
-// Split-K without a second launch: every workgroup stores its raw partial tile (conv_epilogue, ksplit branch), releases it
-// device-wide and takes a ticket from the tile's counter; the workgroup that draws the LAST ticket acquires, sums the ksplit
-// partials of the tile in ascending split order -- dp_splitk_sum, the order of conv_splitk_epilogue_kernel, so the result does
-// not depend on which workgroup happens to be last -- applies the epilogue and re-zeroes the counter for the next launch.
-// (The separate reduction launch was 4.5-9.5 % of the LDM / batch-4 steps: profiles/round2_{ldm,c1}_kernel_stats.csv.)
-template <int BM, int BN>
-__device__ __forceinline__ void conv_splitk_fold(const dp_conv_gemm_params& p, int m0, int n0) {
-    __shared__ unsigned s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // this thread's partial stores: visible to every XCD
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* c = p.tile_counters + ((unsigned)(m0 / BM) * gridDim.x + (unsigned)(n0 / BN));
-        const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned)p.ksplit - 1u) ? 1u : 0u;
-        if (s_last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Split-K without a second launch (round 4: MI355X_MICROARCH.md "publish-large" / cdna_hip_programming.md "in-launch split-K
+// reduction", the write-through form).  Every workgroup of a tile stores its raw accumulators as a SLAB in the workspace --
+// lane-linear 16-byte rows in accumulator-register order (float4 (sub-tile, q) of thread tid at ((sub*4 + q)*256 + tid)*16 bytes:
+// each wave instruction writes 1 KB contiguous), with `sc1` WRITE-THROUGH buffer stores, so no L2 write-back fence is needed --
+// drains its own stores (s_waitcnt vmcnt(0)), meets at the workgroup barrier, and ONE lane takes a ticket with a relaxed
+// agent-scope atomic.  The workgroup that draws the last ticket reads all ksplit slabs of the tile back with `sc1` loads (L2 /
+// fabric-served, never from its own L1) INTO the accumulator registers, summing in ascending split order with the arithmetic of
+// dp_splitk_sum -- the order of conv_splitk_epilogue_kernel, so the bits do not depend on who arrives last -- and then runs the
+// ordinary epilogue on them.  No per-thread fence, no per-element index arithmetic.
+// The "I am last" flag lives in the kernel's ONE LDS array (free after the K loop's final barrier): a second __shared__ object
+// made hipcc put an s_waitcnt vmcnt(0) behind the B-tile DMA of EVERY K tile of every conv_gemm_fast instantiation (round 3's
+// fold did exactly that -- measured on the ISA, /tmp/isa in DESIGN section 4 item 26).
+typedef unsigned dp_u32x4 __attribute__((ext_vector_type(4)));
+#define DP_AUX_SC1 16
+#ifndef DP_FOLD_ST_AUX
+#define DP_FOLD_ST_AUX DP_AUX_SC1
+#endif
+#ifndef DP_FOLD_LD_AUX
+#define DP_FOLD_LD_AUX DP_AUX_SC1
+#endif
+
+template <int TM, int TN, int TMS, int TNS>
+__device__ __forceinline__ void conv_splitk_fold(const dp_conv_gemm_params& p, f32x16 (&acc)[TM][TN], int row0, int col0,
+                                                 unsigned tile_id, int z, float* lds) {
+    constexpr unsigned SLAB_BYTES = TM * TN * 16u * 256u * 4u;        // = BM * BN * 4
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const float* tile_ws = p.ws + (size_t)tile_id * (size_t)p.ksplit * (SLAB_BYTES / 4);
+    const __amdgpu_buffer_rsrc_t rs = dp_rsrc_uniform(tile_ws, (unsigned)p.ksplit * SLAB_BYTES);
+    // The store descriptor points at THIS slice's slab and the stores carry NO scalar offset: hipcc pads the "VALU overwrites the
+    // data registers of a 128-bit buffer store" hazard only when soffset is not a register (GCNHazardRecognizer's rule), and with
+    // soffset in an SGPR the next v_or really did clobber v[2:3] of the float4 before the store had read them on gfx950 --
+    // sporadically, for 16 lanes at a time: [measured, round 4] slab element = the address temporary, bit for bit.
+    const __amdgpu_buffer_rsrc_t rw = dp_rsrc_uniform(tile_ws + (size_t)z * (SLAB_BYTES / 4), SLAB_BYTES);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]};
+                const unsigned off = (unsigned)((((tm * TN + tn) * 4 + q) * 256 + tid) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dp_u32x4, v), rw, (int)off, 0, DP_FOLD_ST_AUX);
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's slab rows have left for memory
+    __syncthreads();                                                 // ... and so have the other three waves'
+#ifdef DP_FOLD_RELEASE
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    unsigned* flag = reinterpret_cast<unsigned*>(lds);
+    if (tid == 0) {
+        unsigned* c = p.tile_counters + tile_id;
+        const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = (t == (unsigned)p.ksplit - 1u) ? 1u : 0u;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+        *flag = last;
     }
     __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const long long total = (long long)p.M * p.NPIX;
-    const int HoWo = p.g.Ho * p.g.Wo;
-    for (int e = threadIdx.x; e < BM * BN; e += 256) {
-        const int r = e / BN, c = e - r * BN;
-        const int m = m0 + r, pix = n0 + c;
-        if (m >= p.M || pix >= p.NPIX) continue;
-        const float a = dp_splitk_sum(p.ws + ((long long)m * p.NPIX + pix), total, p.ksplit);
-        const int img = pix / HoWo;
-        const int r_in = pix - img * HoWo;
-        float v = p.alpha * a;
-        if (p.bias) v += p.bias[m];
-        if (p.tadd) v += p.tadd[(long long)img * p.tadd_stride + m];
-        if (p.res) v += p.res[(long long)img * p.r_img_stride + (long long)m * HoWo + r_in];
-        v *= p.post_scale;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        float* o = p.out + (long long)img * p.o_img_stride + (long long)m * HoWo + r_in;
-        if (p.accumulate) v += *o;
-        *o = v;
-    }
+    if (*flag == 0u) return;
+#ifdef DP_FOLD_ACQUIRE
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+#endif
+    // reducer: sum_z slab[z] in ascending z, 8 slabs' loads in flight per accumulator row (dp_splitk_sum's arithmetic: the
+    // accumulator starts at 0.0f and missing tail entries add 0.0f -- what a load with bit 31 of its vector offset set returns)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned off = (unsigned)((((tm * TN + tn) * 4 + q) * 256 + tid) * 16);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int z0 = 0; z0 < p.ksplit; z0 += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {      // the range check covers the VECTOR offset only, not the scalar one
+                        unsigned o = (z0 + j < p.ksplit) ? off : DP_OOB;
+                        asm volatile("" : "+v"(o));
+                        v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs, (int)o, (int)((unsigned)(z0 + j) * SLAB_BYTES), DP_FOLD_LD_AUX));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += v[j];
+                }
+                acc[tm][tn][4 * q] = a.x; acc[tm][tn][4 * q + 1] = a.y; acc[tm][tn][4 * q + 2] = a.z; acc[tm][tn][4 * q + 3] = a.w;
+            }
+    conv_epilogue<TM, TN, TMS, TNS>(p, acc, row0, col0, lane, 0, false);
 }
 
 static unsigned dp_lds_pad() {
@@ -535,8 +588,10 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_pa
         dp_clk[1] = wall_clock64() - wclk0;
     }
 #endif
-    conv_epilogue<TM, TN, 32, 32>(p, acc, m0 + wm0, n0 + wn0, lane, z, ksplit);
-    if (ksplit && p.tile_counters) conv_splitk_fold<BM, BN>(p, m0, n0);
+    if (ksplit && p.tile_counters)
+        conv_splitk_fold<TM, TN, 32, 32>(p, acc, m0 + wm0, n0 + wn0, blockIdx.y * gridDim.x + (unsigned)(n0 / BN), z, smem);
+    else
+        conv_epilogue<TM, TN, 32, 32>(p, acc, m0 + wm0, n0 + wn0, lane, z, ksplit);
 }
 
 
@@ -866,8 +921,10 @@ __global__ __launch_bounds__(256, DP_FAST_MINBLOCKS) void conv_gemm_fast_kernel(
             __syncthreads();
         }
     }
-    conv_epilogue<TM, TN, TMS, TNS>(p, acc, m0 + wrow, n0 + wcol, lane, z, ksplit);
-    if (ksplit && p.tile_counters) conv_splitk_fold<BM, BN>(p, m0, n0);
+    if (ksplit && p.tile_counters)
+        conv_splitk_fold<TM, TN, TMS, TNS>(p, acc, m0 + wrow, n0 + wcol, blockIdx.y * gridDim.x + blockIdx.x, z, smem);
+    else
+        conv_epilogue<TM, TN, TMS, TNS>(p, acc, m0 + wrow, n0 + wcol, lane, z, ksplit);
 }
 
 static bool conv_fast_ok(const dp_conv_gemm_params& p) {

@@ -202,18 +202,26 @@ def _conv_ksplit(p, device):
         if p.tile != 3:
             p.tile = 0 if p.M > 64 else 1
         p.ksplit = s
-        p.ws = _p(_workspace(s * p.M * p.NPIX, device))
-        if SPLITK_FOLD:
+        if SPLITK_FOLD and s <= SPLITK_FOLD_MAX:
+            # in-kernel reduction: the partials are per-tile SLABS in accumulator-register order (whole tiles, also at the edges)
             bm, bn = (96, 128) if p.tile == 3 else _TILES[p.tile][:2]
-            p.tile_counters = _p(_tile_counters(-(-p.M // bm) * -(-p.NPIX // bn), device))
+            ntiles = -(-p.M // bm) * -(-p.NPIX // bn)
+            p.ws = _p(_workspace(ntiles * s * bm * bn, device))
+            p.tile_counters = _p(_tile_counters(ntiles, device))
+        else:
+            p.ws = _p(_workspace(s * p.M * p.NPIX, device))
 
 
 # Split-K partials reduced by the last-arriving workgroup instead of a second launch (dp_conv_gemm_params.tile_counters).
-# Bit-identical to the reduction launch (tests/test_kernels_gpu.py::test_conv_splitk_fold_equals_reduction_launch) and OFF:
-# [measured, round 3] the agent-scope release / acquire it needs compiles to a full L2 write-back + invalidate per wavefront
-# (buffer_wbl2 sc1 / buffer_inv sc1; 8 XCDs with private L2s) -- LDM CFG forward 27.6 -> 41.9 ms, CIFAR batch 4 11.0 -> 35.7 ms
-# per timestep.  The ~12 us reduction launches it would have removed (5.6 % of the LDM step) are the cheaper evil.
-SPLITK_FOLD = bool(os.environ.get('DP_SPLITK_FOLD'))
+# Bit-identical to the reduction launch (tests/test_kernels_gpu.py::test_conv_splitk_fold_equals_reduction_launch).
+# Round 3 wrote it with a release fence per thread + acquire (buffer_wbl2 / buffer_inv of a whole L2 per wavefront): 1.5-3x
+# slower, off.  Round 4 (csrc/gemm.hip conv_splitk_fold): write-through sc1 slab stores, one relaxed ticket, sc1 slab loads --
+# ON by default; DP_SPLITK_FOLD=0 brings the reduction launch back.
+SPLITK_FOLD = os.environ.get('DP_SPLITK_FOLD', '1') not in ('0', '')
+# The last arriver reads the tile's ksplit slabs ALONE (~65 GB/s for one workgroup): fine for 2-4 slabs of 48-64 KB, a loss for the
+# 32-128 slices of the tiny grids of a batch-4 step, whose reduction launch spreads the same bytes over the whole chip
+# [measured, round 4: CIFAR batch 4 replayed 8.9 ms per timestep with the reduction launches, 12.8 with every split folded]
+SPLITK_FOLD_MAX = int(os.environ.get('DP_SPLITK_FOLD_MAX', '4'))
 _tc_cache = {}
 
 

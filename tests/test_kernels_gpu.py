@@ -968,6 +968,7 @@ def test_conv_splitk_fold_equals_reduction_launch(ops, report, monkeypatch, N, C
     assert seen and all(s[0] >= 2 and not s[1] for s in seen), seen
     del seen[:]
     monkeypatch.setattr(ops, 'SPLITK_FOLD', True)
+    monkeypatch.setattr(ops, 'SPLITK_FOLD_MAX', 1 << 30)          # every split count, also the ones the default leaves to the launch
     n_bad = 0
     for rep in range(25):
         got = run()
