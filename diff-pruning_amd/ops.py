@@ -940,13 +940,19 @@ def softmax_fwd(s, out=None):
     return out
 
 
-# One fused attention kernel (csrc/attention.hip) for the forwards that keep nothing for a backward.  OFF by default this round
-# (DP_FUSED_ATTN=1 turns it on): parity-tested (tests/test_kernels_gpu.py::test_fused_attention_*), not yet timed end to end.
-FUSED_ATTN = bool(os.environ.get('DP_FUSED_ATTN'))
+# One fused attention kernel (csrc/attention.hip) for the forwards that keep nothing for a backward.  Default 'auto': used where
+# it measured faster than the three launches (profiles/round3_attention_fused.txt: T = 256 tokens with heads of <= 512 channels:
+# 1.13-1.52x -- every attention level of the CIFAR / bedroom UNets; T = 256, d = 576: 1.01x; T = 1024, d = 384: 0.85-0.95x, the
+# LDM 32 x 32 level, which keeps the three launches).  DP_FUSED_ATTN=1: every supported shape; DP_FUSED_ATTN=0: never.
+_fa = os.environ.get('DP_FUSED_ATTN', 'auto')
+FUSED_ATTN = {'0': False, '': False, '1': True}.get(_fa, 'auto')
 
 
 def attention_fused_ok(T, d, dv):
-    """Shapes dp_attention_fwd takes (tokens in whole 32-blocks, head widths <= 640); others keep the three launches."""
+    """Shapes dp_attention_fwd takes (tokens in whole 32-blocks, head widths <= 640) and -- with FUSED_ATTN == 'auto' -- runs
+    faster than the three launches; others keep the three launches."""
+    if FUSED_ATTN == 'auto' and not (T <= 256 and d <= 512 and dv <= 512):
+        return False
     return bool(_lib().dp_attention_fwd_supported(int(T), int(d), int(dv)))
 
 

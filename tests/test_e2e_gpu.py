@@ -1189,6 +1189,7 @@ def test_c5_ldm_cin256_full_size(report):
     pr_full, pr_sum = _ldm_masks(m_full), _ldm_masks(model)
     mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
     margin = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in pr_full.records)
+    e_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_sum.records))   # one process vs the summed 4-rank shares
     params_after = sum(p.numel() for p in model.parameters())
     del m_full, pr_full, pr_sum
     torch.cuda.empty_cache()
@@ -1225,10 +1226,11 @@ def test_c5_ldm_cin256_full_size(report):
             if e > worst:
                 worst, worst_name = e, k
     report['e2e/c5_ldm_cin256'] = dict(losses=r_full['losses'], shards2=out[2], shards4=out[4], mask_mismatches=mism, groups=109,
-                                       min_decision_margin=margin, params_after=params_after, sample_rel=e_x0, b1_loss_rel=e_l,
-                                       b1_grad_rel_worst=worst, b1_grad_worst_name=worst_name)
+                                       min_decision_margin=margin, shard_score_rel_worst=e_score, params_after=params_after,
+                                       sample_rel=e_x0, b1_loss_rel=e_l, b1_grad_rel_worst=worst, b1_grad_worst_name=worst_name)
     assert out[2]['loss_rel'] < 1e-5 and out[4]['loss_rel'] < 1e-5 and out[2]['grad_rel'] < 2e-5 and out[4]['grad_rel'] < 2e-5
     assert not mism                                                                    # (c)
+    assert margin > 10 * e_score          # the thinnest decision of the 109 groups is an order of magnitude outside the re-association noise
     assert e_x0 < 1e-4 and e_l < 1e-5 and worst < 5e-5                                 # (d)
 
 

@@ -1,14 +1,6 @@
-set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "splitk_fold" 2>&1 | tail -5
-for mode in max4 max16 off; do
-  case $mode in
-    max4) export DP_SPLITK_FOLD=1 DP_SPLITK_FOLD_MAX=4;;
-    max16) export DP_SPLITK_FOLD=1 DP_SPLITK_FOLD_MAX=16;;
-    off) export DP_SPLITK_FOLD=0;;
-  esac
-  echo "=== $mode"
-  timeout 400 python bench.py --config ldm --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ldm', d['ms_per_step'], d['value'])"
-  timeout 300 python tools/bench_c1_long.py 2>&1 | tail -2
+for l in "" a1b3 a1b2 a0b2 a0b1 a2b4 a0b0 r3 ""; do
+  if [ -n "$l" ]; then export DP_HIP_LIB=$PWD/diff-pruning_amd/libdp_hip_$l.so; else unset DP_HIP_LIB; fi
+  echo "=== lib ${l:-default(a1b4)}"
+  python tools/bench_conv_only.py 2>&1 | grep conv
 done
