@@ -86,6 +86,9 @@ _dr = C.POINTER(Dropout)
 # include/dp_hip.h (every declared symbol must resolve).
 SIGNATURES = {
     'dp_conv_gemm': [C.POINTER(ConvGemmParams), _vp],
+    'dp_conv_wino': [C.POINTER(ConvGemmParams), _vp],
+    'dp_conv_wino_supported': [C.POINTER(ConvGemmParams)],
+    'dp_pack_weight_wino': [_vp, _i, _i, _i, _vp, _i, _vp],
     'dp_nt_gemm': [C.POINTER(NtGemmParams), _vp],
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
     'dp_splitk_reduce_taps': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp],

@@ -1,0 +1,262 @@
+// 3x3 stride-1 'same' convolution as a ONE-DIMENSIONAL Winograd F(2, 3) implicit GEMM on the fp32 matrix cores.
+//
+// Round-3 verdict, item 5 (go / no-go): the direct implicit GEMM has plateaued at 0.79-0.81 of a roofline that is the fp32
+// MFMA rate itself; the lever left is executing fewer multiplies.  The 2-D F(2x2, 3x3) form (16/36 of the MACs) needs 16
+// accumulator sets per output tile -- no workgroup tile worth an MFMA fits the register file -- or a 4x activation round trip
+// through HBM that makes the 128-channel layers HBM-bound.  This is the form that fits the machine: F(2, 3) along W only.
+//   per (channel c, kernel row ky), output pair (2p, 2p+1), d_j = x[c][y + ky - 1][2p + j - 1], g_k = w[m][c][ky][k]:
+//     M0 += (d0 - d2) g0,  M1 += (d1 + d2) (g0 + g1 + g2)/2,  M2 += (d2 - d1) (g0 - g1 + g2)/2,  M3 += (d1 - d3) g2
+//     y[2p] = M0 + M1 + M2,  y[2p + 1] = M1 - M2 - M3
+//   4 multiplies for 2 outputs x 3 taps: 2/3 of the MACs (12 "taps" per channel on HALF the columns instead of 9).
+// Why it maps well:
+//   * ONE raw input image [BK channels][128 pixels] per (channel chunk, ky) in LDS serves all four positions -- they differ only
+//     in the LDS read offset -- so the B tile is fetched 3 times per channel chunk instead of 9, with 16-byte LDS-DMA loads that
+//     are always aligned (no horizontal tap shift, no border fix-up in LDS);
+//   * the input transform happens at FRAGMENT time: a lane reads d0..d3 of its (k, pair) (one ds_read_b64 + two ds_read_b32) and
+//     forms the four B operands with 4 VALU subtractions / additions per 4 MFMAs; left / right zero padding = two per-lane
+//     constant selects (a 128-pixel tile always starts and ends on an image-row boundary: W divides 128);
+//   * the four position accumulators of an output pair live in the same lane and register index, so the output transform is
+//     32 VALU adds in the epilogue and the two pixels of a pair leave as ONE 8-byte store.
+// Weights are packed once per sweep as U[ky][pos][c][m] (dp_pack_weight_wino).  Same epilogue operands as dp_conv_gemm.
+// fp32 everywhere; the result differs from the direct form by re-association (pre-summed taps, signed sums of inputs): ~1e-6.
+#include <cstdlib>
+#include <type_traits>
+#include "dp_common.h"
+
+#define DPW_RSRC_FLAGS 0x00020000
+#define DPW_OOB 0x80000000u
+typedef __attribute__((address_space(3))) void dpw_lds_void;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dpw_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DPW_RSRC_FLAGS);
+}
+
+// BM = 64 output channels x 64 pairs (128 pixels) per 256-thread workgroup; waves 2 x 2, each 32 rows x 32 pairs x 4 positions.
+template <int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const dp_conv_gemm_params p) {
+    constexpr int BM = 64, BP = 64, BN = 2 * BP;
+    constexpr int A_SZ = 4 * BK * BM;                  // [pos][k][m]
+    constexpr int B_SZ = BK * BN;                      // [k][pixel]
+    constexpr int STAGE = A_SZ + B_SZ;
+    constexpr int NJA = A_SZ / 4 / 256;                // 16-byte A loads per lane and K tile (4 / 2)
+    constexpr int NJB = B_SZ / 4 / 256;                // 16-byte B loads per lane and K tile (2 / 1)
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4];      // + 4: d3 of the last pair of the last row reads one past
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    const dp_conv_geom& g = p.g;
+    const int W = g.Wo, H = g.Ho, HW = H * W;
+    const int C = p.C;
+    const int C1 = p.X2 ? g.c_split : C;
+    const int nch = C / BK;
+    const int nIter = 3 * nch;
+
+    // ---- A loader: float4 element e = tid + 256 j of [pos][k][m/4]
+    unsigned a_voff[NJA];
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) {
+        const int e = tid + 256 * j;
+        const int pos = e / (BK * 16), k = (e / 16) % BK, m = m0 + 4 * (e % 16);
+        a_voff[j] = (m < p.lda) ? (unsigned)(((pos * C + k) * p.lda + m) * 4) : DPW_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rA = dpw_rsrc(p.A, p.a_bytes);
+    // ---- B loader: lane = (row of the wave's pair of rows, 4-pixel group)
+    const int g4 = lane & 31, rsub = lane >> 5;
+    unsigned x_pix1, x_pix2, vrow = 0;
+    {
+        const int gp = n0 + 4 * g4;
+        const bool gv = gp < p.NPIX;
+        const int pp = gv ? gp : 0;
+        const int img = pp / HW, r = pp - img * HW;
+        const int ho = r / W, wo = r - ho * W;
+        const unsigned lin = (unsigned)(ho * W + wo);
+        x_pix1 = (unsigned)((long long)img * g.x1_img_stride) + lin;
+        x_pix2 = (unsigned)((long long)img * g.x2_img_stride) + lin;
+        if (gv)
+            for (int ky = 0; ky < 3; ++ky)
+                if ((unsigned)(ho + ky - 1) < (unsigned)H) vrow |= 1u << ky;
+    }
+    unsigned b_voff1[NJB], b_voff2[NJB];
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+        const int row = 8 * j + 2 * wave + rsub;
+        b_voff1[j] = (x_pix1 + (unsigned)(row * HW)) * 4u;
+        b_voff2[j] = (x_pix2 + (unsigned)(row * HW)) * 4u;
+    }
+    // descriptor bases one image row back: the scalar offset of kernel row ky is ky * W * 4 >= 0
+    const __amdgpu_buffer_rsrc_t r1 = dpw_rsrc(p.X1 - W, p.x1_bytes + 4u * (unsigned)W);
+    const __amdgpu_buffer_rsrc_t r2 = dpw_rsrc((p.X2 ? p.X2 : p.X1) - W, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)W);
+
+    float* const ldsA = smem + 4 * (wave * 64);                     // + buf*STAGE + 1024*j
+    float* const ldsB = smem + A_SZ + 2 * wave * BN;                // + buf*STAGE + 8*j*BN
+    const unsigned a_ky_step = (unsigned)(4 * C) * (unsigned)p.lda * 4u;
+
+    int ch = 0, ky = 0;
+    auto dma_tile = [&](int buf) {
+        const unsigned a_soff = (unsigned)ky * a_ky_step + (unsigned)(ch * BK) * (unsigned)p.lda * 4u;
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            unsigned o = a_voff[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw_lds_void*)(ldsA + buf * STAGE + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
+        }
+        const int c0 = ch * BK;
+        const bool first = c0 < C1;
+        const unsigned b_soff = (unsigned)(((first ? c0 : c0 - C1) * HW + ky * W) * 4);
+        const bool tv = (vrow >> ky) & 1u;
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+            unsigned o = tv ? (first ? b_voff1[j] : b_voff2[j]) : DPW_OOB;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw_lds_void*)(ldsB + buf * STAGE + 8 * j * BN), 16, (int)o,
+                                                     (int)b_soff, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        if (++ky == 3) { ky = 0; ++ch; }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    // ---- fragment addressing: lane = (k half, column); A row wr*32 + li of position q, B pair wc*32 + li
+    const int li = lane & 31, lk = lane >> 5;
+    const float* fragA = smem + lk * BM + wr * 32 + li;                      // + (q*BK + 2*ks)*BM
+    const float* fragB = smem + A_SZ + lk * BN + 2 * (wc * 32 + li);         // + 2*ks*BN; d1 d2 at [0..1], d0 at [-1], d3 at [2]
+    // left / right zero padding: pixel 2p - 1 (2p + 2) lies outside the image row
+    const int px = n0 + 2 * (wc * 32 + li);
+    const int wo_p = px % W;
+    const bool pad_l = wo_p == 0, pad_r = wo_p + 2 == W;
+
+    dma_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIter) advance();
+        const float* Af = fragA + buf * STAGE;
+        const float* Bf = fragB + buf * STAGE;
+        float a[2][4], d[2][4];
+        auto frag = [&](int ks, float (&fa)[4], float (&fd)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = Af[(q * BK + 2 * ks) * BM];
+            // plain float reads (hipcc pairs them into one ds_read2_b32): a float2-typed LDS access makes the waitcnt pass
+            // treat the read as aliasing the LDS-DMA writes and drain vmcnt(0) right behind the prefetch
+            fd[1] = Bf[2 * ks * BN];
+            fd[2] = Bf[2 * ks * BN + 1];
+            fd[0] = Bf[2 * ks * BN - 1];
+            fd[3] = Bf[2 * ks * BN + 2];
+        };
+        frag(0, a[0], d[0]);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float d0 = pad_l ? 0.f : d[cur][0], d3 = pad_r ? 0.f : d[cur][3];
+            const float d1 = d[cur][1], d2 = d[cur][2];
+            const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], v0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], v1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], v2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], v3, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 1) { dma_tile(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- output transform + epilogue: col j = lane & 31 -> pair, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (px >= p.NPIX) return;
+    const int img = px / HW, r_in = px - img * HW;
+    float* optr = p.out + (long long)img * p.o_img_stride + r_in;
+    const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
+    const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
+    const int mb = m0 + wr * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float y0 = p.alpha * ((acc[0][r] + acc[1][r]) + acc[2][r]);
+        float y1 = p.alpha * ((acc[1][r] - acc[2][r]) - acc[3][r]);
+        if (p.bias) { const float b = p.bias[m]; y0 += b; y1 += b; }
+        if (tptr) { const float t = tptr[m]; y0 += t; y1 += t; }
+        if (rptr) { const float2 t = *reinterpret_cast<const float2*>(rptr + (long long)m * HW); y0 += t.x; y1 += t.y; }
+        y0 *= p.post_scale;
+        y1 *= p.post_scale;
+        if (p.act == 1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+        float2* o = reinterpret_cast<float2*>(optr + (long long)m * HW);
+        if (p.accumulate) { const float2 t = *o; y0 += t.x; y1 += t.y; }
+        *o = make_float2(y0, y1);
+    }
+}
+
+// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 128 (so it divides the 128-pixel tile
+// and the 16-byte loads are aligned), channel counts (per concat source) in whole K chunks, 8-byte aligned image planes.
+static int wino_bk(const dp_conv_gemm_params& p) {
+    const dp_conv_geom& g = p.g;
+    if (p.a_kc || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups || g.pad_t != 1 || g.pad_l != 1) return 0;
+    if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || p.ksplit > 1) return 0;
+    const int W = g.Wo;
+    if (W < 4 || W > 128 || (W & (W - 1))) return 0;
+    if ((p.lda & 3) || ((g.Ho * g.Wo) & 1)) return 0;
+    const int C1 = p.X2 ? g.c_split : p.C;
+    if (p.C % 16 == 0 && C1 % 16 == 0) return 16;
+    if (p.C % 8 == 0 && C1 % 8 == 0) return 8;
+    return 0;
+}
+
+extern "C" int dp_conv_wino_supported(const dp_conv_gemm_params* p) { return wino_bk(*p); }
+
+extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
+    const dp_conv_gemm_params& p = *pp;
+    if (p.M <= 0 || p.NPIX <= 0) return 0;
+    int bk = wino_bk(p);
+    if (!bk) return (int)hipErrorInvalidValue;
+    static const char* force = getenv("DP_WINO_BK");
+    if (force && atoi(force) == 8) bk = 8;
+    dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64);
+    if (bk == 16) DP_LAUNCH((conv_wino_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else          DP_LAUNCH((conv_wino_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    return DP_LAUNCH_CHECK();
+}
+
+// U[(ky*4 + pos)*K + k][ld] from a torch [Co][Ci][3][3] weight.  mode 0 (forward): K = Ci, columns m = co, taps as stored;
+// mode 1 (input gradient): K = Co, columns m = ci, both tap axes flipped.
+__global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ Wt, int Co, int Ci, int mode,
+                                                               float* __restrict__ dst, int ld) {
+    const int K = mode == 0 ? Ci : Co, Mv = mode == 0 ? Co : Ci;
+    const long long total = 12ll * K * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i % ld);
+        const long long rk = i / ld;
+        const int k = (int)(rk % K);
+        const int kp = (int)(rk / K);
+        const int ky = kp >> 2, pos = kp & 3;
+        float v = 0.f;
+        if (m < Mv) {
+            const float* w = mode == 0 ? Wt + ((long long)m * Ci + k) * 9 + ky * 3 : Wt + ((long long)k * Ci + m) * 9 + (2 - ky) * 3;
+            const float g0 = mode == 0 ? w[0] : w[2], g1 = w[1], g2 = mode == 0 ? w[2] : w[0];
+            v = pos == 0 ? g0 : pos == 1 ? ((g0 + g1) + g2) * 0.5f : pos == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+        }
+        dst[i] = v;
+    }
+}
+
+extern "C" int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream) {
+    const long long total = 12ll * (mode == 0 ? Ci : Co) * ld;
+    if (total <= 0) return 0;
+    long long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    DP_LAUNCH(pack_weight_wino_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, mode, dst, ld);
+    return DP_LAUNCH_CHECK();
+}

@@ -72,7 +72,9 @@ class _Packs:
         hit = self._c.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1], hit[2]
-        if isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
+        if isinstance(mode, tuple) and mode[0] == 'wino':    # ('wino', 0 | 1): Winograd F(2, 3) operand (ops.pack_weight_wino)
+            buf, ld = ops.pack_weight_wino(w, mode[1])
+        elif isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
             weff = self.get_weff(name, w)
             buf, ld = ops.pack_weight(weff[mode[1]], mode[2])
         elif isinstance(mode, tuple):             # ('s2', ph, pw, pad): one parity class of a stride-2 dgrad (ops.conv_dgrad_s2)
@@ -314,6 +316,10 @@ class UNetEngine:
     def _conv(self, name, x, x2, spec, **kw):
         w = self.P[name + '.weight']
         wp, ld = self.packs.get(name, w, 0)
+        # 3x3 / stride 1 / pad 1 layers with a grid worth it: Winograd F(2, 3) along W, 2/3 of the multiplies (csrc/winograd.hip)
+        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and ops.wino_wanted(
+                w.shape[0], (x.shape[1],) + ((x2.shape[1],) if x2 is not None else ()), x.shape[0], x.shape[2], x.shape[3], spec):
+            kw['wino'] = self.packs.get(name, w, ('wino', 0))
         return ops.conv_forward(x, x2, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), **kw)
 
     def _linear(self, name, x2d):
@@ -384,7 +390,12 @@ class UNetEngine:
             packs = [self.packs.get(name, w, ('s2', ph, pw, spec.pad)) for ph in (0, 1) for pw in (0, 1)]
             return ops.conv_dgrad_s2(dy, packs, w.shape[1], spec, in_hw, add=dx_add)
         wd, ldd = self.packs.get(name, w, 1)
-        dx = ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
+        wino = None
+        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and tuple(in_hw) == tuple(dy.shape[2:]) and \
+                ops.wino_wanted(w.shape[1], (w.shape[0],), dy.shape[0], dy.shape[2], dy.shape[3], spec):
+            wino = self.packs.get(name, w, ('wino', 1))
+        dx = ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate,
+                            **({'wino': wino} if wino is not None else {}))
         if dx_add is not None:
             ops.copy_strided(dx_add, dx, accumulate=True)
         return dx

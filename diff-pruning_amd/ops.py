@@ -322,10 +322,61 @@ class ConvSpec:
         return (tot - self.k) // 2 + 1, (totw - self.k) // 2 + 1
 
 
+# ---- Winograd F(2, 3) along W for the 3x3 / stride 1 / pad 1 convolutions (csrc/winograd.hip): 2/3 of the multiplies ----------
+WINO = os.environ.get('DP_WINO', '1') not in ('0', '')
+WINO_MIN_TILES = int(os.environ.get('DP_WINO_MIN_TILES', '512'))     # 64 x 128-pixel tiles; smaller grids keep the split-K direct form
+
+
+def wino_wanted(M, C_sources, N, H, W, spec):
+    """Host-side mirror of the kernel's shape rule (wino_bk in csrc/winograd.hip) plus the grid-size rule: True when a 3x3 / stride
+    1 / pad 1 convolution with M output rows over N x H x W pixels and the given channel counts per concat source should go to
+    dp_conv_wino.  Decided before anything is packed, so layers that never qualify never get a Winograd operand."""
+    if not WINO or getattr(spec, 'keep', False) or getattr(spec, 'sym', False):
+        return False
+    if not (spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad_h == 1 and spec.pad_w == 1 and not spec.ups):
+        return False
+    if W < 4 or W > 128 or (W & (W - 1)) or ((H * W) & 1):
+        return False
+    if any(c % 8 for c in C_sources):
+        return False
+    return -(-M // 64) * -(-(N * H * W) // 128) >= WINO_MIN_TILES
+
+
+def pack_weight_wino(w, mode):
+    """U[(ky*4 + pos)*K + k][ld] for dp_conv_wino from a [Co, Ci, 3, 3] weight: mode 0 forward (K = Ci), mode 1 input gradient
+    (K = Co, taps flipped).  pos 0..3: g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2 of the kernel row."""
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.is_cuda and w.dtype == _f32 and w.is_contiguous()
+    Co, Ci = w.shape[0], w.shape[1]
+    K = Ci if mode == 0 else Co
+    ld = roundup4(Co if mode == 0 else Ci)
+    dst = torch.empty(12 * K * ld, dtype=_f32, device=w.device)
+    L.check(_lib().dp_pack_weight_wino(_p(w), Co, Ci, mode, _p(dst), ld, _stream()), 'dp_pack_weight_wino')
+    return dst, ld
+
+
+def _conv_wino(p, wino, act_bytes):
+    """Run the filled parameter block through dp_conv_wino when the kernel takes the shape and the grid is big enough; False =
+    the caller launches the direct form."""
+    if not WINO:
+        return False
+    U, ld = wino
+    if -(-p.M // 64) * -(-p.NPIX // 128) < WINO_MIN_TILES:
+        return False
+    A0, lda0, ab0 = p.A, p.lda, p.a_bytes
+    p.A, p.lda, p.a_bytes = _p(U), ld, U.numel() * 4
+    if not _lib().dp_conv_wino_supported(C.byref(p)):
+        p.A, p.lda, p.a_bytes = A0, lda0, ab0
+        return False
+    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino', 2.0 * p.M * p.NPIX * p.C * 6,
+                 act_bytes + 4.0 * U.numel()), 'dp_conv_wino')
+    return True
+
+
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
-                 accumulate=False, relu=False):
+                 accumulate=False, relu=False, wino=None):
     """out[N, Cout, Ho, Wo] = conv(cat(x, x2)) (+bias) (+tadd[n, co]) (+res) ; * post_scale.
-    wp/ld: pack_weight(w, 0).  tadd: [N, Cout] per-image per-channel addend (time-embedding projection)."""
+    wp/ld: pack_weight(w, 0).  tadd: [N, Cout] per-image per-channel addend (time-embedding projection).
+    wino: pack_weight_wino(w, 0) -- the launch goes to the Winograd F(2, 3) kernel when it takes the shape (see _conv_wino)."""
     s1 = _chk_act(x)
     N, C1, Hs, Ws = x.shape
     C2 = 0
@@ -359,13 +410,15 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
         p.res, p.r_img_stride = _p(res), _chk_act(res)
         assert res.shape == out.shape
     p.accumulate = 1 if accumulate else 0
+    if wino is not None and _conv_wino(p, wino, 4.0 * (N * Cin * Hs * Ws + out.numel())):
+        return out
     _conv_ksplit(p, x.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
                  4.0 * (N * Cin * Hs * Ws + wp.numel() + out.numel())), 'dp_conv_gemm(forward)')
     return out
 
 
-def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate=False):
+def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate=False, wino=None):
     """Gradient w.r.t. the (virtual, i.e. post-upsample) input of a convolution.
     dy: [N, Cout, Ho, Wo]; wd/ldd: pack_weight(w, 1); returns [N, Cin, Hv, Wv] with (Hv, Wv) = in_hw."""
     sd = _chk_act(dy)
@@ -388,6 +441,8 @@ def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate
     p.out, p.o_img_stride, p.o_bs = _p(out), so, 0
     p.alpha, p.post_scale = alpha, 1.0
     p.accumulate = 1 if accumulate else 0
+    if wino is not None and _conv_wino(p, wino, 4.0 * (dy.numel() + out.numel())):
+        return out
     _conv_ksplit(p, dy.device)
     L.check(_run(lambda: _lib().dp_conv_gemm(C.byref(p), _stream()), _cg_name(p), 2.0 * p.M * p.NPIX * p.C * p.ntaps,
                  4.0 * (dy.numel() + wd.numel() + out.numel())), 'dp_conv_gemm(dgrad)')

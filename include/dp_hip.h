@@ -61,6 +61,20 @@ typedef struct dp_conv_gemm_params {
 } dp_conv_gemm_params;
 int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
 
+/* The same convolution for the 3x3, stride 1, pad 1 case as a one-dimensional Winograd F(2, 3) implicit GEMM (csrc/winograd.hip):
+ * 2/3 of the multiplies of dp_conv_gemm (4 per 2 outputs x 3 taps along W), input transform at fragment-read time, output transform
+ * in the epilogue.  Replaces the same call sites as dp_conv_gemm's 3x3 forward / input-gradient launches
+ * (diffusers/models/resnet.py:606,630 conv1 / conv2 and their ConvolutionBackward input gradients;
+ * ldm/modules/diffusionmodules/openaimodel.py:214-232 in_layers / out_layers).  Same parameter block and epilogue; A is the
+ * operand of dp_pack_weight_wino, U[(ky*4 + pos)*C + c][lda]; ksplit / batches / a_kc must be unset.
+ * dp_conv_wino_supported returns the K-chunk width the kernel would use (16 / 8) or 0 when the shape is not taken
+ * (W a power of two in 4..128, channel counts per concat source multiples of 8, 3x3 / stride 1 / pad 1). */
+int dp_conv_wino(const dp_conv_gemm_params* p, void* stream);
+int dp_conv_wino_supported(const dp_conv_gemm_params* p);
+/* mode 0: forward operand (K = Ci, columns = co); mode 1: input-gradient operand (K = Co, columns = ci, taps flipped).
+ * dst holds 12 * K * ld floats. */
+int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);
+
 /* D[m][c][tap] = alpha * sum_pix A[m][pix] * X(pix, c, tap)  -- weight gradients (split over pixels, one kernel tap
  * per workgroup) and the k-contiguous batched products of attention (P.V, dQ).  Replaces the weight-gradient half of
  * ConvolutionBackward / AddmmBackward reached from loss.backward() (ddpm_prune.py:102) and torch.bmm

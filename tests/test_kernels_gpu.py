@@ -987,3 +987,41 @@ def test_pack_weight_batch_equals_per_layer_pack(ops):
     for (w, m), (buf, ld) in zip(items, got):
         ref, ld0 = ops.pack_weight(w, m)
         assert ld == ld0 and torch.equal(buf, ref)
+
+
+@pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
+                                             (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64)], ids=str)
+def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
+    """dp_conv_wino (3x3 / stride 1 / pad 1 as a one-dimensional Winograd F(2, 3) implicit GEMM) against the fp64 convolution,
+    forward (two concat sources, bias, per-image addend, residual, scale; accumulate) and input gradient, next to the direct
+    kernel's error on the same inputs; K chunks of 16 and of 8 channels; output-channel tails; tiles that span several images."""
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+    xa, xb = rnd(N, C1, H, H, seed=1), (rnd(N, C2, H, H, seed=2) if C2 else None)
+    w = rnd(Cout, C1 + C2, 3, 3, seed=3, scale=0.05)
+    b, tadd, res = rnd(Cout, seed=4), rnd(N, Cout, seed=6), rnd(N, Cout, H, H, seed=7)
+    dy = rnd(N, Cout, H, H, seed=5)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    wd, ldd = ops.pack_weight(w, 1)
+    U0, U1 = ops.pack_weight_wino(w, 0), ops.pack_weight_wino(w, 1)
+    x = torch.cat([xa, xb], 1) if C2 else xa
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    ref = (ref + tadd.double().cpu()[:, :, None, None] + res.double().cpu()) * 0.7
+    ref_d = 0.5 * torch.nn.functional.conv_transpose2d(dy.double().cpu(), w.double().cpu(), padding=1)
+    launched = []
+    real = ops._conv_wino
+    monkeypatch.setattr(ops, '_conv_wino', lambda *a: (launched.append(real(*a)), launched[-1])[1])
+    y_w = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+    y_d = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7)
+    acc = res.clone()
+    ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc, accumulate=True, wino=U0)
+    d_w = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H), alpha=0.5, wino=U1)
+    d_d = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (H, H), alpha=0.5)
+    assert launched == [True, True, Cout % 8 == 0], launched          # dgrad contracts over Cout: 70 channels keep the direct form
+    ref_acc = res.double().cpu() + torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    e = dict(fwd=relerr(y_w, ref), fwd_direct=relerr(y_d, ref), acc=relerr(acc, ref_acc), dgrad=relerr(d_w, ref_d),
+             dgrad_direct=relerr(d_d, ref_d))
+    y_w2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+    report['conv/winograd_f23/%d_%d_%d_%d' % (N, C1 + C2, Cout, H)] = dict(e, run_to_run_equal=bool(torch.equal(y_w, y_w2)))
+    assert torch.equal(y_w, y_w2)
+    assert e['fwd'] < 3e-6 and e['acc'] < 3e-6 and e['dgrad'] < 3e-6, e
