@@ -956,10 +956,30 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
     int i = 0;
     while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
     const dp_pack_item& it = b.it[i];
+    const long long step = (long long)it.nblk * 256;
+    if (it.mode >= 2) {      // Winograd F(2, 3) operand of a 3x3 weight (same element map as pack_weight_wino_kernel, winograd.hip)
+        const int wm = it.mode - 2;
+        const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
+        const long long total = 12ll * K * it.ld;
+        for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
+            const int m = (int)(e % it.ld);
+            const long long rk = e / it.ld;
+            const int k = (int)(rk % K);
+            const int kp = (int)(rk / K);
+            const int ky = kp >> 2, pos = kp & 3;
+            float v = 0.f;
+            if (m < Mv) {
+                const float* w = wm == 0 ? it.W + ((long long)m * it.Ci + k) * 9 + ky * 3 : it.W + ((long long)k * it.Ci + m) * 9 + (2 - ky) * 3;
+                const float g0 = wm == 0 ? w[0] : w[2], g1 = w[1], g2 = wm == 0 ? w[2] : w[0];
+                v = pos == 0 ? g0 : pos == 1 ? ((g0 + g1) + g2) * 0.5f : pos == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+            }
+            it.dst[e] = v;
+        }
+        return;
+    }
     const int K = it.mode == 0 ? it.Ci : it.Co;
     const int Mv = it.mode == 0 ? it.Co : it.Ci;
     const long long total = (long long)it.taps * K * it.ld;
-    const long long step = (long long)it.nblk * 256;
     for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
         const int m = (int)(e % it.ld);
         const long long rk = e / it.ld;
@@ -981,8 +1001,9 @@ extern "C" int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stre
         for (int i = 0; i < b.n; ++i) {
             b.it[i] = items[lo + i];
             dp_pack_item& it = b.it[i];
-            if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || (it.mode != 0 && it.mode != 1)) return (int)hipErrorInvalidValue;
-            const long long total = (long long)it.taps * (it.mode == 0 ? it.Ci : it.Co) * it.ld;
+            if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || it.mode < 0 || it.mode > 3) return (int)hipErrorInvalidValue;
+            if (it.mode >= 2 && it.taps != 9) return (int)hipErrorInvalidValue;
+            const long long total = (long long)(it.mode >= 2 ? 12 : it.taps) * ((it.mode & 1) == 0 ? it.Ci : it.Co) * it.ld;
             long long nb = (total + 1023) / 1024;
             if (nb > 512) nb = 512;
             it.blk0 = blocks;

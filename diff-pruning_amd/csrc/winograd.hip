@@ -31,10 +31,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dpw_rsrc(const float* base, un
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DPW_RSRC_FLAGS);
 }
 
-// BM = 64 output channels x 64 pairs (128 pixels) per 256-thread workgroup; waves 2 x 2, each 32 rows x 32 pairs x 4 positions.
-template <int BK>
+// 256-thread workgroups, every wave 32 rows x 32 pairs x 4 positions.  WR = 2: waves 2 x 2, 64 output channels x 64 pairs (128
+// pixels); WR = 1: waves 1 x 4, 32 output channels x 128 pairs (256 pixels) -- for row counts such as 96 or 288 (pruned widths),
+// which fill 64-row tiles to 75 / 90 %.
+template <int BK, int WR>
 __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const dp_conv_gemm_params p) {
-    constexpr int BM = 64, BP = 64, BN = 2 * BP;
+    constexpr int BM = 32 * WR, BP = 32 * (4 / WR), BN = 2 * BP;
+    constexpr int G4 = BN / 4, RPW = 64 / G4;          // lanes per pixel row of the B tile, rows per wave instruction (2 / 1)
     constexpr int A_SZ = 4 * BK * BM;                  // [pos][k][m]
     constexpr int B_SZ = BK * BN;                      // [k][pixel]
     constexpr int STAGE = A_SZ + B_SZ;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = (WR == 2) ? (wave >> 1) : 0, wc = (WR == 2) ? (wave & 1) : wave;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
 
@@ -61,12 +64,12 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
 #pragma unroll
     for (int j = 0; j < NJA; ++j) {
         const int e = tid + 256 * j;
-        const int pos = e / (BK * 16), k = (e / 16) % BK, m = m0 + 4 * (e % 16);
+        const int pos = e / (BK * (BM / 4)), k = (e / (BM / 4)) % BK, m = m0 + 4 * (e % (BM / 4));
         a_voff[j] = (m < p.lda) ? (unsigned)(((pos * C + k) * p.lda + m) * 4) : DPW_OOB;
     }
     const __amdgpu_buffer_rsrc_t rA = dpw_rsrc(p.A, p.a_bytes);
     // ---- B loader: lane = (row of the wave's pair of rows, 4-pixel group)
-    const int g4 = lane & 31, rsub = lane >> 5;
+    const int g4 = lane % G4, rsub = lane / G4;
     unsigned x_pix1, x_pix2, vrow = 0;
     {
         const int gp = n0 + 4 * g4;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     unsigned b_voff1[NJB], b_voff2[NJB];
 #pragma unroll
     for (int j = 0; j < NJB; ++j) {
-        const int row = 8 * j + 2 * wave + rsub;
+        const int row = 4 * RPW * j + RPW * wave + rsub;
         b_voff1[j] = (x_pix1 + (unsigned)(row * HW)) * 4u;
         b_voff2[j] = (x_pix2 + (unsigned)(row * HW)) * 4u;
     }
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     const __amdgpu_buffer_rsrc_t r2 = dpw_rsrc((p.X2 ? p.X2 : p.X1) - W, (p.X2 ? p.x2_bytes : p.x1_bytes) + 4u * (unsigned)W);
 
     float* const ldsA = smem + 4 * (wave * 64);                     // + buf*STAGE + 1024*j
-    float* const ldsB = smem + A_SZ + 2 * wave * BN;                // + buf*STAGE + 8*j*BN
+    float* const ldsB = smem + A_SZ + RPW * wave * BN;              // + buf*STAGE + 4*RPW*j*BN
     const unsigned a_ky_step = (unsigned)(4 * C) * (unsigned)p.lda * 4u;
 
     int ch = 0, ky = 0;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
         for (int j = 0; j < NJB; ++j) {
             unsigned o = tv ? (first ? b_voff1[j] : b_voff2[j]) : DPW_OOB;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw_lds_void*)(ldsB + buf * STAGE + 8 * j * BN), 16, (int)o,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw_lds_void*)(ldsB + buf * STAGE + 4 * RPW * j * BN), 16, (int)o,
                                                      (int)b_soff, 0, 0);
         }
     };
@@ -200,14 +203,14 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     }
 }
 
-// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 128 (so it divides the 128-pixel tile
+// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 256 (so it divides the 128- / 256-pixel tile
 // and the 16-byte loads are aligned), channel counts (per concat source) in whole K chunks, 8-byte aligned image planes.
 static int wino_bk(const dp_conv_gemm_params& p) {
     const dp_conv_geom& g = p.g;
     if (p.a_kc || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups || g.pad_t != 1 || g.pad_l != 1) return 0;
     if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || p.ksplit > 1) return 0;
     const int W = g.Wo;
-    if (W < 4 || W > 128 || (W & (W - 1))) return 0;
+    if (W < 4 || W > 256 || (W & (W - 1))) return 0;        // W must divide the pixel tile (128, or 256 with the 32-row tiles)
     if ((p.lda & 3) || ((g.Ho * g.Wo) & 1)) return 0;
     const int C1 = p.X2 ? g.c_split : p.C;
     if (p.C % 16 == 0 && C1 % 16 == 0) return 16;
@@ -224,9 +227,19 @@ extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
     if (!bk) return (int)hipErrorInvalidValue;
     static const char* force = getenv("DP_WINO_BK");
     if (force && atoi(force) == 8) bk = 8;
-    dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64);
-    if (bk == 16) DP_LAUNCH((conv_wino_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else          DP_LAUNCH((conv_wino_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    // 32-row tiles when they pad fewer rows than 64-row tiles (M = 96, 288, ...)
+    static const char* fwr = getenv("DP_WINO_WR");
+    const bool wr1 = p.g.Wo > 128 || (fwr ? atoi(fwr) == 1 : ((p.M + 31) / 32) * 32 < ((p.M + 63) / 64) * 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (wr1) {
+        dim3 grid((p.NPIX + 255) / 256, (p.M + 31) / 32);
+        if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 1>), grid, dim3(256), 0, st, p);
+        else          DP_LAUNCH((conv_wino_kernel<8, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64);
+        if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
+        else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
+    }
     return DP_LAUNCH_CHECK();
 }
 

@@ -296,9 +296,12 @@ class UNetEngine:
         must not be recorded into the replayed graph; and once per finetune step, whose optimizer update invalidates every
         pack): all of them in a few batched launches (ops.pack_weight_batch)."""
         todo = []
+        seen = getattr(self, '_wino_seen', ())         # Winograd operands the previous passes asked for (decided by activation shape)
         for name, w in self.P.items():
             if name.endswith('.weight') and w.dim() >= 2:
-                for mode in (0, 1):
+                for mode in (0, 1, ('wino', 0), ('wino', 1)):
+                    if isinstance(mode, tuple) and (name[:-7], mode) not in seen:
+                        continue
                     if not self.packs.has(name[:-7], w, mode):
                         todo.append((name[:-7], w, mode))
         if hasattr(ops, 'pack_weight_batch') and todo and all(w.is_contiguous() for _, w, _ in todo):
@@ -313,13 +316,19 @@ class UNetEngine:
         return float(hd if hd is not None else channels) ** -0.5
 
     # ---- primitive layers ---------------------------------------------------------------------
+    def _wino_pack(self, name, w, mode):
+        if not hasattr(self, '_wino_seen'):
+            self._wino_seen = set()
+        self._wino_seen.add((name, ('wino', mode)))          # prepare_packs() batches it from the next pass on
+        return self.packs.get(name, w, ('wino', mode))
+
     def _conv(self, name, x, x2, spec, **kw):
         w = self.P[name + '.weight']
         wp, ld = self.packs.get(name, w, 0)
         # 3x3 / stride 1 / pad 1 layers with a grid worth it: Winograd F(2, 3) along W, 2/3 of the multiplies (csrc/winograd.hip)
         if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and ops.wino_wanted(
                 w.shape[0], (x.shape[1],) + ((x2.shape[1],) if x2 is not None else ()), x.shape[0], x.shape[2], x.shape[3], spec):
-            kw['wino'] = self.packs.get(name, w, ('wino', 0))
+            kw['wino'] = self._wino_pack(name, w, 0)
         return ops.conv_forward(x, x2, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), **kw)
 
     def _linear(self, name, x2d):
@@ -393,7 +402,7 @@ class UNetEngine:
         wino = None
         if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and tuple(in_hw) == tuple(dy.shape[2:]) and \
                 ops.wino_wanted(w.shape[1], (w.shape[0],), dy.shape[0], dy.shape[2], dy.shape[3], spec):
-            wino = self.packs.get(name, w, ('wino', 1))
+            wino = self._wino_pack(name, w, 1)
         dx = ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate,
                             **({'wino': wino} if wino is not None else {}))
         if dx_add is not None:

@@ -255,7 +255,8 @@ def pack_weight(w, mode):
 
 
 def pack_weight_batch(ws_modes):
-    """pack_weight for a list of (weight, mode) in ceil(n / 64) launches; returns [(packed, ld), ...] in order."""
+    """pack_weight (mode 0 / 1) or pack_weight_wino (mode ('wino', 0 | 1)) for a list of (weight, mode) in ceil(n / 64) launches;
+    returns [(packed, ld), ...] in order."""
     n = len(ws_modes)
     arr = (L.PackItem * n)()
     out = []
@@ -263,10 +264,12 @@ def pack_weight_batch(ws_modes):
         assert w.is_cuda and w.dtype == _f32 and w.is_contiguous(), 'pack_weight_batch takes contiguous fp32 device weights'
         Co, Ci = w.shape[0], w.shape[1]
         taps = w[0, 0].numel() if w.dim() == 4 else 1
-        K = Ci if mode == 0 else Co
-        ld = roundup4(Co if mode == 0 else Ci)
-        dst = torch.empty(taps * K * ld, dtype=_f32, device=w.device)
-        a.W, a.dst, a.Co, a.Ci, a.taps, a.mode, a.ld = w.data_ptr(), dst.data_ptr(), Co, Ci, taps, mode, ld
+        wino = isinstance(mode, tuple)                     # ('wino', 0 | 1): the pack_weight_wino operand
+        m01 = mode[1] if wino else mode
+        K = Ci if m01 == 0 else Co
+        ld = roundup4(Co if m01 == 0 else Ci)
+        dst = torch.empty((12 if wino else taps) * K * ld, dtype=_f32, device=w.device)
+        a.W, a.dst, a.Co, a.Ci, a.taps, a.mode, a.ld = w.data_ptr(), dst.data_ptr(), Co, Ci, taps, (2 + m01 if wino else m01), ld
         out.append((dst, ld))
     if n:
         L.check(_lib().dp_pack_weight_batch(arr, n, _stream()), 'dp_pack_weight_batch')
@@ -335,7 +338,7 @@ def wino_wanted(M, C_sources, N, H, W, spec):
         return False
     if not (spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad_h == 1 and spec.pad_w == 1 and not spec.ups):
         return False
-    if W < 4 or W > 128 or (W & (W - 1)) or ((H * W) & 1):
+    if W < 4 or W > 256 or (W & (W - 1)) or ((H * W) & 1):
         return False
     if any(c % 8 for c in C_sources):
         return False

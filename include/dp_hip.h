@@ -68,7 +68,7 @@ int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
  * ldm/modules/diffusionmodules/openaimodel.py:214-232 in_layers / out_layers).  Same parameter block and epilogue; A is the
  * operand of dp_pack_weight_wino, U[(ky*4 + pos)*C + c][lda]; ksplit / batches / a_kc must be unset.
  * dp_conv_wino_supported returns the K-chunk width the kernel would use (16 / 8) or 0 when the shape is not taken
- * (W a power of two in 4..128, channel counts per concat source multiples of 8, 3x3 / stride 1 / pad 1). */
+ * (W a power of two in 4..256, channel counts per concat source multiples of 8, 3x3 / stride 1 / pad 1). */
 int dp_conv_wino(const dp_conv_gemm_params* p, void* stream);
 int dp_conv_wino_supported(const dp_conv_gemm_params* p);
 /* mode 0: forward operand (K = Ci, columns = co); mode 1: input-gradient operand (K = Co, columns = ci, taps flipped).
@@ -382,7 +382,8 @@ int dp_replay_launch(void* handle, void* main_stream, void* side_stream);
 int dp_replay_info(void* handle, int* info8);
 int dp_replay_free(void* handle);
 
-/* dp_pack_weight for many layers in one launch (blk0 / nblk are filled by the launcher). */
+/* dp_pack_weight for many layers in one launch (blk0 / nblk are filled by the launcher).  mode 0 / 1 as dp_pack_weight;
+ * mode 2 / 3: the dp_pack_weight_wino operand (mode - 2) of a 3x3 weight (taps = 9, dst holds 12 * K * ld floats). */
 typedef struct dp_pack_item {
     const float* W; float* dst;
     int Co, Ci, taps, mode, ld, blk0, nblk, _pad;

@@ -983,14 +983,15 @@ def test_pack_weight_batch_equals_per_layer_pack(ops):
     3x3 / 1x1 convolutions and a Linear, both operand layouts, widths that need the ld padding (90 -> 92)."""
     ws = [rnd(90, 45, 3, 3, seed=1), rnd(128, 256, 1, 1, seed=2), rnd(33, 70, seed=3), rnd(192, 192, 3, 3, seed=4), rnd(3, 96, 3, 3, seed=5)]
     items = [(w, m) for w in ws for m in (0, 1)] * 9                       # > 64 items: more than one launch
+    items += [(w, ('wino', m)) for w in ws if w.dim() == 4 and w.shape[2] == 3 for m in (0, 1)]     # Winograd F(2, 3) operands
     got = ops.pack_weight_batch(items)
     for (w, m), (buf, ld) in zip(items, got):
-        ref, ld0 = ops.pack_weight(w, m)
+        ref, ld0 = ops.pack_weight_wino(w, m[1]) if isinstance(m, tuple) else ops.pack_weight(w, m)
         assert ld == ld0 and torch.equal(buf, ref)
 
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
-                                             (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64)], ids=str)
+                                             (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (1, 32, 0, 48, 256)], ids=str)
 def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_conv_wino (3x3 / stride 1 / pad 1 as a one-dimensional Winograd F(2, 3) implicit GEMM) against the fp64 convolution,
     forward (two concat sources, bias, per-image addend, residual, scale; accumulate) and input gradient, next to the direct
