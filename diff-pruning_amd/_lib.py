@@ -89,6 +89,8 @@ SIGNATURES = {
     'dp_conv_wino': [C.POINTER(ConvGemmParams), _vp],
     'dp_conv_wino_supported': [C.POINTER(ConvGemmParams)],
     'dp_pack_weight_wino': [_vp, _i, _i, _i, _vp, _i, _vp],
+    'dp_wgrad_wino': [C.POINTER(NtGemmParams), _vp],
+    'dp_wgrad_wino_supported': [C.POINTER(NtGemmParams)],
     'dp_nt_gemm': [C.POINTER(NtGemmParams), _vp],
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],
     'dp_splitk_reduce_taps': [_vp, _ll, _i, _vp, _ll, _i, _i, _vp],

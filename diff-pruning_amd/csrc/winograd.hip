@@ -273,3 +273,212 @@ extern "C" int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, flo
     DP_LAUNCH(pack_weight_wino_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, mode, dst, ld);
     return DP_LAUNCH_CHECK();
 }
+
+// ================================================================================================================================
+// Weight gradient of the same convolutions, as the transposed F(2, 3) algorithm (F(3, 2): 3 taps from output pairs): per kernel
+// row ky, 4 multiplies per (output pair, m, c) instead of 6:
+//     a = (dy0, dy0 + dy1, dy0 - dy1, -dy1),  v = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)   [d_j = x[c][y + ky - 1][2p + j - 1]]
+//     G_q[m][c] = sum over pairs a_q v_q;    dW[ky][0] = G0 + (G1 + G2)/2,  dW[ky][1] = (G1 - G2)/2,  dW[ky][2] = (G1 + G2)/2 + G3
+// i.e. 12 contractions over HALF the pixels per channel pair instead of 9 over all of them: 2/3 of the MACs.
+// One workgroup = one 64 x 64 (m, c) tile of one kernel row ky over one pixel range (split-K over pixels like nt_gemm_fast, same
+// tap-major partials, same reduction launch).  Both operands are pixel-contiguous rows; both transforms happen at fragment time
+// (3 + 4 VALU per 4 MFMAs).  K tile = 16 pairs.  Its window of 34 pixels (pairs at pixels b+2 .. b+33, halo b+1 and b+34) is
+// covered by NINE aligned 16-byte slots b .. b+35 when the tiling is shifted by two pixels (b = 32 t - 32, t = 0 .. P/32): aligned
+// slots never straddle an image row, so vertical padding is a per-slot out-of-range offset, and nine slots per row put the 32
+// rows a wavefront reads on 8 different 16-byte bank groups (a dense 8-slot row would put them on one).  Horizontal padding and
+// the pairs outside [0, P) are per-lane multipliers (0 / 1) on d0 / d3 and zeroed A slots.
+// ================================================================================================================================
+__global__ __launch_bounds__(256, 4) void wgrad_wino_kernel(const dp_nt_gemm_params p) {
+    constexpr int RS = 36;                              // floats per LDS row: 9 slots of 4 pixels
+    constexpr int OP_SZ = 64 * RS;                      // one operand tile (64 rows)
+    constexpr int STAGE = 2 * OP_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int split = blockIdx.z / 3, ky = blockIdx.z - 3 * split;
+
+    const dp_conv_geom& g = p.g;
+    const int W = g.Wo, H = g.Ho, HW = H * W;
+    const int lw = 31 - __builtin_clz((unsigned)W), lhw = 31 - __builtin_clz((unsigned)HW);
+    const int C1 = p.X2 ? g.c_split : p.NCOLS;
+    const bool src1 = n0 < C1;                                   // the whole column tile lies in one concat source
+    const float* Xs = src1 ? p.X1 : p.X2;
+    const int ncs = src1 ? C1 : p.NCOLS - C1;                    // channels of that source
+    const int cb = src1 ? n0 : n0 - C1;                          // first channel of the tile inside its source
+    const long long xis = src1 ? g.x1_img_stride : g.x2_img_stride;
+    // K tiles of this split: t in [t0, t1), window base pixel b = 32 t - 32
+    const int T = p.P / 32 + 1;
+    const int tps = p.p_per_split / 32;
+    const int t0 = split * tps, t1 = min(t0 + tps, T);
+    const int nIter = t1 - t0;
+
+    // ---- loaders: A slots q = 256 j + tid (j = 0, 1; j = 2 in wave 0), B slots likewise (j = 2 in wave 1); q -> (row, slot)
+    const __amdgpu_buffer_rsrc_t rA = dpw_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rB = dpw_rsrc(Xs - W, (src1 ? p.x1_bytes : p.x2_bytes) + 4u * (unsigned)W);   // ky row shift >= 0
+    unsigned a_c[3], b_c[3];           // constant part of the per-lane byte offset, DPW_OOB for rows outside the tile's rows
+    bool is8[3];                       // slot 8: the first four pixels of the NEXT 32-pixel block (its own image / row / validity)
+    int dho[3];                        // image-row offset of the slot inside the block (W < 32)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = (j < 2) ? 256 * j + tid : 512 + lane;
+        const int row = q / 9, s = q - 9 * row;
+        is8[j] = s == 8;
+        dho[j] = (s == 8) ? 0 : ((4 * s) >> lw);
+        const int po = (s == 8) ? 0 : 4 * s;                      // pixel offset inside its 32-pixel block
+        a_c[j] = (m0 + row < p.M) ? (unsigned)(((m0 + row) * HW + po) * 4) : DPW_OOB;
+        b_c[j] = (cb + row < ncs) ? (unsigned)(((cb + row) * HW + po) * 4) : DPW_OOB;
+    }
+    float* const ldsA = smem + 4 * (wave * 64);                  // + buf*STAGE + 1024 j  (slot q at float 4 q)
+    float* const ldsA2 = smem + 4 * 512;                         // third instruction: slots 512 .. 575 (wave 0)
+    float* const ldsB = smem + OP_SZ + 4 * (wave * 64);
+    float* const ldsB2 = smem + OP_SZ + 4 * 512;                 // (wave 1)
+
+    auto dma_tile = [&](int t, int buf) {
+        const int b = 32 * t - 32;                               // block 0: pixels b .. b+31 (slots 0..7), block 1: b+32 .. (slot 8)
+        const bool v0 = t >= 1, v1 = t < T - 1;                   // blocks inside [0, P)
+        const int bb0 = v0 ? b : 0, bb1 = v1 ? b + 32 : 0;
+        const int img0 = bb0 >> lhw, r0 = bb0 & (HW - 1), img1 = bb1 >> lhw, r1 = bb1 & (HW - 1);
+        const unsigned a_s0 = (unsigned)((long long)img0 * p.a_img_stride + r0) * 4u;
+        const unsigned a_s1 = (unsigned)((long long)img1 * p.a_img_stride + r1) * 4u;
+        const unsigned b_s0 = (unsigned)((long long)img0 * xis + r0 + ky * W) * 4u;
+        const unsigned b_s1 = (unsigned)((long long)img1 * xis + r1 + ky * W) * 4u;
+        const int ho0 = r0 >> lw, ho1 = r1 >> lw;
+        auto one = [&](int j, float* la, float* lb) {
+            const bool vv = is8[j] ? v1 : v0;
+            unsigned oa = vv ? a_c[j] + (is8[j] ? a_s1 : a_s0) : DPW_OOB;
+            if (a_c[j] == DPW_OOB) oa = DPW_OOB;
+            const int ho = (is8[j] ? ho1 : ho0 + dho[j]) + ky - 1;
+            unsigned ob = (vv && (unsigned)ho < (unsigned)H) ? b_c[j] + (is8[j] ? b_s1 : b_s0) : DPW_OOB;
+            if (b_c[j] == DPW_OOB) ob = DPW_OOB;
+            if (la) {
+                asm volatile("" : "+v"(oa));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw_lds_void*)la, 16, (int)oa, 0, 0, 0);
+            }
+            if (lb) {
+                asm volatile("" : "+v"(ob));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (dpw_lds_void*)lb, 16, (int)ob, 0, 0, 0);
+            }
+        };
+        one(0, ldsA + buf * STAGE, ldsB + buf * STAGE);
+        one(1, ldsA + buf * STAGE + 1024, ldsB + buf * STAGE + 1024);
+        if (wave == 0) one(2, ldsA2 + buf * STAGE, nullptr);
+        if (wave == 1) one(2, nullptr, ldsB2 + buf * STAGE);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    // ---- fragments: lane = (k half lk, row li); pair j = 2 ks + lk of the tile sits at floats 2 j + 2 .. (dy0 dy1) / 2 j + 1 .. 2 j + 4 (d0..d3)
+    const int li = lane & 31, lk = lane >> 5;
+    const float* fragA = smem + (wr * 32 + li) * RS + 2 * lk + 2;
+    const float* fragB = smem + OP_SZ + (wc * 32 + li) * RS + 2 * lk + 1;
+    // horizontal padding: multipliers on d0 (pair starts an image row) and d3 (pair ends one).  The pair's pixel is
+    // b + 2 + 2 j with b a multiple of 32: for W <= 32 a per-lane constant; for W >= 64 only the last two pairs of a tile can touch
+    // a row boundary, and only in the tile that ends the row (decided per tile).
+    float fl[8], fr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int px = 2 + 2 * (2 * ks + lk);
+        const bool small = W <= 32;
+        fl[ks] = (small && (px & (W - 1)) == 0) ? 0.f : 1.f;
+        fr[ks] = (small && ((px + 2) & (W - 1)) == 0) ? 0.f : 1.f;
+    }
+    auto row_end_flags = [&](int t) {                            // W >= 64: pair 15 starts a row / pair 14 ends one iff b + 32 = 0 (mod W)
+        if (W >= 64) {
+            const bool e = ((32 * t) & (W - 1)) == 0;
+            fl[7] = (e && lk == 1) ? 0.f : 1.f;
+            fr[7] = (e && lk == 0) ? 0.f : 1.f;
+        }
+    };
+
+    if (nIter > 0) {
+        dma_tile(t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < nIter; ++it) {
+            const int buf = it & 1;
+            row_end_flags(t0 + it);
+            const float* Af = fragA + buf * STAGE;
+            const float* Bf = fragB + buf * STAGE;
+            float a[2][2], d[2][4];
+            auto frag = [&](int ks, float (&fa)[2], float (&fd)[4]) {
+                fa[0] = Af[4 * ks];
+                fa[1] = Af[4 * ks + 1];
+                fd[0] = Bf[4 * ks];
+                fd[1] = Bf[4 * ks + 1];
+                fd[2] = Bf[4 * ks + 2];
+                fd[3] = Bf[4 * ks + 3];
+            };
+            frag(0, a[0], d[0]);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < 8) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float y0 = a[cur][0], y1 = a[cur][1];
+                const float d0 = d[cur][0] * fl[ks], d1 = d[cur][1], d2 = d[cur][2], d3 = d[cur][3] * fr[ks];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, d0 - d2, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 + y1, d1 + d2, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 - y1, d2 - d1, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-y1, d1 - d3, acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1) { dma_tile(t0 + (it + 1 < nIter ? it + 1 : it), buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: G -> the three taps of kernel row ky; output element (m, c, tap) as in nt_gemm_fast
+    const int o_cs = p.o_col_stride ? p.o_col_stride : p.ntaps;
+    const long long o_ts = p.o_tap_stride ? p.o_tap_stride : 1;
+    float* __restrict__ outb = p.out + (long long)split * p.o_bs;
+    const int col = n0 + wc * 32 + (lane & 31);
+    if (col >= p.NCOLS || (src1 && col >= C1)) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        const float hs = 0.5f * (acc[1][r] + acc[2][r]);
+        const float t[3] = {acc[0][r] + hs, 0.5f * (acc[1][r] - acc[2][r]), hs + acc[3][r]};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* o = outb + (long long)(3 * ky + kx) * o_ts + (long long)m * p.ldo + (long long)col * o_cs;
+            float v = p.alpha * t[kx];
+            if (p.accumulate) v += *o;
+            *o = v;
+        }
+    }
+}
+
+static bool wgrad_wino_ok(const dp_nt_gemm_params& p) {
+    const dp_conv_geom& g = p.g;
+    if (p.batched || p.merge || p.col_bias || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups) return false;
+    if (g.pad_t != 1 || g.pad_l != 1 || g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv) return false;
+    const int W = g.Wo, HW = g.Ho * g.Wo;
+    if (W < 8 || W > 256 || (W & (W - 1)) || (HW & (HW - 1)) || HW < 64) return false;
+    if ((p.P % 32) || (p.p_per_split % 32) || p.p_per_split <= 0) return false;
+    if (p.X2 && (g.c_split % 64)) return false;
+    return true;
+}
+
+extern "C" int dp_wgrad_wino_supported(const dp_nt_gemm_params* p) { return wgrad_wino_ok(*p) ? 1 : 0; }
+
+// p as for dp_nt_gemm's weight-gradient launches (A = dy, X1 / X2 = the convolution input, ntaps = 9); the split-K range is counted
+// in K tiles of 32 pixels over P/32 + 1 tiles: splits * p_per_split must cover P + 32 pixels.
+extern "C" int dp_wgrad_wino(const dp_nt_gemm_params* pp, void* stream) {
+    const dp_nt_gemm_params& p = *pp;
+    if (p.M <= 0 || p.NCOLS <= 0) return 0;
+    if (!wgrad_wino_ok(p) || p.splits <= 0 || (long long)p.splits * p.p_per_split < (long long)p.P + 32) return (int)hipErrorInvalidValue;
+    const int C1 = p.X2 ? p.g.c_split : p.NCOLS;
+    dim3 grid((C1 + 63) / 64 + (p.X2 ? (p.NCOLS - C1 + 63) / 64 : 0), (p.M + 63) / 64, 3 * p.splits);
+    DP_LAUNCH(wgrad_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return DP_LAUNCH_CHECK();
+}

@@ -206,8 +206,12 @@ def _conv_ksplit(p, device):
             # in-kernel reduction: the partials are per-tile SLABS in accumulator-register order (whole tiles, also at the edges)
             bm, bn = (96, 128) if p.tile == 3 else _TILES[p.tile][:2]
             ntiles = -(-p.M // bm) * -(-p.NPIX // bn)
-            p.ws = _p(_workspace(ntiles * s * bm * bn, device))
-            p.tile_counters = _p(_tile_counters(ntiles, device))
+            # both buffers stay referenced until the launch has been issued: inside a stream capture they are fresh tensors of the
+            # graph's pool, and a workspace dropped right after taking its pointer handed ITS block to the counters allocated next
+            # (slabs and tickets in the same memory: the captured Diff-Pruning sweep lost 4 % of its loss, round 4)
+            ws_t, tc_t = _workspace(ntiles * s * bm * bn, device), _tile_counters(ntiles, device)
+            p._keep = (ws_t, tc_t)
+            p.ws, p.tile_counters = _p(ws_t), _p(tc_t)
         else:
             p.ws = _p(_workspace(s * p.M * p.NPIX, device))
 
@@ -563,6 +567,48 @@ def _workspace(n, device):
     return t
 
 
+WGRAD_WINO = os.environ.get('DP_WGRAD_WINO', '1') not in ('0', '')
+WGRAD_WINO_MIN_WORK = int(os.environ.get('DP_WGRAD_WINO_MIN_WORK', '512'))      # (64x64 tiles x 3 kernel rows) x (pixels / 1024)
+
+
+def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
+    """3x3 / stride 1 / pad 1 weight gradient on the transposed Winograd F(2, 3) kernel (csrc/winograd.hip): 2/3 of the multiplies.
+    Same split-K partials and reduction launch as the direct form.  None = the kernel does not take the shape."""
+    N, Cout, Ho, Wo = dy.shape
+    C1 = x.shape[1]
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    P = N * Ho * Wo
+    p = L.NtGemmParams()
+    p.A, p.a_bs, p.a_img_stride = _p(dy), 0, sd
+    p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(dy), _extent_bytes(x), _extent_bytes(x2)
+    p.g = _geom(Ho, Wo, Ho, Wo, Ho, Wo, 3, 1, 1, 1, 1, 0, C1 if x2 is not None else Cin, s1, s2)
+    p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, 9, P
+    tiles = -(-Cout // 64) * (-(-C1 // 64) + (-(-(Cin - C1) // 64) if x2 is not None else 0)) * 3
+    nt = P // 32 + 1                                   # K tiles of 16 pairs (the tiling is shifted by two pixels: one more tile)
+    splits = max(1, min(WGRAD_BLOCKS // tiles, nt // 4))
+    tps = -(-nt // splits)
+    splits = -(-nt // tps)
+    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 32, 0, 0
+    p.alpha = alpha
+    p.ldo = Cin * 9
+    if not _lib().dp_wgrad_wino_supported(C.byref(p)):
+        return None
+    flops = 2.0 * Cout * Cin * 6 * P
+    if splits == 1:
+        p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino', flops), 'dp_wgrad_wino')
+    else:
+        n = Cout * Cin * 9
+        ws = _workspace(splits * n, dy.device)
+        p.out, p.o_bs, p.accumulate = _p(ws), n, 0
+        p.ldo, p.o_col_stride, p.o_tap_stride = Cin, 1, Cout * Cin          # tap-major partials [split][tap][Cout][Cin]
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino', flops), 'dp_wgrad_wino')
+        L.check(_lib().dp_splitk_reduce_taps(_p(ws), n, splits, _p(gw), Cout * Cin, 9, 1 if accumulate else 0, _stream()),
+                'dp_splitk_reduce_taps')
+    return gw
+
+
 def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=None):
     """gw[Cout, Cin(, k, k)] (+)= alpha * sum_pixels dy (x) gathered(cat(x, x2)).  Deterministic split-K."""
     sd = _chk_act(dy)
@@ -584,6 +630,11 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
                and 2 * spec.pad == spec.k - 1)
     if WGRAD_MERGE_TAPS and square and (few_in or few_out):
         return _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in)
+    if (WINO and WGRAD_WINO and taps == 9 and square and spec.stride == 1 and spec.pad == 1 and not spec.ups and max_splits is None
+            and (Hs, Ws) == (Ho, Wo) and P % 32 == 0 and -(-Cout // 64) * -(-Cin // 64) * 3 * (P // 1024) >= WGRAD_WINO_MIN_WORK):
+        r = _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
+        if r is not None:
+            return r
     # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension
     # (N*Ho*Wo, up to 262144) supplies the parallelism; partial sums are reduced in a fixed order (deterministic).
     geom = _geom(Ho, Wo, Hs, Ws, Hs << spec.ups, Ws << spec.ups, spec.kw, spec.stride, 1, spec.pad_h, spec.pad_w, spec.ups,

@@ -103,6 +103,15 @@ typedef struct dp_nt_gemm_params {
 } dp_nt_gemm_params;
 int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
 
+/* Weight gradient of the same convolutions by the transposed algorithm (3 taps from output pairs: 4 multiplies instead of 6 per
+ * pair, kernel row and channel pair), csrc/winograd.hip wgrad_wino_kernel.  Parameter block as for dp_nt_gemm's weight-gradient
+ * launches (A = dy, X1 / X2 = the layer input, ntaps = 9, tap-major split-K partials); the K range is counted in 32-pixel tiles
+ * over P/32 + 1 tiles, so splits * p_per_split must cover P + 32.  Replaces the ConvolutionBackward weight gradient of
+ * diffusers/models/resnet.py:606,630 (conv1 / conv2).  Shapes: 3x3 / stride 1 / pad 1, W a power of two in 8..256, H*W a power of
+ * two >= 64, P % 32 == 0, c_split % 64 == 0 with two sources. */
+int dp_wgrad_wino(const dp_nt_gemm_params* p, void* stream);
+int dp_wgrad_wino_supported(const dp_nt_gemm_params* p);
+
 /* out[i] (+)= sum_s ws[s*stride + i], fixed summation order (deterministic split-K epilogue). */
 int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate, void* stream);
 /* same for tap-major partials ws[s][tap][mc] -> out[mc][ntaps] (the torch weight layout) */

@@ -267,10 +267,13 @@ ATTN_CASES = [
 
 
 @pytest.mark.parametrize('N,heads,d,dv,H,sliced,gain', ATTN_CASES)
-def test_fused_attention_matches_fp64_sdpa(ops, report, N, heads, d, dv, H, sliced, gain):
+def test_fused_attention_matches_fp64_sdpa(ops, report, monkeypatch, N, heads, d, dv, H, sliced, gain):
     """dp_attention_fwd (QK^T -> online softmax -> P.V in one kernel, csrc/attention.hip) vs fp64 softmax attention and vs the
     three-launch path it replaces in sampling forwards; twice: bit-identical; both schedules."""
     T = H * H
+    # the default ('auto') takes the kernel only where it measured faster (T <= 256, heads <= 512 wide): every supported shape here
+    assert ops.FUSED_ATTN == 'auto' and ops.attention_fused_ok(T, d, dv) == (T <= 256 and d <= 512 and dv <= 512 and T % 32 == 0)
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
     if sliced and d == dv:                              # channel slices of one fused QKV activation (engine.attn_fwd)
         qkv = rnd(N, 3 * heads * d, H, H, seed=1)
         q, k, v = qkv[:, :heads * d], qkv[:, heads * d:2 * heads * d], qkv[:, 2 * heads * d:]
@@ -304,10 +307,14 @@ def test_fused_attention_in_the_sampling_forward(ops, report, monkeypatch):
     model = make_model(gc.CIFAR_CFG, 0)
     x = rnd(4, 3, 32, 32, seed=5)
     t = torch.tensor([10, 400, 700, 999], device=DEV)
+    monkeypatch.setattr(ops, 'FUSED_ATTN', False)
     with torch.no_grad():
         y0 = model(x, t).sample
         monkeypatch.setattr(ops, 'FUSED_ATTN', True)
         y1 = model(x, t).sample
+        monkeypatch.setattr(ops, 'FUSED_ATTN', 'auto')                  # the default: T = 256, d = 256 -> the fused kernel
+        y2 = model(x, t).sample
+    assert torch.equal(y2, y1)
     e = relerr(y1, y0)
     ldm = pkg('ldm')
     m2 = ldm.UNetModel(**gc.LDM_TINY_CFG)
@@ -315,6 +322,7 @@ def test_fused_attention_in_the_sampling_forward(ops, report, monkeypatch):
     m2 = m2.to(DEV).eval()
     xl, ctx = rnd(2, 3, 16, 16, seed=6), rnd(2, 1, 16, seed=7)
     tl = torch.tensor([3, 500], device=DEV)
+    monkeypatch.setattr(ops, 'FUSED_ATTN', True)
     with torch.no_grad():
         z1 = m2(xl, tl, context=ctx)
         monkeypatch.setattr(ops, 'FUSED_ATTN', False)
@@ -1026,3 +1034,36 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
     report['conv/winograd_f23/%d_%d_%d_%d' % (N, C1 + C2, Cout, H)] = dict(e, run_to_run_equal=bool(torch.equal(y_w, y_w2)))
     assert torch.equal(y_w, y_w2)
     assert e['fwd'] < 3e-6 and e['acc'] < 3e-6 and e['dgrad'] < 3e-6, e
+
+
+@pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 192, 8),
+                                             (2, 64, 0, 96, 64), (8, 40, 0, 70, 16), (1, 32, 0, 48, 256)], ids=str)
+def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
+    """dp_wgrad_wino (3x3 / stride 1 / pad 1 weight gradient by the transposed Winograd F(2, 3) algorithm) against the fp64 weight
+    gradient, next to the direct kernel's error: two concat sources, row / column tails (96, 70, 40 channels), images of 8 .. 256
+    pixels width, accumulation into an existing gradient, several split counts; run-to-run bit-identical."""
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)
+    xa, xb = rnd(N, C1, H, H, seed=1), (rnd(N, C2, H, H, seed=2) if C2 else None)
+    dy = rnd(N, Cout, H, H, seed=5)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    x = torch.cat([xa, xb], 1) if C2 else xa
+    xd = x.double().cpu().requires_grad_(False)
+    wz = torch.zeros(Cout, C1 + C2, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xd, wz, None, padding=1).backward(dy.double().cpu())
+    ref = 0.5 * wz.grad
+    used = []
+    real = ops._conv_wgrad_wino
+    monkeypatch.setattr(ops, '_conv_wgrad_wino', lambda *a: (lambda r: (used.append(r is not None), r)[1])(real(*a)))
+    g0 = rnd(Cout, C1 + C2, 3, 3, seed=9)
+    gw = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gw, spec, alpha=0.5, accumulate=True)
+    gw2 = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gw2, spec, alpha=0.5, accumulate=True)
+    assert used == [True, True], used
+    monkeypatch.setattr(ops, 'WGRAD_WINO', False)
+    gd = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gd, spec, alpha=0.5, accumulate=True)
+    e_w, e_d = relerr(gw - g0, ref), relerr(gd - g0, ref)
+    report['wgrad/winograd_f23/%d_%d_%d_%d' % (N, C1 + C2, Cout, H)] = dict(wino=e_w, direct=e_d, run_to_run_equal=bool(torch.equal(gw, gw2)))
+    assert torch.equal(gw, gw2)
+    assert e_w < 5e-6, (e_w, e_d)

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ops = importlib.import_module('diff-pruning_amd.ops')
 ops.WINO_MIN_TILES = 0
+ops.WGRAD_WINO_MIN_WORK = 0
 B = int(os.environ.get('B', '256'))
 
 
@@ -27,10 +28,22 @@ for (ci, c2, co, h) in [(256, 0, 256, 16), (128, 0, 128, 32), (128, 128, 128, 32
     x2 = ops.empty_act((bb, c2, h, h), torch.device('cuda')).normal_() if c2 else None
     w = torch.randn(co, ci + c2, 3, 3, device='cuda') / math.sqrt((ci + c2) * 9)
     spec = ops.ConvSpec(3, 1, 1, 0)
-    for mode, name in ((0, 'fwd'), (1, 'dgrad')):
-        wp, ld = ops.pack_weight(w, mode)
-        U = ops.pack_weight_wino(w, mode)
-        if mode == 0:
+    for mode, name in ((0, 'fwd'), (1, 'dgrad'), (2, 'wgrad')):
+        if mode == 2:
+            dy = ops.empty_act((bb, co, h, h), x.device).normal_()
+            y1, y2 = torch.zeros_like(w), torch.zeros_like(w)
+            def f_d():
+                ops.WGRAD_WINO = False
+                ops.conv_wgrad(dy, x, x2, y1, spec, accumulate=False)
+            def f_w():
+                ops.WGRAD_WINO = True
+                ops.conv_wgrad(dy, x, x2, y2, spec, accumulate=False)
+        if mode < 2:
+            wp, ld = ops.pack_weight(w, mode)
+            U = ops.pack_weight_wino(w, mode)
+        if mode == 2:
+            pass
+        elif mode == 0:
             y1 = ops.empty_act((bb, co, h, h), x.device); y2 = ops.empty_act((bb, co, h, h), x.device)
             f_d = lambda: ops.conv_forward(x, x2, wp, ld, co, spec, out=y1)
             f_w = lambda: ops.conv_forward(x, x2, wp, ld, co, spec, out=y2, wino=U)
