@@ -1400,6 +1400,11 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
     outputs / gradients / prune masks must still come out: masks bit-exact, tensors within the tolerances of the original tests."""
     ops = pkg('ops')
     monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)              # ... and every supported weight gradient its Winograd kernel
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
+    nw = [0]
+    real_w = ops._conv_wgrad_wino
+    monkeypatch.setattr(ops, '_conv_wgrad_wino', lambda *a: (lambda r: (nw.__setitem__(0, nw[0] + (r is not None)), r)[1])(real_w(*a)))
     n = [0]
     real = ops._conv_wino
     monkeypatch.setattr(ops, '_conv_wino', lambda *a: (lambda r: (n.__setitem__(0, n[0] + bool(r)), r)[1])(real(*a)))
@@ -1409,5 +1414,5 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
      'c1_size_1000': test_c1_size_1000_step_sweep_masks_match_reference, 'ddim': test_ddim_sampling_matches_reference,
      'pruned_sweep': test_pruned_model_sweep_matches_oracle, 'ldm_fwd_bwd': test_ldm_unet_forward_backward_matches_reference,
      'finetune': test_autograd_bridge_and_finetune_step}[which](sub)
-    report['wino_forced/' + which] = dict(sub, winograd_launches=n[0])
-    assert n[0] > 0
+    report['wino_forced/' + which] = dict(sub, winograd_launches=n[0], winograd_wgrad_launches=nw[0])
+    assert n[0] > 0 and (nw[0] > 0 or which in ('tiny_forward', 'ddim'))

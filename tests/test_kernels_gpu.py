@@ -1043,6 +1043,7 @@ def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, C
     gradient, next to the direct kernel's error: two concat sources, row / column tails (96, 70, 40 channels), images of 8 .. 256
     pixels width, accumulation into an existing gradient, several split counts; run-to-run bit-identical."""
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
     xa, xb = rnd(N, C1, H, H, seed=1), (rnd(N, C2, H, H, seed=2) if C2 else None)
     dy = rnd(N, Cout, H, H, seed=5)
     spec = ops.ConvSpec(3, 1, 1, 0)
