@@ -88,6 +88,7 @@ SIGNATURES = {
     'dp_conv_gemm': [C.POINTER(ConvGemmParams), _vp],
     'dp_conv_wino': [C.POINTER(ConvGemmParams), _vp],
     'dp_conv_wino_supported': [C.POINTER(ConvGemmParams)],
+    'dp_conv_splitk_epilogue': [C.POINTER(ConvGemmParams), _vp],
     'dp_pack_weight_wino': [_vp, _i, _i, _i, _vp, _i, _vp],
     'dp_wgrad_wino': [C.POINTER(NtGemmParams), _vp],
     'dp_wgrad_wino_supported': [C.POINTER(NtGemmParams)],

@@ -1081,6 +1081,15 @@ static bool conv_few_out_ok(const dp_conv_gemm_params& p) {
            p.NPIX % (g.Ho * g.Wo) == 0;
 }
 
+// the reduction launch of a split-K convolution (also used by dp_conv_wino): out = epilogue(sum_z ws[z][m][pix])
+extern "C" int dp_conv_splitk_epilogue(const dp_conv_gemm_params* pp, void* stream) {
+    const dp_conv_gemm_params& p = *pp;
+    long long nb = ((long long)p.M * p.NPIX + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    DP_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    return DP_LAUNCH_CHECK();
+}
+
 extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
     const dp_conv_gemm_params& p = *pp;
     hipStream_t st = (hipStream_t)stream;
@@ -1113,10 +1122,7 @@ extern "C" int dp_conv_gemm(const dp_conv_gemm_params* pp, void* stream) {
         default: return (int)hipErrorInvalidValue;
     }
     if (e || p.ksplit <= 1 || p.tile_counters) return e;
-    long long nb = ((long long)p.M * p.NPIX + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    DP_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
-    return DP_LAUNCH_CHECK();
+    return dp_conv_splitk_epilogue(pp, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     const int C = p.C;
     const int C1 = p.X2 ? g.c_split : C;
     const int nch = C / BK;
-    const int nIter = 3 * nch;
+    const int nIterAll = 3 * nch;
+    // split-K (small grids): workgroup z reduces K tiles [it0, it0 + nIter) and writes its output-transformed partial sums to
+    // ws[z][m][pix]; dp_conv_splitk_epilogue sums them in ascending z and applies the epilogue (the transform is linear)
+    const bool ksplit = p.ksplit > 1;
+    const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
+    const int it0 = ksplit ? (int)blockIdx.z * per : 0;
+    const int nIter = ksplit ? max(0, min(per, nIterAll - it0)) : nIterAll;
 
     // ---- A loader: float4 element e = tid + 256 j of [pos][k][m/4]
     unsigned a_voff[NJA];
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     float* const ldsB = smem + A_SZ + RPW * wave * BN;              // + buf*STAGE + 4*RPW*j*BN
     const unsigned a_ky_step = (unsigned)(4 * C) * (unsigned)p.lda * 4u;
 
-    int ch = 0, ky = 0;
+    int ch = it0 / 3, ky = it0 - 3 * (it0 / 3);
     auto dma_tile = [&](int buf) {
         const unsigned a_soff = (unsigned)ky * a_ky_step + (unsigned)(ch * BK) * (unsigned)p.lda * 4u;
 #pragma unroll
@@ -139,9 +145,11 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     const int wo_p = px % W;
     const bool pad_l = wo_p == 0, pad_r = wo_p + 2 == W;
 
-    dma_tile(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nIter > 0) {
+        dma_tile(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     for (int it = 0; it < nIter; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIter) advance();
@@ -180,6 +188,18 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
 
     // ---- output transform + epilogue: col j = lane & 31 -> pair, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     if (px >= p.NPIX) return;
+    if (ksplit) {
+        float* wsb = p.ws + (long long)blockIdx.z * p.M * p.NPIX + px;
+        const int mbs = m0 + wr * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbs + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) continue;
+            *reinterpret_cast<float2*>(wsb + (long long)m * p.NPIX) =
+                make_float2((acc[0][r] + acc[1][r]) + acc[2][r], (acc[1][r] - acc[2][r]) - acc[3][r]);
+        }
+        return;
+    }
     const int img = px / HW, r_in = px - img * HW;
     float* optr = p.out + (long long)img * p.o_img_stride + r_in;
     const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
 static int wino_bk(const dp_conv_gemm_params& p) {
     const dp_conv_geom& g = p.g;
     if (p.a_kc || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups || g.pad_t != 1 || g.pad_l != 1) return 0;
-    if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || p.ksplit > 1) return 0;
+    if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || (p.ksplit > 1 && (!p.ws || (p.NPIX & 1)))) return 0;
     const int W = g.Wo;
     if (W < 4 || W > 256 || (W & (W - 1))) return 0;        // W must divide the pixel tile (128, or 256 with the 32-row tiles)
     if ((p.lda & 3) || ((g.Ho * g.Wo) & 1)) return 0;
@@ -219,6 +239,7 @@ static int wino_bk(const dp_conv_gemm_params& p) {
 }
 
 extern "C" int dp_conv_wino_supported(const dp_conv_gemm_params* p) { return wino_bk(*p); }
+extern "C" int dp_conv_splitk_epilogue(const dp_conv_gemm_params* p, void* stream);      // gemm.hip
 
 extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
     const dp_conv_gemm_params& p = *pp;
@@ -232,15 +253,17 @@ extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
     const bool wr1 = p.g.Wo > 128 || (fwr ? atoi(fwr) == 1 : ((p.M + 31) / 32) * 32 < ((p.M + 63) / 64) * 64);
     hipStream_t st = (hipStream_t)stream;
     if (wr1) {
-        dim3 grid((p.NPIX + 255) / 256, (p.M + 31) / 32);
+        dim3 grid((p.NPIX + 255) / 256, (p.M + 31) / 32, p.ksplit > 1 ? p.ksplit : 1);
         if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 1>), grid, dim3(256), 0, st, p);
         else          DP_LAUNCH((conv_wino_kernel<8, 1>), grid, dim3(256), 0, st, p);
     } else {
-        dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64);
+        dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : 1);
         if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
         else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
     }
-    return DP_LAUNCH_CHECK();
+    const int e = DP_LAUNCH_CHECK();
+    if (e || p.ksplit <= 1) return e;
+    return dp_conv_splitk_epilogue(pp, stream);
 }
 
 // U[(ky*4 + pos)*K + k][ld] from a torch [Co][Ci][3][3] weight.  mode 0 (forward): K = Ci, columns m = co, taps as stored;

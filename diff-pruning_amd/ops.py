@@ -346,7 +346,13 @@ def wino_wanted(M, C_sources, N, H, W, spec):
         return False
     if any(c % 8 for c in C_sources):
         return False
-    return -(-M // 64) * -(-(N * H * W) // 128) >= WINO_MIN_TILES
+    tiles = -(-M // 64) * -(-(N * H * W) // 128)
+    if tiles >= WINO_MIN_TILES:
+        return True
+    C = sum(C_sources)                                   # smaller grids: split-K must supply >= half of the wanted workgroups
+    n_iter = 3 * (C // 16 if all(c % 16 == 0 for c in C_sources) else C // 8)
+    ks = min(WINO_MIN_TILES // max(tiles, 1), n_iter // 8)
+    return ks >= 2 and tiles * ks >= WINO_MIN_TILES // 2
 
 
 def pack_weight_wino(w, mode):
@@ -367,12 +373,22 @@ def _conv_wino(p, wino, act_bytes):
     if not WINO:
         return False
     U, ld = wino
-    if -(-p.M // 64) * -(-p.NPIX // 128) < WINO_MIN_TILES:
-        return False
+    tiles = -(-p.M // 64) * -(-p.NPIX // 128)
+    ks = 1
+    if tiles < WINO_MIN_TILES:
+        # small grids: split the (channel chunk, kernel row) loop like _conv_ksplit does for the direct form (>= 8 K tiles a slice)
+        n_iter = 3 * (p.C // 16 if p.C % 16 == 0 else p.C // 8)
+        ks = min(WINO_MIN_TILES // max(tiles, 1), n_iter // 8)
+        if ks < 2 or tiles * ks < WINO_MIN_TILES // 2 or (p.NPIX & 1):
+            return False
     A0, lda0, ab0 = p.A, p.lda, p.a_bytes
     p.A, p.lda, p.a_bytes = _p(U), ld, U.numel() * 4
+    if ks > 1:
+        ws_t = _workspace(ks * p.M * p.NPIX, U.device)
+        p._keep = (ws_t,)
+        p.ksplit, p.ws, p.tile_counters = ks, _p(ws_t), None
     if not _lib().dp_conv_wino_supported(C.byref(p)):
-        p.A, p.lda, p.a_bytes = A0, lda0, ab0
+        p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
         return False
     L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino', 2.0 * p.M * p.NPIX * p.C * 6,
                  act_bytes + 4.0 * U.numel()), 'dp_conv_wino')

@@ -66,11 +66,14 @@ int dp_conv_gemm(const dp_conv_gemm_params* p, void* stream);
  * in the epilogue.  Replaces the same call sites as dp_conv_gemm's 3x3 forward / input-gradient launches
  * (diffusers/models/resnet.py:606,630 conv1 / conv2 and their ConvolutionBackward input gradients;
  * ldm/modules/diffusionmodules/openaimodel.py:214-232 in_layers / out_layers).  Same parameter block and epilogue; A is the
- * operand of dp_pack_weight_wino, U[(ky*4 + pos)*C + c][lda]; ksplit / batches / a_kc must be unset.
+ * operand of dp_pack_weight_wino, U[(ky*4 + pos)*C + c][lda]; batches / a_kc / tile_counters must be unset; ksplit > 1 splits the
+ * (channel chunk, kernel row) loop over blockIdx.z with partials in ws and the reduction launch of dp_conv_gemm.
  * dp_conv_wino_supported returns the K-chunk width the kernel would use (16 / 8) or 0 when the shape is not taken
  * (W a power of two in 4..256, channel counts per concat source multiples of 8, 3x3 / stride 1 / pad 1). */
 int dp_conv_wino(const dp_conv_gemm_params* p, void* stream);
 int dp_conv_wino_supported(const dp_conv_gemm_params* p);
+/* the reduction launch of a split-K convolution (ksplit > 1, no tile_counters): out = epilogue(sum_z ws[z][m][pix]), ascending z */
+int dp_conv_splitk_epilogue(const dp_conv_gemm_params* p, void* stream);
 /* mode 0: forward operand (K = Ci, columns = co); mode 1: input-gradient operand (K = Co, columns = ci, taps flipped).
  * dst holds 12 * K * ld floats. */
 int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);

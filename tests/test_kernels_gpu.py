@@ -1031,6 +1031,19 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
     e = dict(fwd=relerr(y_w, ref), fwd_direct=relerr(y_d, ref), acc=relerr(acc, ref_acc), dgrad=relerr(d_w, ref_d),
              dgrad_direct=relerr(d_d, ref_d))
     y_w2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+    # split-K form (small grids): the (channel chunk, kernel row) loop over blockIdx.z + the reduction launch
+    seen = []
+    real_sup = ops._lib().dp_conv_wino
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 4 * (-(-Cout // 64)) * (-(-(N * H * H) // 128)))      # wants 4 slices, gets min(4, K tiles / 8)
+    if (C1 + C2) >= 96:                                  # >= 16 K tiles: at least two slices of 8
+        import ctypes
+        y_s = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+        acc_s = res.clone()
+        ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc_s, accumulate=True, wino=U0)
+        y_s2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+        e['fwd_splitk'], e['acc_splitk'] = relerr(y_s, ref), relerr(acc_s, ref_acc)
+        assert launched[-3:] == [True, True, True] and torch.equal(y_s, y_s2)
+        assert e['fwd_splitk'] < 3e-6 and e['acc_splitk'] < 3e-6, e
     report['conv/winograd_f23/%d_%d_%d_%d' % (N, C1 + C2, Cout, H)] = dict(e, run_to_run_equal=bool(torch.equal(y_w, y_w2)))
     assert torch.equal(y_w, y_w2)
     assert e['fwd'] < 3e-6 and e['acc'] < 3e-6 and e['dgrad'] < 3e-6, e
