@@ -417,7 +417,7 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step):
     cnt, fl, sec, ab = agg[dom]
     # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
     # this same command, aggregated by tools/pmc_aggregate.py; KB -> bytes) that cannot run inside this process: they are read
-    # from the newest profiles/round*_pmc_bench_traffic.json, which records the git blob of csrc/gemm.hip it was measured on.
+    # from the newest profiles/round*_pmc_bench_traffic.json, which records a hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip) it was measured on.
     # A different blob today = stale counters = traffic null.  FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on
     # gfx950 (MI355X_MICROARCH.md, HBM section).
     traffic, traffic_src = None, None
@@ -425,8 +425,8 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step):
         import glob
         import hashlib
         cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic.json')))
-        src = open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', 'gemm.hip'), 'rb').read()
-        blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
+        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
+        blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()          # the contraction kernels' sources, concatenated
         pm = json.load(open(cand[-1]))
         measured_on = pm.get('_gemm_hip_blob')
         traffic_src = dict(file=os.path.relpath(cand[-1], ROOT), measured_on_gemm_hip_blob=measured_on,

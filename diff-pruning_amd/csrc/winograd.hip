@@ -166,20 +166,33 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
             fd[0] = Bf[2 * ks * BN - 1];
             fd[3] = Bf[2 * ks * BN + 2];
         };
+        // The input transform of k-step ks + 1 is issued BEHIND the four MFMAs of k-step ks (DPW_VPIPE, default): a transform
+        // directly in front of its MFMA costs a VALU -> MFMA operand stall (s_nop 1) per matrix instruction.
+        float v[2][4];
+        auto xform = [&](const float (&fd)[4], float (&fv)[4]) {
+            const float d0 = pad_l ? 0.f : fd[0], d3 = pad_r ? 0.f : fd[3];
+            fv[0] = d0 - fd[2]; fv[1] = fd[1] + fd[2]; fv[2] = fd[2] - fd[1]; fv[3] = fd[1] - d3;
+        };
         frag(0, a[0], d[0]);
+#ifndef DPW_NO_VPIPE
+        xform(d[0], v[0]);
+#endif
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int cur = ks & 1;
             if (ks + 1 < BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const float d0 = pad_l ? 0.f : d[cur][0], d3 = pad_r ? 0.f : d[cur][3];
-            const float d1 = d[cur][1], d2 = d[cur][2];
-            const float v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], v0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], v1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], v2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], v3, acc[3], 0, 0, 0);
+#ifdef DPW_NO_VPIPE
+            xform(d[cur], v[cur]);
+#endif
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], v[cur][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], v[cur][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], v[cur][2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], v[cur][3], acc[3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef DPW_NO_VPIPE
+            if (ks + 1 < BK / 2) { xform(d[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
+#endif
             if (ks == 1) { dma_tile(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,19 +452,33 @@ __global__ __launch_bounds__(256, 4) void wgrad_wino_kernel(const dp_nt_gemm_par
                 fd[2] = Bf[4 * ks + 2];
                 fd[3] = Bf[4 * ks + 3];
             };
+            float ua[2][4], ub[2][4];                   // transformed operands, one k-step ahead of the MFMAs (see conv_wino_kernel)
+            auto xform = [&](int ks, const float (&fa)[2], const float (&fd)[4], float (&xa)[4], float (&xb)[4]) {
+                const float y0 = fa[0], y1 = fa[1];
+                const float d0 = fd[0] * fl[ks], d1 = fd[1], d2 = fd[2], d3 = fd[3] * fr[ks];
+                xa[0] = y0; xa[1] = y0 + y1; xa[2] = y0 - y1; xa[3] = -y1;
+                xb[0] = d0 - d2; xb[1] = d1 + d2; xb[2] = d2 - d1; xb[3] = d1 - d3;
+            };
             frag(0, a[0], d[0]);
+#ifndef DPW_NO_VPIPE
+            xform(0, a[0], d[0], ua[0], ub[0]);
+#endif
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int cur = ks & 1;
                 if (ks + 1 < 8) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                const float y0 = a[cur][0], y1 = a[cur][1];
-                const float d0 = d[cur][0] * fl[ks], d1 = d[cur][1], d2 = d[cur][2], d3 = d[cur][3] * fr[ks];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, d0 - d2, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 + y1, d1 + d2, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 - y1, d2 - d1, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-y1, d1 - d3, acc[3], 0, 0, 0);
+#ifdef DPW_NO_VPIPE
+                xform(ks, a[cur], d[cur], ua[cur], ub[cur]);
+#endif
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[cur][0], ub[cur][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[cur][1], ub[cur][1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[cur][2], ub[cur][2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[cur][3], ub[cur][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef DPW_NO_VPIPE
+                if (ks + 1 < 8) { xform(ks + 1, a[cur ^ 1], d[cur ^ 1], ua[cur ^ 1], ub[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 if (ks == 1) { dma_tile(t0 + (it + 1 < nIter ? it + 1 : it), buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -387,10 +387,12 @@ def _conv_wino(p, wino, act_bytes):
         ws_t = _workspace(ks * p.M * p.NPIX, U.device)
         p._keep = (ws_t,)
         p.ksplit, p.ws, p.tile_counters = ks, _p(ws_t), None
-    if not _lib().dp_conv_wino_supported(C.byref(p)):
+    bk = _lib().dp_conv_wino_supported(C.byref(p))
+    if not bk:
         p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
         return False
-    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino', 2.0 * p.M * p.NPIX * p.C * 6,
+    wr = 1 if (p.g.Wo > 128 or -(-p.M // 32) * 32 < -(-p.M // 64) * 64) else 2          # the launcher's tile rule (csrc/winograd.hip)
+    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino_kernel<%d, %d>' % (bk, wr), 2.0 * p.M * p.NPIX * p.C * 6,
                  act_bytes + 4.0 * U.numel()), 'dp_conv_wino')
     return True
 
@@ -614,13 +616,13 @@ def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     flops = 2.0 * Cout * Cin * 6 * P
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino', flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel', flops), 'dp_wgrad_wino')
     else:
         n = Cout * Cin * 9
         ws = _workspace(splits * n, dy.device)
         p.out, p.o_bs, p.accumulate = _p(ws), n, 0
         p.ldo, p.o_col_stride, p.o_tap_stride = Cin, 1, Cout * Cin          # tap-major partials [split][tap][Cout][Cin]
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino', flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel', flops), 'dp_wgrad_wino')
         L.check(_lib().dp_splitk_reduce_taps(_p(ws), n, splits, _p(gw), Cout * Cin, 9, 1 if accumulate else 0, _stream()),
                 'dp_splitk_reduce_taps')
     return gw

@@ -30,10 +30,10 @@ def main():
         if k.startswith('at::') or len(k) > 160:
             continue
         res[k] = {c: {('avg_kb' if c.endswith('_SIZE') else 'avg'): v / n, 'n': n} for c, (n, v) in cs.items()}
-    # stamp the source the counters were measured on: bench.py refuses the numbers once csrc/gemm.hip has changed
+    # stamp the source the counters were measured on: bench.py refuses the numbers once csrc/gemm.hip or csrc/winograd.hip has changed
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, 'diff-pruning_amd', 'csrc', 'gemm.hip'), 'rb').read()
+    src = b''.join(open(os.path.join(root, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
     res['_gemm_hip_blob'] = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
     print('wrote', out, len(res), 'kernels')

@@ -1,11 +1,11 @@
-# Round-3 evidence (one MI355X via gpurun).  usage: bash tools/run_evidence.sh tests|bench|profiles|pmc
+# Round-4 evidence (one MI355X via gpurun).  usage: bash tools/run_evidence.sh tests|bench|profiles|pmc
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
-R=round3
+R=round4
 stats() {  # name, -- command: rocprofv3 per-kernel summary of one bench.py configuration
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r3_prof_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r4_prof_$name.log 2>&1
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1); cp "$f" $O/${R}_${name}_kernel_stats.csv 2>/dev/null
 }
 case "$1" in
@@ -33,7 +33,7 @@ profiles)
   ls -la $O/${R}_*kernel_stats.csv ;;
 pmc)
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r3_pmc_$ctr.log 2>&1
+    DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/r4_pmc_$ctr.log 2>&1
   done
   python tools/pmc_aggregate.py $O/${R}_pmc_bench_traffic.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE ;;
 esac
