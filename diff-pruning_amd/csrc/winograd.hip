@@ -324,17 +324,24 @@ extern "C" int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, flo
 // rows a wavefront reads on 8 different 16-byte bank groups (a dense 8-slot row would put them on one).  Horizontal padding and
 // the pairs outside [0, P) are per-lane multipliers (0 / 1) on d0 / d3 and zeroed A slots.
 // ================================================================================================================================
-__global__ __launch_bounds__(256, 4) void wgrad_wino_kernel(const dp_nt_gemm_params p) {
+// WRxWC wavefronts per workgroup, each a 32 x 32 (m, c) tile with its four position accumulators: 2 x 2 (64 x 64 tile, 256 threads)
+// or 3 x 3 (96 x 96, 576 threads) for the 96-multiples of pruned models, which fill 64-wide tiles to 56 - 75 %.
+template <int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, 4) void wgrad_wino_kernel(const dp_nt_gemm_params p) {
+    constexpr int NT = 64 * WR * WC, BMt = 32 * WR, BNt = 32 * WC;
     constexpr int RS = 36;                              // floats per LDS row: 9 slots of 4 pixels
-    constexpr int OP_SZ = 64 * RS;                      // one operand tile (64 rows)
-    constexpr int STAGE = 2 * OP_SZ;
+    constexpr int SA = BMt * 9, SB = BNt * 9;           // 16-byte slots per operand tile
+    constexpr int RA = (SA + 63) / 64 * 64, RB = (SB + 63) / 64 * 64;      // ... rounded to whole wave instructions (zero-filled tail)
+    constexpr int OP_SZ = 4 * RA;                       // floats in front of the B tile
+    constexpr int STAGE = 4 * (RA + RB);
+    constexpr int NA = (SA + NT - 1) / NT, NB = (SB + NT - 1) / NT;        // load instructions per lane and K tile
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wr = wave / WC, wc = wave - WC * wr;
+    const int m0 = blockIdx.y * BMt, n0 = blockIdx.x * BNt;
     const int split = blockIdx.z / 3, ky = blockIdx.z - 3 * split;
 
     const dp_conv_geom& g = p.g;
@@ -352,26 +359,26 @@ __global__ __launch_bounds__(256, 4) void wgrad_wino_kernel(const dp_nt_gemm_par
     const int t0 = split * tps, t1 = min(t0 + tps, T);
     const int nIter = t1 - t0;
 
-    // ---- loaders: A slots q = 256 j + tid (j = 0, 1; j = 2 in wave 0), B slots likewise (j = 2 in wave 1); q -> (row, slot)
+    // ---- loaders: slot q = NT j + tid of the A tile (j < NA) and of the B tile (j < NB); q -> (row q / 9, slot q % 9).  The last
+    //      instruction of an operand is issued by the waves that still hold slots of it (wave-uniform branch).
     const __amdgpu_buffer_rsrc_t rA = dpw_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rB = dpw_rsrc(Xs - W, (src1 ? p.x1_bytes : p.x2_bytes) + 4u * (unsigned)W);   // ky row shift >= 0
-    unsigned a_c[3], b_c[3];           // constant part of the per-lane byte offset, DPW_OOB for rows outside the tile's rows
-    bool is8[3];                       // slot 8: the first four pixels of the NEXT 32-pixel block (its own image / row / validity)
-    int dho[3];                        // image-row offset of the slot inside the block (W < 32)
+    constexpr int NL = (NA > NB) ? NA : NB;
+    unsigned a_c[NL], b_c[NL];         // constant part of the per-lane byte offset, DPW_OOB for rows / slots outside the tile
+    bool is8[NL];                      // slot 8: the first four pixels of the NEXT 32-pixel block (its own image / row / validity)
+    int dho[NL];                       // image-row offset of the slot inside the block (W < 32)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int q = (j < 2) ? 256 * j + tid : 512 + lane;
+    for (int j = 0; j < NL; ++j) {
+        const int q = NT * j + tid;
         const int row = q / 9, s = q - 9 * row;
         is8[j] = s == 8;
         dho[j] = (s == 8) ? 0 : ((4 * s) >> lw);
         const int po = (s == 8) ? 0 : 4 * s;                      // pixel offset inside its 32-pixel block
-        a_c[j] = (m0 + row < p.M) ? (unsigned)(((m0 + row) * HW + po) * 4) : DPW_OOB;
-        b_c[j] = (cb + row < ncs) ? (unsigned)(((cb + row) * HW + po) * 4) : DPW_OOB;
+        a_c[j] = (q < SA && m0 + row < p.M) ? (unsigned)(((m0 + row) * HW + po) * 4) : DPW_OOB;
+        b_c[j] = (q < SB && cb + row < ncs) ? (unsigned)(((cb + row) * HW + po) * 4) : DPW_OOB;
     }
-    float* const ldsA = smem + 4 * (wave * 64);                  // + buf*STAGE + 1024 j  (slot q at float 4 q)
-    float* const ldsA2 = smem + 4 * 512;                         // third instruction: slots 512 .. 575 (wave 0)
+    float* const ldsA = smem + 4 * (wave * 64);                  // + buf*STAGE + 4 NT j  (slot q at float 4 q)
     float* const ldsB = smem + OP_SZ + 4 * (wave * 64);
-    float* const ldsB2 = smem + OP_SZ + 4 * 512;                 // (wave 1)
 
     auto dma_tile = [&](int t, int buf) {
         const int b = 32 * t - 32;                               // block 0: pixels b .. b+31 (slots 0..7), block 1: b+32 .. (slot 8)
@@ -383,26 +390,21 @@ __global__ __launch_bounds__(256, 4) void wgrad_wino_kernel(const dp_nt_gemm_par
         const unsigned b_s0 = (unsigned)((long long)img0 * xis + r0 + ky * W) * 4u;
         const unsigned b_s1 = (unsigned)((long long)img1 * xis + r1 + ky * W) * 4u;
         const int ho0 = r0 >> lw, ho1 = r1 >> lw;
-        auto one = [&](int j, float* la, float* lb) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
             const bool vv = is8[j] ? v1 : v0;
-            unsigned oa = vv ? a_c[j] + (is8[j] ? a_s1 : a_s0) : DPW_OOB;
-            if (a_c[j] == DPW_OOB) oa = DPW_OOB;
-            const int ho = (is8[j] ? ho1 : ho0 + dho[j]) + ky - 1;
-            unsigned ob = (vv && (unsigned)ho < (unsigned)H) ? b_c[j] + (is8[j] ? b_s1 : b_s0) : DPW_OOB;
-            if (b_c[j] == DPW_OOB) ob = DPW_OOB;
-            if (la) {
+            if (j < NA && NT * j + 64 * wave < RA) {
+                unsigned oa = (vv && a_c[j] != DPW_OOB) ? a_c[j] + (is8[j] ? a_s1 : a_s0) : DPW_OOB;
                 asm volatile("" : "+v"(oa));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw_lds_void*)la, 16, (int)oa, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw_lds_void*)(ldsA + buf * STAGE + 4 * NT * j), 16, (int)oa, 0, 0, 0);
             }
-            if (lb) {
+            if (j < NB && NT * j + 64 * wave < RB) {
+                const int ho = (is8[j] ? ho1 : ho0 + dho[j]) + ky - 1;
+                unsigned ob = (vv && (unsigned)ho < (unsigned)H && b_c[j] != DPW_OOB) ? b_c[j] + (is8[j] ? b_s1 : b_s0) : DPW_OOB;
                 asm volatile("" : "+v"(ob));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (dpw_lds_void*)lb, 16, (int)ob, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (dpw_lds_void*)(ldsB + buf * STAGE + 4 * NT * j), 16, (int)ob, 0, 0, 0);
             }
-        };
-        one(0, ldsA + buf * STAGE, ldsB + buf * STAGE);
-        one(1, ldsA + buf * STAGE + 1024, ldsB + buf * STAGE + 1024);
-        if (wave == 0) one(2, ldsA2 + buf * STAGE, nullptr);
-        if (wave == 1) one(2, nullptr, ldsB2 + buf * STAGE);
+        }
     };
 
     f32x16 acc[4];
@@ -515,20 +517,23 @@ static bool wgrad_wino_ok(const dp_nt_gemm_params& p) {
     const int W = g.Wo, HW = g.Ho * g.Wo;
     if (W < 8 || W > 256 || (W & (W - 1)) || (HW & (HW - 1)) || HW < 64) return false;
     if ((p.P % 32) || (p.p_per_split % 32) || p.p_per_split <= 0) return false;
-    if (p.X2 && (g.c_split % 64)) return false;
+    const int bn = p.tile == 3 ? 96 : 64;
+    if (p.X2 && (g.c_split % bn)) return false;
     return true;
 }
 
 extern "C" int dp_wgrad_wino_supported(const dp_nt_gemm_params* p) { return wgrad_wino_ok(*p) ? 1 : 0; }
 
 // p as for dp_nt_gemm's weight-gradient launches (A = dy, X1 / X2 = the convolution input, ntaps = 9); the split-K range is counted
-// in K tiles of 32 pixels over P/32 + 1 tiles: splits * p_per_split must cover P + 32 pixels.
+// in K tiles of 32 pixels over P/32 + 1 tiles: splits * p_per_split must cover P + 32 pixels.  tile = 3: 96 x 96 tiles (9 waves).
 extern "C" int dp_wgrad_wino(const dp_nt_gemm_params* pp, void* stream) {
     const dp_nt_gemm_params& p = *pp;
     if (p.M <= 0 || p.NCOLS <= 0) return 0;
     if (!wgrad_wino_ok(p) || p.splits <= 0 || (long long)p.splits * p.p_per_split < (long long)p.P + 32) return (int)hipErrorInvalidValue;
     const int C1 = p.X2 ? p.g.c_split : p.NCOLS;
-    dim3 grid((C1 + 63) / 64 + (p.X2 ? (p.NCOLS - C1 + 63) / 64 : 0), (p.M + 63) / 64, 3 * p.splits);
-    DP_LAUNCH(wgrad_wino_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int bt = p.tile == 3 ? 96 : 64;
+    dim3 grid((C1 + bt - 1) / bt + (p.X2 ? (p.NCOLS - C1 + bt - 1) / bt : 0), (p.M + bt - 1) / bt, 3 * p.splits);
+    if (p.tile == 3) DP_LAUNCH((wgrad_wino_kernel<3, 3>), grid, dim3(576), 0, (hipStream_t)stream, p);
+    else             DP_LAUNCH((wgrad_wino_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return DP_LAUNCH_CHECK();
 }

@@ -603,12 +603,16 @@ def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(dy), _extent_bytes(x), _extent_bytes(x2)
     p.g = _geom(Ho, Wo, Ho, Wo, Ho, Wo, 3, 1, 1, 1, 1, 0, C1 if x2 is not None else Cin, s1, s2)
     p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, 9, P
-    tiles = -(-Cout // 64) * (-(-C1 // 64) + (-(-(Cin - C1) // 64) if x2 is not None else 0)) * 3
+    # 96 x 96 tiles (nine wavefronts) when they cover [Cout x Cin] with clearly less padding than 64 x 64 tiles
+    a64 = (-(-Cout // 64) * 64) * (-(-Cin // 64) * 64)
+    a96 = (-(-Cout // 96) * 96) * (-(-Cin // 96) * 96)
+    bt = 96 if (a96 < 0.9 * a64 and (x2 is None or C1 % 96 == 0)) else 64
+    tiles = -(-Cout // bt) * (-(-C1 // bt) + (-(-(Cin - C1) // bt) if x2 is not None else 0)) * 3 * (2 if bt == 96 else 1)
     nt = P // 32 + 1                                   # K tiles of 16 pairs (the tiling is shifted by two pixels: one more tile)
     splits = max(1, min(WGRAD_BLOCKS // tiles, nt // 4))
     tps = -(-nt // splits)
     splits = -(-nt // tps)
-    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 32, 0, 0
+    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 32, (3 if bt == 96 else 0), 0
     p.alpha = alpha
     p.ldo = Cin * 9
     if not _lib().dp_wgrad_wino_supported(C.byref(p)):
@@ -616,13 +620,13 @@ def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     flops = 2.0 * Cout * Cin * 6 * P
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel', flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel<%d, %d>' % ((3, 3) if bt == 96 else (2, 2)), flops), 'dp_wgrad_wino')
     else:
         n = Cout * Cin * 9
         ws = _workspace(splits * n, dy.device)
         p.out, p.o_bs, p.accumulate = _p(ws), n, 0
         p.ldo, p.o_col_stride, p.o_tap_stride = Cin, 1, Cout * Cin          # tap-major partials [split][tap][Cout][Cin]
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel', flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel<%d, %d>' % ((3, 3) if bt == 96 else (2, 2)), flops), 'dp_wgrad_wino')
         L.check(_lib().dp_splitk_reduce_taps(_p(ws), n, splits, _p(gw), Cout * Cin, 9, 1 if accumulate else 0, _stream()),
                 'dp_splitk_reduce_taps')
     return gw
@@ -651,8 +655,10 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
         return _conv_wgrad_merged(dy, x, gw, spec, alpha, accumulate, few_in)
     if (WINO and WGRAD_WINO and taps == 9 and square and spec.stride == 1 and spec.pad == 1 and not spec.ups and max_splits is None
             and (Hs, Ws) == (Ho, Wo) and P % 32 == 0 and -(-Cout // 64) * -(-Cin // 64) * 3 * (P // 1024) >= WGRAD_WINO_MIN_WORK
-            # 64 x 64 tiles: a 96 x 96 gradient fills 56 % of them and is faster on the direct kernel's 96 x 96 tile [measured 0.90x]
-            and Cout * Cin >= WGRAD_WINO_MIN_FILL * (-(-Cout // 64) * 64) * (-(-Cin // 64) * 64)):
+            # 64 x 64 tiles (or 96 x 96 for the 96-multiples of pruned models): a 96 x 96 gradient fills 56 % of four 64 x 64 tiles and
+            # is then slower than the direct kernel's 96 x 96 tile [measured 0.90x]
+            and Cout * Cin >= WGRAD_WINO_MIN_FILL * min((-(-Cout // 64) * 64) * (-(-Cin // 64) * 64),
+                                                        (-(-Cout // 96) * 96) * (-(-Cin // 96) * 96))):
         r = _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
         if r is not None:
             return r

@@ -1050,7 +1050,8 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
 
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 192, 8),
-                                             (2, 64, 0, 96, 64), (8, 40, 0, 70, 16), (1, 32, 0, 48, 256)], ids=str)
+                                             (2, 64, 0, 96, 64), (8, 40, 0, 70, 16), (1, 32, 0, 48, 256), (8, 96, 0, 96, 32), (4, 192, 96, 96, 16),
+                                             (4, 179, 0, 90, 16)], ids=str)
 def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_wgrad_wino (3x3 / stride 1 / pad 1 weight gradient by the transposed Winograd F(2, 3) algorithm) against the fp64 weight
     gradient, next to the direct kernel's error: two concat sources, row / column tails (96, 70, 40 channels), images of 8 .. 256
