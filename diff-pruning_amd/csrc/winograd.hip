@@ -49,8 +49,21 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = (WR == 2) ? (wave >> 1) : 0, wc = (WR == 2) ? (wave & 1) : wave;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // The gy row tiles of one pixel tile read the same input tile: with the plain (x, y) order they are gx workgroups apart and run
+    // on whatever XCD that lands on (FETCH_SIZE 1.7x the operands, profiles/round4_pmc_bench_traffic.json).  Remap (grids whose x
+    // extent is a multiple of 8): linear id b -> XCD b % 8, slot b / 8; slot = (pixel-tile group) * gy + row tile, so the row tiles
+    // of pixel tile 8 g + xcd run back to back on one XCD and the second to gy-th read the input from that L2.
+    int bxx = blockIdx.x, byy = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, slot = b >> 3;
+        const int gy = gridDim.y;
+        const int grp = slot / gy;
+        byy = slot - grp * gy;
+        bxx = grp * 8 + xcd;
+    }
+    const int m0 = byy * BM;
+    const int n0 = bxx * BN;
 
     const dp_conv_geom& g = p.g;
     const int W = g.Wo, H = g.Ho, HW = H * W;
@@ -341,8 +354,27 @@ __global__ __launch_bounds__(64 * WR * WC, 4) void wgrad_wino_kernel(const dp_nt
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave - WC * wr;
-    const int m0 = blockIdx.y * BMt, n0 = blockIdx.x * BNt;
-    const int split = blockIdx.z / 3, ky = blockIdx.z - 3 * split;
+    // Workgroup b is dispatched to XCD b % 8 and every XCD has its own L2 (see nt_gemm_fast_kernel): p.xcd gives XCD x a contiguous
+    // run of the split-major order, so the gx * gy * 3 workgroups that stream ONE pixel range share one L2's copy of dy and x.
+    int bx = blockIdx.x, by = blockIdx.y, split, ky;
+    if (p.xcd) {
+        const int gxy = gridDim.x * gridDim.y;
+        const int per_split = gxy * 3;
+        const int nwg = per_split * p.splits;
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7, k8 = b >> 3;
+        const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+        split = __builtin_amdgcn_readfirstlane(v / per_split);
+        const int rem = v - split * per_split;
+        ky = __builtin_amdgcn_readfirstlane(rem / gxy);
+        const int rem2 = rem - ky * gxy;
+        by = __builtin_amdgcn_readfirstlane(rem2 / (int)gridDim.x);
+        bx = rem2 - by * (int)gridDim.x;
+    } else {
+        split = blockIdx.z / 3;
+        ky = blockIdx.z - 3 * split;
+    }
+    const int m0 = by * BMt, n0 = bx * BNt;
 
     const dp_conv_geom& g = p.g;
     const int W = g.Wo, H = g.Ho, HW = H * W;

@@ -615,6 +615,7 @@ def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 32, (3 if bt == 96 else 0), 0
     p.alpha = alpha
     p.ldo = Cin * 9
+    p.xcd = 0 if os.environ.get('DP_NO_XCD') else 1
     if not _lib().dp_wgrad_wino_supported(C.byref(p)):
         return None
     flops = 2.0 * Cout * Cin * 6 * P

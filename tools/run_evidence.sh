@@ -21,8 +21,14 @@ print('$c', round(d['value'],2), d['unit'], round(d['ms_per_step'],2), 'ms/step;
   done
   ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log
   python tools/bench_attention.py 2>&1 | grep -v amdgpu.ids > $O/${R}_attention_fused.txt; cat $O/${R}_attention_fused.txt
-  python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_three_launch.json
-  DP_FUSED_ATTN=1 python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_fused_attn.json ;;
+  DP_FUSED_ATTN=0 python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_three_launch.json
+  python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_fused_attn.json
+  # the Winograd gate (verdict item 5) and the same headline command on the direct kernels only
+  python tools/bench_wino.py 2>&1 | grep -v amdgpu.ids > $O/${R}_winograd_gate.txt; cat $O/${R}_winograd_gate.txt
+  DP_WINO=0 DP_WGRAD_WINO=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_line_direct_kernels.json
+  python -c "
+import json; a=json.load(open('$O/${R}_bench_line.json')); b=json.load(open('$O/${R}_bench_line_direct_kernels.json'))
+print('headline ms/step: winograd', round(a['ms_per_step'],2), 'direct kernels only', round(b['ms_per_step'],2))" ;;
 profiles)
   stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
   DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
