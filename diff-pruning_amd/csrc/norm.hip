@@ -482,6 +482,123 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
     }
 }
 
+// gn_bwd_vec4_kernel with x-hat and dy KEPT IN REGISTERS between the two passes (round 4): groups of up to 8 channels x 1024
+// pixels (every 32 x 32 layer of the CIFAR UNet incl. the 256-channel concat inputs).  A wavefront owns channels wave and wave + 4
+// in BOTH passes, lane l the float4 elements l, l + 64, l + 128, l + 192 of a channel plane -- the assignment and the summation
+// order of gn_bwd_vec4_kernel, so the per-channel sums, the group terms and dx are the same expressions on the same values; what
+// goes away is the second pass's re-read of x and dz (through L2, behind the barrier) and its second evaluation of silu' (two
+// exponentials and a division per element).
+template <int NCH>
+__global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats,
+                                                           const float* __restrict__ dz, long long dz_img_stride, int C,
+                                                           int HW, int G, int silu, float* __restrict__ dx,
+                                                           long long dx_img_stride, const float* __restrict__ add1,
+                                                           long long add1_s, const float* __restrict__ add2, long long add2_s,
+                                                           float* __restrict__ pws, DpDrop drop, float* __restrict__ rows) {
+    __shared__ float s1[GN_MAXCPG], s2[GN_MAXCPG];
+    const int n = blockIdx.x / G;
+    const int g = blockIdx.x - n * G;
+    const int cpg = C / G;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c_base = g * cpg;
+    const int HW4 = HW / 4;
+    const float mean = stats[(long long)blockIdx.x * 2 + 0];
+    const float rstd = stats[(long long)blockIdx.x * 2 + 1];
+    const float* dzb = dz + (long long)n * dz_img_stride;
+    const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
+    float4 xh[NCH][4], dd[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int cl = wave + 4 * k;
+        if (cl < cpg) {
+            const int c = c_base + cl;
+            const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
+            const float4* dp = reinterpret_cast<const float4*>(dzb + (long long)c * HW);
+            const float ga = gamma[c], be = beta[c];
+            float4 xv[4], dv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // all loads of the channel in flight before the first use
+                const int i = lane + 64 * j;
+                if (i < HW4) { xv[j] = xp[i]; dv[j] = dp[i]; }
+            }
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;
+                if (i < HW4) {
+                    float4 h, d = dv[j];
+                    h.x = (xv[j].x - mean) * rstd; h.y = (xv[j].y - mean) * rstd; h.z = (xv[j].z - mean) * rstd; h.w = (xv[j].w - mean) * rstd;
+                    if (drop.thr24) {
+                        const float4 m = dp_drop4(drop, didx0 + 4 * ((long long)cl * HW4 + i));
+                        d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+                    }
+                    if (silu) {
+                        d.x *= dp_silu_grad(h.x * ga + be); d.y *= dp_silu_grad(h.y * ga + be);
+                        d.z *= dp_silu_grad(h.z * ga + be); d.w *= dp_silu_grad(h.w * ga + be);
+                    }
+                    xh[k][j] = h;
+                    dd[k][j] = d;
+                    a1 += (d.x + d.y) + (d.z + d.w);
+                    a2 += (d.x * h.x + d.y * h.y) + (d.z * h.z + d.w * h.w);
+                }
+            }
+            a1 = dp_wave_sum(a1);
+            a2 = dp_wave_sum(a2);
+            if (lane == 0) {
+                s1[cl] = a1;
+                s2[cl] = a2;
+                pws[((long long)n * C + c) * 2 + 0] = a1;
+                pws[((long long)n * C + c) * 2 + 1] = a2;
+            }
+        }
+    }
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+    for (int cl = 0; cl < cpg; ++cl) {
+        const float ga = gamma[c_base + cl];
+        a += ga * s1[cl];
+        b += ga * s2[cl];
+    }
+    const float invM = 1.0f / (float)(cpg * HW);
+    a *= invM;
+    b *= invM;
+    float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
+    const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
+    const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int cl = wave + 4 * k;
+        if (cl < cpg) {
+            const float ga = gamma[c_base + cl];
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = lane + 64 * j;
+                if (i < HW4) {
+                    const int e = cl * HW4 + i;
+                    const float4 t1 = a1b ? a1b[e] : zero4, t2 = a2b ? a2b[e] : zero4;
+                    const float4 d = dd[k][j], h = xh[k][j];
+                    float4 v;
+                    v.x = rstd * (ga * d.x - a - h.x * b) + t1.x + t2.x;
+                    v.y = rstd * (ga * d.y - a - h.y * b) + t1.y + t2.y;
+                    v.z = rstd * (ga * d.z - a - h.z * b) + t1.z + t2.z;
+                    v.w = rstd * (ga * d.w - a - h.w * b) + t1.w + t2.w;
+                    dxb[e] = v;
+                    r += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+            if (rows) {
+                r = dp_wave_sum(r);
+                if (lane == 0) rows[(long long)n * C + c_base + cl] = r;
+            }
+        }
+    }
+}
+
 // Backward, one wavefront per (image, group): HW / 4 is a power of two <= 64, so every wave-wide float4 step covers 64 / HW4
 // whole channels and the per-channel sums are segmented xor-shuffle reductions over HW4 lanes.  x-hat and dy stay in registers
 // between the two phases (the workgroup kernel re-reads them through L2 behind a barrier).  Fixed shuffle order: deterministic.
@@ -590,7 +707,16 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
         DP_LAUNCH(gn_bwd_wave_kernel, dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
                            pws, dd, rows, N * G);
-    else if (vec4)
+    else if (vec4 && HW4 <= 256 && C / G <= 8 && !getenv("DP_NO_GN_CACHE")) {
+        if (C / G <= 4)
+            DP_LAUNCH((gn_bwd_vec4c_kernel<1>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                               dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
+                               pws, dd, rows);
+        else
+            DP_LAUNCH((gn_bwd_vec4c_kernel<2>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
+                               dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
+                               pws, dd, rows);
+    } else if (vec4)
         DP_LAUNCH(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
                            pws, dd, rows);

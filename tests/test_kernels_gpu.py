@@ -221,7 +221,7 @@ def test_bmm_variants(ops, report, Z, M, K, N):
 @pytest.mark.parametrize('N,C1,C2,H,G,silu', [(40, 256, 0, 8, 32, True), (33, 128, 128, 16, 32, False), (64, 512, 0, 4, 32, True),
                                               (2, 32, 0, 8, 8, True), (3, 128, 0, 32, 32, True), (2, 100, 92, 4, 32, True),
                                              (2, 64, 0, 16, 32, False), (1, 128, 0, 128, 32, True), (2, 32, 0, 3, 8, True),
-                                             (2, 48, 80, 64, 16, True), (1, 20, 44, 32, 8, True), (2, 64, 0, 256, 32, False)])
+                                             (2, 48, 80, 64, 16, True), (1, 20, 44, 32, 8, True), (2, 64, 0, 256, 32, False), (2, 128, 128, 32, 32, True)])
 def test_groupnorm(ops, report, N, C1, C2, H, G, silu):
     xa = rnd(N, C1, H, H, seed=1) + 0.3
     xb = rnd(N, C2, H, H, seed=2) if C2 else None
@@ -535,7 +535,7 @@ def test_dropout_masks_bit_exact_vs_philox_oracle(ops, report):
 
 @pytest.mark.parametrize('N,C1,C2,H,G', [(40, 256, 0, 8, 32), (33, 128, 128, 16, 32), (64, 512, 0, 4, 32), (128, 64, 0, 2, 8),
                                          (2, 32, 0, 8, 8), (3, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8),
-                                         (1, 128, 0, 128, 32), (2, 48, 80, 64, 16)], ids=str)
+                                         (1, 128, 0, 128, 32), (2, 48, 80, 64, 16), (2, 128, 128, 32, 32)], ids=str)
 def test_groupnorm_silu_dropout_fused(ops, report, N, C1, C2, H, G):
     """y = dropout(silu(gn(x))) in one kernel and its backward (mask regenerated, nothing stored) against fp64 autograd with
     the oracle's masks: vec4 / scalar / split (few large groups) variants, virtual concat, an image offset (rank shard)."""
@@ -777,7 +777,7 @@ def test_general_conv_forward_relu(ops, report, shape):
 
 
 @pytest.mark.parametrize('N,C1,C2,H,G', [(40, 128, 0, 32, 32), (2, 100, 92, 4, 32), (2, 32, 0, 3, 8), (4, 256, 0, 16, 32), (3, 128, 0, 32, 32),
-                                         (40, 256, 0, 8, 32), (33, 128, 128, 16, 32), (64, 512, 0, 4, 32)], ids=str)
+                                         (40, 256, 0, 8, 32), (33, 128, 128, 16, 32), (64, 512, 0, 4, 32), (2, 128, 128, 32, 32)], ids=str)
 def test_groupnorm_bwd_row_sums(ops, report, N, C1, C2, H, G):
     """The GroupNorm backward kernels also emit rows[n, c] = sum_hw dx (the next layer's bias / time-embedding-projection
     gradient rows): equal to a separate row-sum pass over dx up to summation order, and dx itself is unchanged."""
