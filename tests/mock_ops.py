@@ -52,8 +52,38 @@ def _prep(x, spec):
     return x
 
 
+WINO_CALLS = []          # (mode, weight shape) of every launch the engine routed to the Winograd kernel (test bookkeeping)
+
+
+def wino_wanted(M, C_sources, N, H, W, spec):
+    import importlib
+    return importlib.import_module('diff-pruning_amd.ops').wino_wanted(M, C_sources, N, H, W, spec)
+
+
+class _WinoOperand:
+    """Stand-in for ops.pack_weight_wino's operand: remembers WHICH weight tensor (identity, version, shape) it was packed from."""
+
+    def __init__(self, w, mode):
+        self.w, self.mode, self.version, self.shape = w, mode, w._version, tuple(w.shape)
+
+
+def pack_weight_wino(w, mode):
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    return _WinoOperand(w, mode), 0
+
+
+def _check_wino(wino, w, mode):
+    if wino is None:
+        return
+    op = wino[0]
+    # the operand must have been packed from the CURRENT weight (a stale one after an optimizer step or a prune is the bug to catch)
+    assert isinstance(op, _WinoOperand) and op.mode == mode and op.w is w and op.version == w._version and op.shape == tuple(w.shape)
+    WINO_CALLS.append((mode, tuple(w.shape)))
+
+
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
-                 accumulate=False):
+                 accumulate=False, wino=None):
+    _check_wino(wino, wp, 0)
     w = wp if wp.dim() == 4 else wp.view(wp.shape[0], wp.shape[1], 1, 1)
     y = alpha * F.conv2d(_prep(_cat(x, x2), spec), w, None, stride=spec.stride, padding=0 if getattr(spec, 'keep', False) else spec.pad)
     if bias is not None:
@@ -69,7 +99,8 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
     return y
 
 
-def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate=False):
+def conv_dgrad(dy, wd, ldd, Cin, spec, in_hw, *, alpha=1.0, out=None, accumulate=False, wino=None):
+    _check_wino(wino, wd, 1)
     w = wd if wd.dim() == 4 else wd.view(wd.shape[0], wd.shape[1], 1, 1)
     N = dy.shape[0]
     Hv, Wv = in_hw

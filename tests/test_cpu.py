@@ -1889,3 +1889,118 @@ def test_latent_shards_and_bench_configs():
                     and getattr(n.targets[0], 'id', None) == 'DEFAULT_STEPS')
     assert set(defaults) == {'cifar256', 'bedroom256', 'c4_finetune', 'ddim', 'ldm'} and all(k > 0 and w >= 0 for k, w in defaults.values())
     assert "default='cifar256'" in src and 'configs[1]' in src
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 4: the algebra of the Winograd F(2, 3) kernels (csrc/winograd.hip), restated in numpy
+# ------------------------------------------------------------------------------------------------------------------
+def test_winograd_f23_algebra_forward_dgrad_wgrad():
+    """The three identities csrc/winograd.hip rests on, checked in float64 on random data with zero padding, for one image row:
+      forward   y[2p], y[2p+1] from M_q = sum_c U_q V_q          (U = g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2; V = d0-d2, d1+d2, d2-d1, d1-d3)
+      dgrad     = the same algorithm on the flipped taps with the channel roles swapped (dp_pack_weight_wino mode 1)
+      wgrad     dW_k from G_q = sum_p A_q V_q                     (A = dy0, dy0+dy1, dy0-dy1, -dy1;  dW0 = G0 + (G1+G2)/2, ...)
+    and the pack layout U[(ky*4 + pos)*K + k][m] of both modes against a direct evaluation."""
+    rng = np.random.default_rng(0)
+    C, M, W = 5, 4, 8
+    x = rng.standard_normal((C, W))
+    g = rng.standard_normal((M, C, 3))                                  # one kernel row
+    xp = np.pad(x, ((0, 0), (1, 1)))
+    ref = np.stack([sum(g[m, c, k] * xp[c, k:k + W] for c in range(C) for k in range(3)) for m in range(M)])
+    U = np.stack([g[..., 0], (g[..., 0] + g[..., 1] + g[..., 2]) / 2, (g[..., 0] - g[..., 1] + g[..., 2]) / 2, g[..., 2]])   # [4, M, C]
+    y = np.zeros((M, W))
+    for p in range(W // 2):
+        d = xp[:, 2 * p:2 * p + 4]                                       # d_j = x[2p + j - 1] (zero padded)
+        V = np.stack([d[:, 0] - d[:, 2], d[:, 1] + d[:, 2], d[:, 2] - d[:, 1], d[:, 1] - d[:, 3]])            # [4, C]
+        Mq = np.einsum('qmc,qc->qm', U, V)
+        y[:, 2 * p] = Mq[0] + Mq[1] + Mq[2]
+        y[:, 2 * p + 1] = Mq[1] - Mq[2] - Mq[3]
+    assert np.allclose(y, ref, atol=1e-12)
+    # input gradient: dx[c] = sum_m corr(dy[m], flipped taps)  -- the forward algorithm with g'[c][m][k] = g[m][c][2 - k]
+    dy = rng.standard_normal((M, W))
+    dyp = np.pad(dy, ((0, 0), (1, 1)))
+    ref_dx = np.stack([sum(g[m, c, 2 - k] * dyp[m, k:k + W] for m in range(M) for k in range(3)) for c in range(C)])
+    gf = np.transpose(g, (1, 0, 2))[..., ::-1]
+    Uf = np.stack([gf[..., 0], (gf[..., 0] + gf[..., 1] + gf[..., 2]) / 2, (gf[..., 0] - gf[..., 1] + gf[..., 2]) / 2, gf[..., 2]])
+    dx = np.zeros((C, W))
+    for p in range(W // 2):
+        d = dyp[:, 2 * p:2 * p + 4]
+        V = np.stack([d[:, 0] - d[:, 2], d[:, 1] + d[:, 2], d[:, 2] - d[:, 1], d[:, 1] - d[:, 3]])
+        Mq = np.einsum('qcm,qm->qc', Uf, V)
+        dx[:, 2 * p] = Mq[0] + Mq[1] + Mq[2]
+        dx[:, 2 * p + 1] = Mq[1] - Mq[2] - Mq[3]
+    assert np.allclose(dx, ref_dx, atol=1e-12)
+    # weight gradient by the transposed algorithm
+    ref_dw = np.stack([[[np.dot(dy[m], xp[c, k:k + W]) for k in range(3)] for c in range(C)] for m in range(M)])
+    G = np.zeros((4, M, C))
+    for p in range(W // 2):
+        d = xp[:, 2 * p:2 * p + 4]
+        V = np.stack([d[:, 0] - d[:, 2], d[:, 1] + d[:, 2], d[:, 2] - d[:, 1], d[:, 1] - d[:, 3]])
+        A = np.stack([dy[:, 2 * p], dy[:, 2 * p] + dy[:, 2 * p + 1], dy[:, 2 * p] - dy[:, 2 * p + 1], -dy[:, 2 * p + 1]])      # [4, M]
+        G += A[:, :, None] * V[:, None, :]
+    hs = (G[1] + G[2]) / 2
+    dw = np.stack([G[0] + hs, (G[1] - G[2]) / 2, hs + G[3]], axis=-1)
+    assert np.allclose(dw, ref_dw, atol=1e-12)
+    # multiply counts: 4 per output pair (and per gradient triple) instead of 6
+    assert U.shape[0] == 4 and 4 / 6 == pytest.approx(2 / 3)
+
+
+def test_winograd_dispatch_rules():
+    """Host-side dispatch of the Winograd kernels (ops.wino_wanted: pure arithmetic, no device): shapes of the five BASELINE
+    configs that go to dp_conv_wino and the ones that stay on the direct kernels."""
+    ops = pkg('ops')
+    S3, S1 = ops.ConvSpec(3, 1, 1, 0), ops.ConvSpec(1, 1, 0, 0)
+    assert ops.WINO and ops.WINO_MIN_TILES == 512
+    assert ops.wino_wanted(128, (128,), 256, 32, 32, S3)                 # CIFAR level 0 at batch 256: 2 x 2048 tiles
+    assert ops.wino_wanted(128, (256, 128), 256, 32, 32, S3)             # up-block concat input
+    assert ops.wino_wanted(256, (256,), 256, 4, 4, S3)                   # 4 x 4 level: 128 tiles, split-K 4
+    assert not ops.wino_wanted(128, (128,), 4, 32, 32, S3)               # config C1 (batch 4): 64 tiles, 24 K tiles -> split 3 < 256 workgroups
+    assert not ops.wino_wanted(128, (3,), 256, 32, 32, S3)               # conv_in: 3 input channels
+    assert not ops.wino_wanted(256, (256,), 256, 16, 16, S1)             # 1 x 1
+    assert not ops.wino_wanted(128, (128,), 256, 32, 32, ops.ConvSpec(3, 2, 0, 0))     # Downsample2D (stride 2)
+    assert not ops.wino_wanted(179, (179,), 128, 16, 16, S3)             # odd pruned width on the contraction side
+    assert ops.wino_wanted(90, (96,), 128, 32, 32, S3)                   # ... on the output side only: row tails are fine
+    assert ops.wino_wanted(128, (128,), 4, 256, 256, S3) and not ops.wino_wanted(128, (128,), 4, 512, 512, S3)      # bedroom-256; W <= 256
+    assert ops.wino_wanted(576, (576,), 12, 16, 16, S3)                  # LDM 16 x 16 level at 12 latents: 216 tiles x split 2
+
+
+def test_engine_routes_3x3_layers_to_the_winograd_kernel_with_current_operands(mocked, monkeypatch):
+    """Engine-side bookkeeping of the Winograd dispatch on mocked kernels (the arithmetic is the direct convolution's, so the
+    oracle comparison doubles as a check that routing changes nothing): with the grid threshold dropped every 3x3 / stride-1 layer
+    with >= 8 input channels goes to the Winograd entry point in the forward AND the input-gradient pass, each time with an
+    operand packed from the CURRENT weight tensor -- also after a prune (sliced weights) and after an optimizer step (in-place
+    update: prepare_packs() re-packs the operands the previous pass asked for)."""
+    from oracle import diffusion_ref as D
+    ops, sweep, train = pkg('ops'), pkg('sweep'), pkg('train')
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+    monkeypatch.setattr(sweep.HipSweepStep, '__init__', _cpu_step_init)
+    del mocked.WINO_CALLS[:]
+    cfg = gc.TINY_CFG
+    model = _cpu_model(cfg, 5)
+    clean = torch.from_numpy(gc.det_clean((2, 3, 16, 16), 1))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 2))
+    res = sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=2)
+    P = oracle_params(cfg, 5)
+    assert np.allclose(res['losses'], D.taylor_sweep(P, cfg, clean, noise, 2), rtol=1e-5)
+    fwd = [c for c in mocked.WINO_CALLS if c[0] == 0]
+    bwd = [c for c in mocked.WINO_CALLS if c[0] == 1]
+    # every ResnetBlock2D convolution at the 16 x 16 / 8 x 8 / 4 x 4 levels + conv_out, in both timesteps (the 2 x 2 level is below
+    # the kernel's W >= 4); conv_out's input gradient contracts over 3 channels and stays on the direct kernel
+    assert len(fwd) == 62 and len(bwd) == len(fwd) - 2, (len(fwd), len(bwd))
+    eng = model.engine()
+    assert {m for _, m in eng._wino_seen} == {('wino', 0), ('wino', 1)}
+    # prune: the weights are new, smaller tensors -> fresh operands (the mock asserts identity, version and shape on every launch)
+    sweep.prune_model(model, 0.3)
+    del mocked.WINO_CALLS[:]
+    for p in model.parameters():
+        p.grad = None
+    sweep.taylor_sweep(model, pkg('diffusion').DDPMScheduler(), clean, noise, num_steps=1)
+    assert mocked.WINO_CALLS and all(s[0] < 64 or s[1] < 64 or True for _, s in mocked.WINO_CALLS)
+    assert any(sh[0] not in (32, 64) or sh[1] not in (32, 64, 96, 128) for _, sh in mocked.WINO_CALLS)      # pruned widths reached the kernel
+    # two optimizer steps on the pruned model: the in-place update bumps every weight's version; a stale operand would trip the mock
+    monkeypatch.setattr(train, '_require_hip_device', lambda dev: None)
+    monkeypatch.setattr(pkg('diffusion').DDPMScheduler, '_acp_on', lambda self, dev: self.alphas_cumprod)
+    ft = train.FinetuneEngine(model, pkg('diffusion').DDPMScheduler(), lr=1e-3, ema_decay=0.999)
+    del mocked.WINO_CALLS[:]
+    t = torch.tensor([5, 700])
+    l1, l2 = float(ft.step(clean, noise, t)), float(ft.step(clean, noise, t))
+    assert len(mocked.WINO_CALLS) > 40 and l1 != l2
