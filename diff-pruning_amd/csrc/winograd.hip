@@ -34,9 +34,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dpw_rsrc(const float* base, un
 // 256-thread workgroups, every wave 32 rows x 32 pairs x 4 positions.  WR = 2: waves 2 x 2, 64 output channels x 64 pairs (128
 // pixels); WR = 1: waves 1 x 4, 32 output channels x 128 pairs (256 pixels) -- for row counts such as 96 or 288 (pruned widths),
 // which fill 64-row tiles to 75 / 90 %.
-template <int BK, int WR>
-__global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const dp_conv_gemm_params p) {
-    constexpr int BM = 32 * WR, BP = 32 * (4 / WR), BN = 2 * BP;
+// TM = 2 (with WR = 2, BK = 8): every wave 64 rows x 32 pairs -- 128-row workgroup tiles, ONE transformed B fragment feeds two row
+// tiles (half the LDS reads and transform VALU per MFMA, half the B traffic per row), 128 accumulator registers (occupancy 3).
+template <int BK, int WR, int TM = 1>
+__global__ __launch_bounds__(256, (BK == 16 || TM == 2) ? 3 : 4) void conv_wino_kernel(const dp_conv_gemm_params p) {
+    constexpr int BM = 32 * WR * TM, BP = 32 * (4 / WR), BN = 2 * BP;
     constexpr int G4 = BN / 4, RPW = 64 / G4;          // lanes per pixel row of the B tile, rows per wave instruction (2 / 1)
     constexpr int A_SZ = 4 * BK * BM;                  // [pos][k][m]
     constexpr int B_SZ = BK * BN;                      // [k][pixel]
@@ -143,15 +145,17 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
         if (++ky == 3) { ky = 0; ++ch; }
     };
 
-    f32x16 acc[4];
+    f32x16 acc[TM][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
 
-    // ---- fragment addressing: lane = (k half, column); A row wr*32 + li of position q, B pair wc*32 + li
+    // ---- fragment addressing: lane = (k half, column); A row wr*32*TM + 32 t + li of position q, B pair wc*32 + li
     const int li = lane & 31, lk = lane >> 5;
-    const float* fragA = smem + lk * BM + wr * 32 + li;                      // + (q*BK + 2*ks)*BM
+    const float* fragA = smem + lk * BM + wr * (32 * TM) + li;               // + (q*BK + 2*ks)*BM + 32 t
     const float* fragB = smem + A_SZ + lk * BN + 2 * (wc * 32 + li);         // + 2*ks*BN; d1 d2 at [0..1], d0 at [-1], d3 at [2]
     // left / right zero padding: pixel 2p - 1 (2p + 2) lies outside the image row
     const int px = n0 + 2 * (wc * 32 + li);
@@ -168,10 +172,12 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
         if (it + 1 < nIter) advance();
         const float* Af = fragA + buf * STAGE;
         const float* Bf = fragB + buf * STAGE;
-        float a[2][4], d[2][4];
-        auto frag = [&](int ks, float (&fa)[4], float (&fd)[4]) {
+        float a[2][TM * 4], d[2][4];
+        auto frag = [&](int ks, float (&fa)[TM * 4], float (&fd)[4]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fa[q] = Af[(q * BK + 2 * ks) * BM];
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[4 * t + q] = Af[(q * BK + 2 * ks) * BM + 32 * t];
             // plain float reads (hipcc pairs them into one ds_read2_b32): a float2-typed LDS access makes the waitcnt pass
             // treat the read as aliasing the LDS-DMA writes and drain vmcnt(0) right behind the prefetch
             fd[1] = Bf[2 * ks * BN];
@@ -198,10 +204,11 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
 #ifdef DPW_NO_VPIPE
             xform(d[cur], v[cur]);
 #endif
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], v[cur][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], v[cur][1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], v[cur][2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], v[cur][3], acc[3], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][4 * t + q], v[cur][q], acc[t][q], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef DPW_NO_VPIPE
             if (ks + 1 < BK / 2) { xform(d[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
@@ -216,13 +223,16 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     if (px >= p.NPIX) return;
     if (ksplit) {
         float* wsb = p.ws + (long long)blockIdx.z * p.M * p.NPIX + px;
-        const int mbs = m0 + wr * 32 + 4 * (lane >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbs + (r & 3) + 8 * (r >> 2);
-            if (m >= p.M) continue;
-            *reinterpret_cast<float2*>(wsb + (long long)m * p.NPIX) =
-                make_float2((acc[0][r] + acc[1][r]) + acc[2][r], (acc[1][r] - acc[2][r]) - acc[3][r]);
+        for (int t = 0; t < TM; ++t) {
+            const int mbs = m0 + wr * (32 * TM) + 32 * t + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbs + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                *reinterpret_cast<float2*>(wsb + (long long)m * p.NPIX) =
+                    make_float2((acc[t][0][r] + acc[t][1][r]) + acc[t][2][r], (acc[t][1][r] - acc[t][2][r]) - acc[t][3][r]);
+            }
         }
         return;
     }
@@ -230,13 +240,14 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 4) void conv_wino_kernel(const 
     float* optr = p.out + (long long)img * p.o_img_stride + r_in;
     const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
     const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
-    const int mb = m0 + wr * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const int m = m0 + wr * (32 * TM) + 32 * t + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
         if (m >= p.M) continue;
-        float y0 = p.alpha * ((acc[0][r] + acc[1][r]) + acc[2][r]);
-        float y1 = p.alpha * ((acc[1][r] - acc[2][r]) - acc[3][r]);
+        float y0 = p.alpha * ((acc[t][0][r] + acc[t][1][r]) + acc[t][2][r]);
+        float y1 = p.alpha * ((acc[t][1][r] - acc[t][2][r]) - acc[t][3][r]);
         if (p.bias) { const float b = p.bias[m]; y0 += b; y1 += b; }
         if (tptr) { const float t = tptr[m]; y0 += t; y1 += t; }
         if (rptr) { const float2 t = *reinterpret_cast<const float2*>(rptr + (long long)m * HW); y0 += t.x; y1 += t.y; }
@@ -283,9 +294,16 @@ extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
         if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 1>), grid, dim3(256), 0, st, p);
         else          DP_LAUNCH((conv_wino_kernel<8, 1>), grid, dim3(256), 0, st, p);
     } else {
-        dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : 1);
-        if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
-        else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
+        static const char* ftm = getenv("DP_WINO_TM");
+        const int tm_want = ftm ? atoi(ftm) : 1;
+        if (tm_want == 2 && p.M % 128 == 0) {
+            dim3 grid((p.NPIX + 127) / 128, p.M / 128, p.ksplit > 1 ? p.ksplit : 1);
+            DP_LAUNCH((conv_wino_kernel<8, 2, 2>), grid, dim3(256), 0, st, p);
+        } else {
+            dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : 1);
+            if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
+            else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
+        }
     }
     const int e = DP_LAUNCH_CHECK();
     if (e || p.ksplit <= 1) return e;
