@@ -392,7 +392,7 @@ def _conv_wino(p, wino, act_bytes):
         p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
         return False
     wr = 1 if (p.g.Wo > 128 or -(-p.M // 32) * 32 < -(-p.M // 64) * 64) else 2          # the launcher's tile rule (csrc/winograd.hip)
-    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino_kernel<%d, %d>' % (bk, wr), 2.0 * p.M * p.NPIX * p.C * 6,
+    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino_kernel<%d, %d, 1>' % (bk, wr), 2.0 * p.M * p.NPIX * p.C * 6,
                  act_bytes + 4.0 * U.numel()), 'dp_conv_wino')
     return True
 
