@@ -1399,6 +1399,8 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
     EVERY supported layer of the fixture models takes the Winograd kernel, forward and input gradient, and the reference's recorded
     outputs / gradients / prune masks must still come out: masks bit-exact, tensors within the tolerances of the original tests."""
     ops = pkg('ops')
+    monkeypatch.setattr(ops, 'WINO', True)                          # (also under DP_WINO=0 / DP_WGRAD_WINO=0 in the environment)
+    monkeypatch.setattr(ops, 'WGRAD_WINO', True)
     monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)              # ... and every supported weight gradient its Winograd kernel
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
