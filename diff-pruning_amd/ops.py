@@ -344,7 +344,7 @@ def wino_wanted(M, C_sources, N, H, W, spec):
         return False
     if W < 4 or W > 256 or (W & (W - 1)) or ((H * W) & 1):
         return False
-    if any(c % 8 for c in C_sources):
+    if any(c % 8 for c in C_sources) or M < 16:          # conv_out (3 output rows) is an HBM-bound stencil: conv_few_out_kernel
         return False
     tiles = -(-M // 64) * -(-(N * H * W) // 128)
     if tiles >= WINO_MIN_TILES:

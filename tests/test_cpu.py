@@ -1959,6 +1959,7 @@ def test_winograd_dispatch_rules():
     assert not ops.wino_wanted(128, (128,), 256, 32, 32, ops.ConvSpec(3, 2, 0, 0))     # Downsample2D (stride 2)
     assert not ops.wino_wanted(179, (179,), 128, 16, 16, S3)             # odd pruned width on the contraction side
     assert ops.wino_wanted(90, (96,), 128, 32, 32, S3)                   # ... on the output side only: row tails are fine
+    assert not ops.wino_wanted(3, (128,), 256, 32, 32, S3)               # conv_out: 3 output rows -> the stencil kernel
     assert ops.wino_wanted(128, (128,), 4, 256, 256, S3) and not ops.wino_wanted(128, (128,), 4, 512, 512, S3)      # bedroom-256; W <= 256
     assert ops.wino_wanted(576, (576,), 12, 16, 16, S3)                  # LDM 16 x 16 level at 12 latents: 216 tiles x split 2
 
@@ -1983,9 +1984,9 @@ def test_engine_routes_3x3_layers_to_the_winograd_kernel_with_current_operands(m
     assert np.allclose(res['losses'], D.taylor_sweep(P, cfg, clean, noise, 2), rtol=1e-5)
     fwd = [c for c in mocked.WINO_CALLS if c[0] == 0]
     bwd = [c for c in mocked.WINO_CALLS if c[0] == 1]
-    # every ResnetBlock2D convolution at the 16 x 16 / 8 x 8 / 4 x 4 levels + conv_out, in both timesteps (the 2 x 2 level is below
-    # the kernel's W >= 4); conv_out's input gradient contracts over 3 channels and stays on the direct kernel
-    assert len(fwd) == 62 and len(bwd) == len(fwd) - 2, (len(fwd), len(bwd))
+    # every ResnetBlock2D convolution at the 16 x 16 / 8 x 8 / 4 x 4 levels, in both timesteps (the 2 x 2 level is below the kernel's
+    # W >= 4; conv_in has 3 input channels, conv_out 3 output rows: direct / stencil kernels)
+    assert len(fwd) == 60 and len(bwd) == len(fwd), (len(fwd), len(bwd))
     eng = model.engine()
     assert {m for _, m in eng._wino_seen} == {('wino', 0), ('wino', 1)}
     # prune: the weights are new, smaller tensors -> fresh operands (the mock asserts identity, version and shape on every launch)
