@@ -60,29 +60,48 @@ def pkg(sub):
 
 
 def cpu_baseline(config, steps=8):
-    """Oracle sweep (plain PyTorch fp32 on the host cores), SURVEY.md §8(d).  cifar256: 1 warm-up + 8 timed timesteps at B=4
-    (config C1's batch) and at B=16, `value` the better; bedroom256: 1 warm-up + 2 timed timesteps of one 256x256 image."""
+    """Oracle sweep (plain PyTorch fp32 on the host cores), SURVEY.md §8(d) -- the host's BEST, not its default: a 32x32 UNet at
+    batch 16 is oversubscribed on all 128+ threads of the GPU box (round 4 read 2.7-5.7 images/s there against the 13.5 the survey
+    measured on 8 threads), so the thread count is swept.  cifar256: B=16 at {8, 16, 32, 64, all} threads (1 warm-up + 2 timed
+    timesteps each), then B=64 at the best thread count (1 warm-up + 1 timed); `value` = the best rate, `cores` = the threads it
+    used, `host_cores` = what the box has.  bedroom256: one 256x256 image, {16, all} threads, 1 warm-up + 1 timed timestep."""
     from oracle import unet_ref, diffusion_ref
+    host = os.cpu_count() or torch.get_num_threads()
+    default_threads = torch.get_num_threads()
     if config == 'cifar256':
-        cfg, hw, batches = gc.CIFAR_CFG, 32, (4, 16)
+        cfg, hw = gc.CIFAR_CFG, 32
+        plan = [(16, n, 2) for n in sorted({n for n in (8, 16, 32, 64, default_threads) if n <= max(host, default_threads)})]
     elif config == 'bedroom256':
-        cfg, hw, batches, steps = gc.BEDROOM_CFG, 256, (1,), 2
+        cfg, hw = gc.BEDROOM_CFG, 256
+        plan = [(1, n, 1) for n in sorted({min(16, default_threads), default_threads})]
     else:
         return None
     shapes = unet_ref.param_shapes(cfg)
     P = {n: torch.from_numpy(gc.det_param(n, s, 0)).requires_grad_(True) for n, s in shapes.items()}
     rates = {}
-    for B in batches:
+
+    def timed(B, threads, k):
+        torch.set_num_threads(threads)
         clean = torch.from_numpy(gc.det_clean((B, 3, hw, hw), 1))
         noise = torch.from_numpy(gc.det_noise((B, 3, hw, hw), 2))
         marks = []
-        diffusion_ref.taylor_sweep(P, cfg, clean, noise, steps + 1, on_step=lambda k, l: marks.append(time.perf_counter()))
-        rates[B] = B * steps / (marks[-1] - marks[0])
+        diffusion_ref.taylor_sweep(P, cfg, clean, noise, k + 1, on_step=lambda i, l: marks.append(time.perf_counter()))
+        rates[(B, threads)] = B * k / (marks[-1] - marks[0])
+
+    try:
+        for B, threads, k in plan:
+            timed(B, threads, k)
+        if config == 'cifar256':
+            timed(64, max(rates, key=rates.get)[1], 1)
+    finally:
+        torch.set_num_threads(default_threads)
     best = max(rates, key=rates.get)
-    return dict(value=rates[best], unit='images/s', cores=torch.get_num_threads(), kind='port',
-                by_batch={'B=%d' % b: r for b, r in rates.items()},
-                sample='oracle sweep, %dx%d UNet, 1 warm-up + %d timed timesteps (fwd+bwd) at B in %s (value = B=%d), fp32 '
-                       'PyTorch CPU' % (hw, hw, steps, list(batches), best))
+    return dict(value=rates[best], unit='images/s', cores=best[1], host_cores=host, kind='port',
+                by_batch_and_threads={'B=%d,threads=%d' % k: r for k, r in rates.items()},
+                sample='oracle sweep, %dx%d UNet, fwd+bwd timesteps after 1 warm-up each, fp32 PyTorch CPU: %s; value = the best '
+                       '(B=%d on %d threads)' % (hw, hw, ', '.join('B=%d x %d timed @ %d threads' % (b, k, n) for b, n, k in plan)
+                                                 + (', then B=64 x 1 at the best thread count' if config == 'cifar256' else ''),
+                                                 best[0], best[1]))
 
 
 def _self_launch(args):
@@ -398,7 +417,46 @@ class LdmWorkload:
         return one
 
 
-def roofline(ops, one_step, step_seconds, flop_reference_per_step):
+def kernel_switches(ops):
+    """Which kernel families the measured process had active (module-level switches of ops.py / engine.py, i.e. the DP_*
+    environment as it was read at import) and every DP_* variable set in the environment: a stray DP_WINO=0 must show on the line."""
+    eng, sweep = pkg('engine'), pkg('sweep')
+    return {'wino': bool(ops.WINO), 'wgrad_wino': bool(ops.WINO and ops.WGRAD_WINO), 'wino_min_tiles': ops.WINO_MIN_TILES,
+            'splitk_fold': bool(ops.SPLITK_FOLD), 'splitk_fold_max': ops.SPLITK_FOLD_MAX,
+            'wgrad_splitk_fold': bool(getattr(ops, 'WGRAD_FOLD', False)),
+            'fused_attn': ops.FUSED_ATTN, 'ups_subpixel': bool(eng.UPS_SUBPIXEL), 's2_parity': bool(eng.S2_PARITY),
+            'timestep_pipelines_default': sweep.TIMESTEP_PIPELINES,
+            'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('DP_')}}
+
+
+def _pmc_traffic(config_name, dom):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
+    THIS config's bench command, aggregated by tools/pmc_aggregate.py; KB -> bytes; they cannot run inside this process).  Read from
+    the newest profiles/round*_pmc_bench_traffic[_<config>].json whose `_config` equals the config being timed and whose recorded
+    hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip) equals today's; anything else = null.
+    FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on gfx950 (MI355X_MICROARCH.md, HBM section)."""
+    import glob
+    import hashlib
+    try:
+        sfx = '' if config_name == 'cifar256' else '_' + config_name
+        cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))
+        if not cand:
+            return None, dict(file=None, reason='no PMC pass of config %r under profiles/' % config_name)
+        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
+        blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()          # the contraction kernels' sources, concatenated
+        pm = json.load(open(cand[-1]))
+        measured_on, measured_cfg = pm.get('_gemm_hip_blob'), pm.get('_config', 'cifar256')
+        src_info = dict(file=os.path.relpath(cand[-1], ROOT), measured_on_gemm_hip_blob=measured_on, current_gemm_hip_blob=blob,
+                        stale=measured_on != blob, config=measured_cfg)
+        k = pm.get(dom)
+        if k and measured_on == blob and measured_cfg == config_name:
+            return (k['FETCH_SIZE']['avg_kb'] + k['WRITE_SIZE']['avg_kb']) * 1024.0, src_info
+        return None, src_info
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
+def roofline(ops, one_step, step_seconds, flop_reference_per_step, config_name='cifar256'):
     """HIP events around every contraction launch of one instrumented step (after one un-instrumented pass of the same step)."""
     one_step(0)
     torch.cuda.synchronize()
@@ -415,27 +473,7 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step):
         a[3] += ab
     dom = max(agg, key=lambda n: agg[n][2])
     cnt, fl, sec, ab = agg[dom]
-    # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
-    # this same command, aggregated by tools/pmc_aggregate.py; KB -> bytes) that cannot run inside this process: they are read
-    # from the newest profiles/round*_pmc_bench_traffic.json, which records a hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip) it was measured on.
-    # A different blob today = stale counters = traffic null.  FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on
-    # gfx950 (MI355X_MICROARCH.md, HBM section).
-    traffic, traffic_src = None, None
-    try:
-        import glob
-        import hashlib
-        cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic.json')))
-        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
-        blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()          # the contraction kernels' sources, concatenated
-        pm = json.load(open(cand[-1]))
-        measured_on = pm.get('_gemm_hip_blob')
-        traffic_src = dict(file=os.path.relpath(cand[-1], ROOT), measured_on_gemm_hip_blob=measured_on,
-                           current_gemm_hip_blob=blob, stale=measured_on != blob, config=pm.get('_config', 'cifar256'))
-        k = pm.get(dom)
-        if k and measured_on == blob:
-            traffic = (k['FETCH_SIZE']['avg_kb'] + k['WRITE_SIZE']['avg_kb']) * 1024.0
-    except (OSError, KeyError, ValueError, IndexError):
-        traffic = None
+    traffic, traffic_src = _pmc_traffic(config_name, dom)
     executed = sum(v[1] for v in agg.values())
     # The Winograd F(2, 3) kernels execute 2/3 of the multiply-adds of the convolution they compute (6 instead of 9 per output,
     # channel pair and pixel): `achieved` / `frac` are EXECUTED FLOPs over time (the number to hold against the matrix pipe);
@@ -450,11 +488,12 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step):
                 # Whole-step rates.  `executed`: the multiply-adds the kernels of one step actually perform (sum over the
                 # instrumented launches) -- the number to hold against the MFMA peak.  `reference_equivalent`: SURVEY 8(d)'s count
                 # of the reference's own arithmetic over the same time; it exceeds the executed count because the upsample
-                # convolutions run in their sub-pixel form and stride-2 input gradients by parity classes -- a rate of useful
-                # work, not of hardware utilisation.
+                # convolutions run in their sub-pixel form, stride-2 input gradients by parity classes and the 3x3 layers as
+                # Winograd F(2, 3) -- a rate of useful work, not of hardware utilisation (it may exceed 1.0 of the peak).
                 executed_flop_per_step=executed, step_tflops=executed / step_seconds / 1e12,
                 step_frac=executed / step_seconds / 1e12 / PEAK_F32_TFLOPS,
-                step_tflops_reference_equivalent=flop_reference_per_step / step_seconds / 1e12)
+                step_tflops_reference_equivalent=flop_reference_per_step / step_seconds / 1e12,
+                step_frac_reference_arithmetic=flop_reference_per_step / step_seconds / 1e12 / PEAK_F32_TFLOPS)
 
 
 DEFAULT_STEPS = {'cifar256': (20, 2), 'bedroom256': (20, 2), 'c4_finetune': (20, 3), 'ddim': (40, 5), 'ldm': (4, 1)}
@@ -528,7 +567,7 @@ def main():
         # per-rank work of one step against this rank's kernels (weak scaling: 1/world of the units; ldm: this rank's latents)
         per_rank_units = units_per_step / world if wl.scaling == 'weak' else r['extra'].get('latents_this_rank', units_per_step)
         one_step = wl.instrumented()
-        roof = roofline(ops, one_step, step_seconds, wl.flop_unit * per_rank_units) if one_step is not None else None
+        roof = roofline(ops, one_step, step_seconds, wl.flop_unit * per_rank_units, args.config) if one_step is not None else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.config)
@@ -538,6 +577,7 @@ def main():
         cfg.update(wl.config())
         cfg.update(r['extra'])
         cfg['steps_executed'] = steps_done
+        cfg['kernels'] = kernel_switches(ops)
         out = {'metric': wl.metric, 'value': r['units'] / t_total, 'unit': wl.unit, 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': step_seconds * 1e3, 'higher_is_better': True, 'scaling': wl.scaling,
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': cfg, 'roofline': roof, 'cpu_baseline': cpu}

@@ -269,6 +269,9 @@ static int wino_bk(const dp_conv_gemm_params& p) {
     const int W = g.Wo;
     if (W < 4 || W > 256 || (W & (W - 1))) return 0;        // W must divide the pixel tile (128, or 256 with the 32-row tiles)
     if ((p.lda & 3) || ((g.Ho * g.Wo) & 1)) return 0;
+    // the X descriptors start one image row in front of the tensor (num_records = extent + 4 W): the out-of-range marker 0x80000000
+    // must stay outside them, i.e. an activation within 4 W bytes of 2 GiB keeps the direct kernel  [advisor, round 4]
+    if ((unsigned long long)p.x1_bytes + 4ull * W >= 0x80000000ull || (p.X2 && (unsigned long long)p.x2_bytes + 4ull * W >= 0x80000000ull)) return 0;
     const int C1 = p.X2 ? g.c_split : p.C;
     if (p.C % 16 == 0 && C1 % 16 == 0) return 16;
     if (p.C % 8 == 0 && C1 % 8 == 0) return 8;
@@ -567,6 +570,8 @@ static bool wgrad_wino_ok(const dp_nt_gemm_params& p) {
     const int W = g.Wo, HW = g.Ho * g.Wo;
     if (W < 8 || W > 256 || (W & (W - 1)) || (HW & (HW - 1)) || HW < 64) return false;
     if ((p.P % 32) || (p.p_per_split % 32) || p.p_per_split <= 0) return false;
+    // same rule as wino_bk: the input descriptor is one image row longer than the tensor and must not reach the 0x80000000 marker
+    if ((unsigned long long)p.x1_bytes + 4ull * W >= 0x80000000ull || (p.X2 && (unsigned long long)p.x2_bytes + 4ull * W >= 0x80000000ull)) return false;
     const int bn = p.tile == 3 ? 96 : 64;
     if (p.X2 && (g.c_split % bn)) return false;
     return true;

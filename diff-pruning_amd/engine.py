@@ -296,7 +296,13 @@ class UNetEngine:
         must not be recorded into the replayed graph; and once per finetune step, whose optimizer update invalidates every
         pack): all of them in a few batched launches (ops.pack_weight_batch)."""
         todo = []
-        seen = getattr(self, '_wino_seen', ())         # Winograd operands the previous passes asked for (decided by activation shape)
+        # Winograd operands the LAST pass (or the one in progress) asked for -- decided by activation shape at launch time.  Layers
+        # that stopped qualifying (a prune left 90 channels, the batch or resolution changed) age out instead of being re-packed
+        # for ever  [advisor, round 4]
+        gen = getattr(self, '_wino_gen', 0)
+        seen = getattr(self, '_wino_seen', None) or {}
+        for k in [k for k, g in seen.items() if g < gen - 1]:
+            del seen[k]
         for name, w in self.P.items():
             if name.endswith('.weight') and w.dim() >= 2:
                 for mode in (0, 1, ('wino', 0), ('wino', 1)):
@@ -318,8 +324,8 @@ class UNetEngine:
     # ---- primitive layers ---------------------------------------------------------------------
     def _wino_pack(self, name, w, mode):
         if not hasattr(self, '_wino_seen'):
-            self._wino_seen = set()
-        self._wino_seen.add((name, ('wino', mode)))          # prepare_packs() batches it from the next pass on
+            self._wino_seen = {}
+        self._wino_seen[(name, ('wino', mode))] = getattr(self, '_wino_gen', 0)     # prepare_packs() batches it from the next pass on
         return self.packs.get(name, w, ('wino', mode))
 
     def _conv(self, name, x, x2, spec, **kw):
@@ -619,6 +625,7 @@ class UNetEngine:
         Lr = cfg['layers_per_block']
         nb = len(boc)
         ctx = {} if save else None
+        self._wino_gen = getattr(self, '_wino_gen', 0) + 1       # one generation per forward pass (see prepare_packs)
         if save:
             self.decide_overlap(sample)
         if cfg.get('center_input_sample', False):

@@ -2062,3 +2062,42 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
                 assert not any('scratch_' in t for t in seg), (fname, 'scratch access inside the K loop')
                 checked += 1
     assert checked >= 10, checked            # 6 fast-conv + 4 fast-wgrad + 5 Winograd-conv + 2 Winograd-wgrad instantiations
+
+
+def test_winograd_refuses_activations_within_a_row_of_2gib():
+    """Advisor finding of round 4: the Winograd kernels address X through descriptors that start one image row in front of the
+    tensor (num_records = extent + 4 W) and mark padding with the offset 0x80000000.  An activation whose extent is within 4 W bytes of
+    2 GiB would put that marker inside the descriptor; dp_conv_wino_supported / dp_wgrad_wino_supported refuse such shapes
+    (host-side shape rules: no GPU needed), so the dispatch keeps them on the direct kernels."""
+    L = pkg('_lib')
+    lib = L.load()
+
+    def geom():
+        g = L.ConvGeom()
+        g.Ho = g.Hs = g.Hv = 64
+        g.Wo = g.Ws = g.Wv = 64
+        g.kw, g.stride, g.sden, g.pad_t, g.pad_l, g.ups, g.c_split = 3, 1, 1, 1, 1, 0, 64
+        g.x1_img_stride = g.x2_img_stride = 64 * 64 * 64
+        return g
+
+    def conv(x1_bytes, x2_bytes=0):
+        p = L.ConvGemmParams()
+        p.g = geom()
+        p.M, p.C, p.NPIX, p.ntaps, p.batches, p.lda, p.ksplit = 64, 64, 64 * 64 * 4, 9, 1, 64, 1
+        p.a_bytes, p.x1_bytes, p.x2_bytes = 12 * 64 * 64 * 4, x1_bytes, x2_bytes
+        if x2_bytes:
+            p.X2, p.C, p.g.c_split = 16, 128, 64
+        return lib.dp_conv_wino_supported(ctypes.byref(p))
+
+    def wgrad(x1_bytes):
+        p = L.NtGemmParams()
+        p.g = geom()
+        p.M, p.C, p.NCOLS, p.ntaps, p.P = 64, 64, 64, 9, 64 * 64 * 4
+        p.batches, p.splits, p.p_per_split, p.tile = 1, 4, 64 * 64 + 32, 0
+        p.a_bytes, p.x1_bytes = 4 << 20, x1_bytes
+        return lib.dp_wgrad_wino_supported(ctypes.byref(p))
+
+    lim = (1 << 31) - 4 * 64           # extent + 4 W must stay below 0x80000000
+    assert conv(4 << 20) == 16 and conv(lim - 4) == 16 and conv(lim) == 0 and conv((1 << 31) - 4) == 0
+    assert conv(4 << 20, 4 << 20) == 16 and conv(4 << 20, lim) == 0
+    assert wgrad(4 << 20) == 1 and wgrad(lim - 4) == 1 and wgrad(lim) == 0

@@ -18,6 +18,21 @@ def _inputs(B, H, s1=1, s2=2):
     return (torch.from_numpy(gc.det_clean((B, 3, H, H), s1)), torch.from_numpy(gc.det_noise((B, 3, H, H), s2)))
 
 
+class _direct_kernels:
+    """`with _direct_kernels():` -- every convolution on the direct implicit-GEMM kernels (what DP_WINO=0 DP_WGRAD_WINO=0 select):
+    the full-size tests compare the masks of the default (Winograd F(2, 3)) dispatch against this run."""
+
+    def __enter__(self):
+        ops = pkg('ops')
+        self.saved = (ops.WINO, ops.WGRAD_WINO)
+        ops.WINO = ops.WGRAD_WINO = False
+
+    def __exit__(self, *exc):
+        ops = pkg('ops')
+        ops.WINO, ops.WGRAD_WINO = self.saved
+        return False
+
+
 def test_tiny_forward_matches_reference_and_oracle(report):
     from oracle import diffusion_ref as D, unet_ref as U
     cfg = gc.TINY_CFG
@@ -229,11 +244,11 @@ def test_full_size_determinism_and_shard_linearity(report):
     clean, noise = clean.to(DEV), noise.to(DEV)
     sched = diffusion.DDPMScheduler()
 
-    def run(lo, hi):
+    def run(lo, hi, n_steps=steps):
         model = make_model(cfg, 0)
         flat = sweep.flatten_grads(model)
         step = sweep.HipSweepStep(model, sched, clean[lo:hi], noise[lo:hi], B * clean[0].numel(), 'mse', B)
-        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=steps, step_fn=step, flat_grads=flat)
+        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, step_fn=step, flat_grads=flat)
         torch.cuda.synchronize()
         return model, flat, res['losses']
 
@@ -664,6 +679,12 @@ def test_c3_bedroom256_full_size(report):
     assert r_full['steps'] == steps                                                    # 0.05 does not trigger in 2 steps
     assert torch.equal(g_full, g_again) and r_full['losses'] == r_again['losses']      # (a)
     del g_again
+    with _direct_kernels():                                                            # (f) the same sweep on the direct kernels only
+        model._engine.packs.clear()
+        g_direct, r_direct = run(0, B)
+    model._engine.packs.clear()
+    e_wino_grad = relerr(g_full, g_direct)
+    e_wino_loss = max(abs(a - b) / b for a, b in zip(r_full['losses'], r_direct['losses']))
     g_micro, r_micro = run(0, B, micro=2)                                              # (d)
     e_micro = relerr(g_micro, g_full)
     assert r_micro['steps'] == r_full['steps'] and np.allclose(r_micro['losses'], r_full['losses'], rtol=1e-6)
@@ -674,14 +695,21 @@ def test_c3_bedroom256_full_size(report):
     e_shard = relerr(g1 + g2, g_full)
     g2.add_(g1)                                                                        # what the all-reduce leaves
     del g1
-    m_full = copy.deepcopy(model)
+    from oracle import pruning_ref as R
+    m_full, m_direct = copy.deepcopy(model), copy.deepcopy(model)
     flat_f = sweep.flatten_grads(m_full)
     flat_f.copy_(g_full)
+    sweep.flatten_grads(m_direct).copy_(g_direct)
     pr_sum = sweep.prune_model(model, 0.3)
     pr_full = sweep.prune_model(m_full, 0.3)
+    pr_direct = sweep.prune_model(m_direct, 0.3)
     mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
+    mism_direct = [a[0] for a, b in zip(pr_full.records, pr_direct.records) if a[3] != b[3]]
+    margin = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in pr_full.records)
+    e_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_sum.records))
+    e_wino_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_direct.records))
     params_after = sum(p.numel() for p in model.parameters())
-    del m_full, flat_f, g_full, g2, pr_sum, pr_full
+    del m_full, m_direct, flat_f, g_full, g_direct, g2, pr_sum, pr_full, pr_direct
     torch.cuda.empty_cache()
     # (e) one image against the oracle, with a threshold that can trigger within the 3 steps run
     model1 = make_model(cfg, 0)
@@ -698,9 +726,15 @@ def test_c3_bedroom256_full_size(report):
     report['e2e/c3_bedroom256'] = dict(micro_vs_full_grad_rel=e_micro, shard_loss_rel=e_loss, shard_grad_rel=e_shard,
                                        mask_mismatches=mism, groups=71, params_after=params_after,
                                        b1_steps=res1['steps'], b1_ref_steps=len(ref), b1_loss_rel=e_l1, b1_grad_rel_worst=worst,
-                                       losses=r_full['losses'])
+                                       losses=r_full['losses'], min_decision_margin=margin, shard_score_rel_worst=e_score,
+                                       wino_vs_direct_score_rel=e_wino_score, wino_vs_direct_grad_rel=e_wino_grad,
+                                       wino_vs_direct_loss_rel=e_wino_loss, wino_vs_direct_mask_mismatches=mism_direct)
     assert e_micro < 1e-5 and e_loss < 1e-5 and e_shard < 2e-5                         # fp32 re-association only
     assert not mism                                                                    # (c)
+    # (f) Winograd F(2, 3) vs the direct kernels at full size: same masks for all 71 groups, and the thinnest decision of the run is
+    # an order of magnitude outside both the shard re-association and the Winograd-vs-direct movement of the scores
+    assert not mism_direct and e_wino_loss < 1e-5 and e_wino_grad < 2e-5
+    assert margin > 10 * max(e_score, e_wino_score)
     assert res1['steps'] == len(ref) and e_l1 < 1e-5 and worst < 2e-5                  # (e)
 
 
@@ -1179,6 +1213,14 @@ def test_c5_ldm_cin256_full_size(report):
     assert r_full['steps'] == 2 and r_full['accumulated'] == 2
     assert torch.equal(g_full, g_again) and r_full['losses'] == r_again['losses']      # (a)
     del g_again
+    # (e) the whole pass (CFG sampler + scored forward / backward) on the direct kernels only: what DP_WINO=0 DP_WGRAD_WINO=0 run
+    with _direct_kernels():
+        model._engine.packs.clear()
+        g_direct, r_direct = run()
+        g_direct = g_direct.clone()
+    model._engine.packs.clear()
+    e_wino_grad = relerr(g_full, g_direct)
+    e_wino_loss = max(abs(a - b) / b for a, b in zip(r_full['losses'], r_direct['losses']))
     out = {}
     for world in (2, 4):                                                               # (b)
         acc, lsum, sizes = None, [0.0, 0.0], []
@@ -1192,16 +1234,19 @@ def test_c5_ldm_cin256_full_size(report):
         if world == 2:
             del acc
     assert out[2]['sizes'] == [3, 3] and out[4]['sizes'] == [2, 2, 1, 1]
-    m_full = copy.deepcopy(model)                                                      # (c)
+    m_full, m_direct = copy.deepcopy(model), copy.deepcopy(model)                      # (c)
     sweep.flatten_grads(m_full).copy_(g_full)
+    sweep.flatten_grads(m_direct).copy_(g_direct)
     sweep.flatten_grads(model).copy_(acc)
-    del acc, g_full
-    pr_full, pr_sum = _ldm_masks(m_full), _ldm_masks(model)
+    del acc, g_full, g_direct
+    pr_full, pr_sum, pr_direct = _ldm_masks(m_full), _ldm_masks(model), _ldm_masks(m_direct)
     mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
+    mism_direct = [a[0] for a, b in zip(pr_full.records, pr_direct.records) if a[3] != b[3]]
     margin = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in pr_full.records)
     e_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_sum.records))   # one process vs the summed 4-rank shares
+    e_wino_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_direct.records))   # Winograd vs direct kernels
     params_after = sum(p.numel() for p in model.parameters())
-    del m_full, pr_full, pr_sum
+    del m_full, m_direct, pr_full, pr_sum, pr_direct
     torch.cuda.empty_cache()
     # (d) one latent vs the oracle on the host
     model1 = ldm.UNetModel(**cfg)
@@ -1237,10 +1282,15 @@ def test_c5_ldm_cin256_full_size(report):
                 worst, worst_name = e, k
     report['e2e/c5_ldm_cin256'] = dict(losses=r_full['losses'], shards2=out[2], shards4=out[4], mask_mismatches=mism, groups=109,
                                        min_decision_margin=margin, shard_score_rel_worst=e_score, params_after=params_after,
-                                       sample_rel=e_x0, b1_loss_rel=e_l, b1_grad_rel_worst=worst, b1_grad_worst_name=worst_name)
+                                       sample_rel=e_x0, b1_loss_rel=e_l, b1_grad_rel_worst=worst, b1_grad_worst_name=worst_name,
+                                       wino_vs_direct_score_rel=e_wino_score, wino_vs_direct_grad_rel=e_wino_grad,
+                                       wino_vs_direct_loss_rel=e_wino_loss, wino_vs_direct_mask_mismatches=mism_direct)
     assert out[2]['loss_rel'] < 1e-5 and out[4]['loss_rel'] < 1e-5 and out[2]['grad_rel'] < 2e-5 and out[4]['grad_rel'] < 2e-5
     assert not mism                                                                    # (c)
-    assert margin > 10 * e_score          # the thinnest decision of the 109 groups is an order of magnitude outside the re-association noise
+    assert not mism_direct                # (e) all 109 masks of the default (Winograd) dispatch == the direct kernels' masks
+    # the thinnest decision of the 109 groups is an order of magnitude outside the re-association noise AND outside the movement of
+    # the scores between the Winograd and the direct kernels (20 guided sampling steps + the scored pass, both changed)
+    assert margin > 10 * max(e_score, e_wino_score)
     assert e_x0 < 1e-4 and e_l < 1e-5 and worst < 5e-5                                 # (d)
 
 
@@ -1256,16 +1306,30 @@ def test_c2_cifar_batch256_1000_steps_as_written(report):
     clean, noise = clean.to(DEV), noise.to(DEV)
     sched = diffusion.DDPMScheduler()
 
-    def run(lo, hi):
+    def run(lo, hi, n_steps=steps):
         model = make_model(cfg, 0)
         flat = sweep.flatten_grads(model)
         step = sweep.HipSweepStep(model, sched, clean[lo:hi], noise[lo:hi], B * clean[0].numel(), 'mse', B)
-        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=steps, step_fn=step, flat_grads=flat)
+        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, step_fn=step, flat_grads=flat)
         torch.cuda.synchronize()
         return model, flat, res
 
     m_full, g_full, r_full = run(0, B)
     assert r_full['steps'] == steps and len(r_full['losses']) == steps
+    # Winograd F(2, 3) vs the direct kernels on this configuration (a 24-timestep sweep each: the relative movement of an
+    # accumulated score does not grow with the number of accumulated timesteps): same 50 masks, score movement reported
+    short = {}
+    for key in ('wino', 'direct'):
+        if key == 'direct':
+            with _direct_kernels():
+                m_s, _, _ = run(0, B, 24)
+        else:
+            m_s, _, _ = run(0, B, 24)
+        short[key] = sweep.prune_model(m_s, 0.3).records
+        del m_s
+    mism_direct = [a[0] for a, b in zip(short['wino'], short['direct']) if a[3] != b[3]]
+    e_wino_score = max(relerr(a[2], b[2]) for a, b in zip(short['wino'], short['direct']))
+    margin_short = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in short['direct'])
     m1, g1, r1 = run(0, B // 2)
     m2, g2, r2 = run(B // 2, B)
     e_loss = max(abs((a + b) - c) / c for a, b, c in zip(r1['losses'], r2['losses'], r_full['losses']))
@@ -1278,10 +1342,14 @@ def test_c2_cifar_batch256_1000_steps_as_written(report):
     e_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_sum.records))
     report['e2e/c2_as_written'] = dict(steps=steps, batch=B, loss_rel=e_loss, shard_grad_rel=e_grad, groups=len(pr_full.records),
                                        mask_mismatches=mism, min_decision_margin=margin, shard_score_rel_worst=e_score,
-                                       params_after=sum(p.numel() for p in m_full.parameters()))
+                                       params_after=sum(p.numel() for p in m_full.parameters()),
+                                       wino_vs_direct_score_rel_24_steps=e_wino_score, wino_vs_direct_mask_mismatches_24_steps=mism_direct,
+                                       min_decision_margin_24_steps=margin_short)
     assert e_loss < 1e-5 and e_grad < 5e-5                                    # fp32 re-association over 1000 accumulations
     assert len(pr_full.records) == len(pr_sum.records) == 50 and not mism
-    assert margin > 2 * e_score                                               # the decisions are not within rounding of each other
+    assert not mism_direct and margin_short > 10 * e_wino_score
+    # the decisions are an order of magnitude outside the shard re-association and the Winograd-vs-direct movement of the scores
+    assert margin > 10 * max(e_score, e_wino_score)
     assert sum(p.numel() for p in m_full.parameters()) == sum(p.numel() for p in m1.parameters())
 
 
@@ -1392,7 +1460,7 @@ def test_two_timesteps_in_flight_match_single_pipeline(report):
 
 
 @pytest.mark.parametrize('which', ['tiny_forward', 'tiny_sweep', 'tiny_prune', 'cifar_c1', 'c1_size_1000', 'ddim', 'pruned_sweep', 'ldm_fwd_bwd',
-                                   'finetune'])
+                                   'finetune', 'ldm_prune', 'ldm_sweep', 'multi_head', 'bedroom_topology', 'ddpm', 'criteria'])
 def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report, monkeypatch):
     """Round 4: the 3x3 / stride-1 convolutions of big launches run as a Winograd F(2, 3) implicit GEMM (csrc/winograd.hip; the
     default leaves grids of < 512 tiles -- every fixture-sized model -- on the direct kernel).  Here the threshold is dropped, so
@@ -1415,6 +1483,13 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
      'tiny_prune': test_tiny_prune_masks_bit_exact_and_post_prune_forward, 'cifar_c1': test_cifar_c1_masks_bit_exact,
      'c1_size_1000': test_c1_size_1000_step_sweep_masks_match_reference, 'ddim': test_ddim_sampling_matches_reference,
      'pruned_sweep': test_pruned_model_sweep_matches_oracle, 'ldm_fwd_bwd': test_ldm_unet_forward_backward_matches_reference,
-     'finetune': test_autograd_bridge_and_finetune_step}[which](sub)
+     'finetune': test_autograd_bridge_and_finetune_step,
+     # round 5 (verdict item 1a): the fixtures whose decision margins are the thinnest -- the LDM masks (margin 6e-5), the LDM
+     # importance-pass driver, the multi-head and 6-level topologies, ancestral sampling and the five sibling criteria
+     'ldm_prune': test_ldm_prune_masks_bit_exact, 'ldm_sweep': test_ldm_importance_sweep_matches_oracle,
+     'multi_head': test_multi_head_unet_matches_reference, 'bedroom_topology': test_bedroom_topology_sweep_matches_oracle,
+     'ddpm': test_ddpm_sampling_matches_reference,
+     'criteria': lambda rep: [test_sibling_criteria_masks_bit_exact(rep, c) for c in ('full1', 'full2', 'abs', 'fisher', 'magnitude')],
+     }[which](sub)
     report['wino_forced/' + which] = dict(sub, winograd_launches=n[0], winograd_wgrad_launches=nw[0])
-    assert n[0] > 0 and (nw[0] > 0 or which in ('tiny_forward', 'ddim'))
+    assert n[0] > 0 and (nw[0] > 0 or which in ('tiny_forward', 'ddim', 'ddpm'))

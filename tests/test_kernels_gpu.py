@@ -986,6 +986,71 @@ def test_conv_splitk_fold_equals_reduction_launch(ops, report, monkeypatch, N, C
     assert n_bad == 0
 
 
+def test_conv_splitk_fold_under_concurrent_streams(ops, report, monkeypatch):
+    """Advisor finding of round 4: the in-kernel split-K fold orders its slab stores before the ticket with write-through (sc1)
+    stores + `s_waitcnt vmcnt(0)` + a relaxed agent-scope atomic and reads the slabs back with sc1 loads -- no fence.  Its one
+    bit-identity test ran on an otherwise idle GPU.  Here three HIP streams issue fold launches AT THE SAME TIME (the main stream,
+    the weight-gradient side stream and a second timestep pipeline's stream are what a sweep runs), each over more than eight
+    XCD-spanning tiles, with big Winograd / weight-gradient launches of the other streams filling the L2s in between; 60 rounds x 3
+    streams x 3 launches, every output compared bit for bit with the reduction-launch form (DP_SPLITK_FOLD=0: the safety switch)."""
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    shapes = [(12, 384, 384, 32), (16, 256, 256, 16), (6, 576, 576, 16)]      # (N, Cin, Cout, H): 288 / 64 / 60 tiles of 128 x 128
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(2)]
+    work = []
+    for i, (N, Ci, Co, H) in enumerate(shapes):
+        x, w = rnd(N, Ci, H, H, seed=10 + i), rnd(Co, Ci, 3, 3, seed=20 + i, scale=0.02)
+        dy, res, b = rnd(N, Co, H, H, seed=30 + i), rnd(N, Co, H, H, seed=40 + i), rnd(Co, seed=50 + i)
+        work.append(dict(x=x, w=w, dy=dy, res=res, b=b, fw=ops.pack_weight(w, 0), bw=ops.pack_weight(w, 1), Ci=Ci, Co=Co, H=H))
+    big_x, big_w = rnd(64, 128, 32, 32, seed=7), rnd(128, 128, 3, 3, seed=8, scale=0.02)
+    big_u = ops.pack_weight_wino(big_w, 0)
+    big_p = ops.pack_weight(big_w, 0)
+    big_g = torch.zeros_like(big_w)
+    seen = []
+    real = ops._conv_ksplit
+    monkeypatch.setattr(ops, '_conv_ksplit', lambda p, d: (real(p, d), seen.append((p.ksplit, bool(p.tile_counters))))[0])
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 1 << 30)            # the three test convolutions stay on the direct (split-K) kernel
+    monkeypatch.setattr(ops, 'SPLITK_FOLD_MAX', 8)
+
+    def launches(wk):
+        y = ops.conv_forward(wk['x'], None, *wk['fw'], wk['Co'], spec, bias=wk['b'], res=wk['res'], post_scale=0.7)
+        acc = wk['res'].clone()
+        ops.conv_forward(wk['x'], None, *wk['fw'], wk['Co'], spec, out=acc, accumulate=True)
+        d = ops.conv_dgrad(wk['dy'], *wk['bw'], wk['Ci'], spec, (wk['H'], wk['H']), alpha=0.5)
+        return y, acc, d
+
+    monkeypatch.setattr(ops, 'SPLITK_FOLD', False)
+    ref = [tuple(t.clone() for t in launches(wk)) for wk in work]
+    torch.cuda.synchronize()
+    assert all(k >= 2 and not f for k, f in seen), seen
+    del seen[:]
+    monkeypatch.setattr(ops, 'SPLITK_FOLD', True)
+    n_bad, n_cmp = 0, 0
+    for rnd_i in range(60):
+        outs = []
+        for si, st in enumerate(streams):
+            st.wait_stream(streams[0])
+            with torch.cuda.stream(st):
+                wk = work[(si + rnd_i) % 3]                       # every stream sees every shape over the rounds
+                if rnd_i % 2 == si % 2:                           # L2 / CU contention from the kernels a sweep runs beside the folds
+                    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+                    ops.conv_forward(big_x, None, *big_p, 128, spec, wino=big_u)
+                    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 1 << 30)
+                else:
+                    ops.conv_wgrad(big_x, big_x, None, big_g, spec, accumulate=False)
+                outs.append(((si + rnd_i) % 3, launches(wk)))
+        for st in streams[1:]:
+            streams[0].wait_stream(st)
+        torch.cuda.synchronize()
+        for wi, got in outs:
+            for a, r in zip(got, ref[wi]):
+                n_cmp += 1
+                n_bad += 0 if torch.equal(a, r) else 1
+    folded = [k for k, f in seen if f]
+    report['conv/splitk_fold_concurrent'] = dict(compared=n_cmp, mismatching=n_bad, fold_launches=len(folded), ksplits=sorted(set(folded)))
+    assert folded and all(f for k, f in seen if 2 <= k <= 8), seen[:6]
+    assert n_bad == 0
+
+
 def test_pack_weight_batch_equals_per_layer_pack(ops):
     """dp_pack_weight_batch (every layer of a finetune step in a few launches) against dp_pack_weight, element for element:
     3x3 / 1x1 convolutions and a Linear, both operand layouts, widths that need the ld padding (90 -> 92)."""

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter_collection.csv files into {kernel: {counter: {avg_kb|avg, n}}} (per-launch averages).
-    python tools/pmc_aggregate.py OUT.json DIR [DIR ...]
+    python tools/pmc_aggregate.py [--config NAME] OUT.json DIR [DIR ...]
+--config: the bench.py --config the passes ran (default cifar256); stamped as `_config`, bench.py only quotes `roofline.traffic`
+from a file whose `_config` is the config it is timing.
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (MI355X_MICROARCH.md, HBM section) -> key 'avg_kb'."""
 import collections, csv, glob, json, os, re, sys
 
@@ -11,7 +13,11 @@ def clean(name):
 
 
 def main():
-    out, dirs = sys.argv[1], sys.argv[2:]
+    argv = sys.argv[1:]
+    config = 'cifar256'
+    if argv and argv[0] == '--config':
+        config, argv = argv[1], argv[2:]
+    out, dirs = argv[0], argv[1:]
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for d in dirs:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
@@ -35,6 +41,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = b''.join(open(os.path.join(root, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
     res['_gemm_hip_blob'] = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
+    res['_config'] = config
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
     print('wrote', out, len(res), 'kernels')
 
