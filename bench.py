@@ -269,7 +269,10 @@ class FinetuneWorkload:
         t_total = time.perf_counter() - t0
         return dict(units=self.env.world * self.B * K, steps_done=K, t_total=t_total, t_steps=t_total,
                     extra={'host_enqueue_ms_per_step': t_enq / K * 1e3,
-                           'kernel_launches_per_step': (lib.dp_launch_count() - launches0) / K, 'dropout': 0.1,
+                           'kernel_launches_per_step': ((self.ft._cap['call'].info.get('kernels', 0) if self.ft._cap else 0)
+                                                        + (lib.dp_launch_count() - launches0) / K),
+                           'step_replayed_natively': self.ft._cap is not None,
+                           'replay_info': dict(self.ft._cap['call'].info) if self.ft._cap else None, 'dropout': 0.1,
                            'params': sum(p.numel() for p in self.model.parameters()), 'last_local_loss': float(loss)})
 
     def workload(self, K):
@@ -287,6 +290,7 @@ class FinetuneWorkload:
         ts = self._ts()
 
         def one(k):
+            self.ft.replay = False                     # HIP events around every launch need the eager step
             self.model._engine.overlap_wgrad = False
             self.ft.step(self.clean, self.noise, ts)
         return one
@@ -304,31 +308,38 @@ class DdimWorkload:
         self.sched.set_timesteps(100)
         self.x = torch.from_numpy(gc.det_noise((self.B, 3, 32, 32), 500 + env.rank)).to(env.dev)
 
-    def _steps(self, n):
+    def _steps(self, n, fwd):
+        """n steps of ddpm_sample.py's inner loop as DDIMPipeline.__call__ runs them: eps = UNet(x, t) through `fwd`
+        (UNet2DModel.sampling_forward: the captured forward replayed natively, or the eager pinned call), then the scheduler step."""
         x = self.x
-        ts = self.sched.timesteps
-        with torch.no_grad(), self.model.pin_weights():
+        ts = [int(v) for v in self.sched.timesteps.tolist()]
+        with torch.no_grad():
             for i in range(n):
-                t = int(ts[i % len(ts)])
-                tt = torch.full((self.B,), t, dtype=torch.long, device=self.env.dev)
-                e = self.model(x, tt).sample
+                t = ts[i % len(ts)]
+                e = fwd(x, t)
                 x = self.sched.step(e, t, x, eta=0.0).prev_sample
         return x
 
     def warmup(self, W):
-        self._steps(W)
+        self.fwd = self.model.sampling_forward(tuple(self.x.shape), 100)       # what a 100-step DDIMPipeline call gets
+        self._steps(W, self.fwd)
 
     def run(self, K):
         lib = pkg('ops')._lib()
         launches0 = lib.dp_launch_count()
         t0 = time.perf_counter()
-        x = self._steps(K)
+        x = self._steps(K, self.fwd)
         t_enq = time.perf_counter() - t0
         self.env.barrier()
         t_total = time.perf_counter() - t0
+        replayed = type(self.fwd).__name__ == '_CapturedForward'
+        info = dict(self.fwd.call.info) if replayed else {}
+        self.fwd.close()
         return dict(units=self.env.world * self.B * K, steps_done=K, t_total=t_total, t_steps=t_total,
                     extra={'host_enqueue_ms_per_step': t_enq / K * 1e3,
-                           'kernel_launches_per_step': (lib.dp_launch_count() - launches0) / K,
+                           'kernel_launches_per_step': (info.get('kernels', 0) + (lib.dp_launch_count() - launches0) / K) if replayed
+                           else (lib.dp_launch_count() - launches0) / K,
+                           'forward_replayed_natively': replayed, 'replay_nodes': info.get('nodes'),
                            'finite': bool(torch.isfinite(x).all())})
 
     def workload(self, K):
@@ -339,7 +350,8 @@ class DdimWorkload:
                 'parallelism': 'dp%d (independent batches per rank)' % self.env.world}
 
     def instrumented(self):
-        return lambda k: self._steps(1)
+        eager = self.model.sampling_forward(tuple(self.x.shape), 1, replay=False)     # HIP events need the eager launches
+        return lambda k: self._steps(1, eager)
 
 
 class LdmWorkload:

@@ -56,7 +56,7 @@ class AttentionParams(C.Structure):
 
 class Dropout(C.Structure):
     _fields_ = [('thr24', C.c_uint), ('scale', C.c_float), ('seed', C.c_ulonglong), ('site', C.c_uint), ('step', C.c_uint),
-                ('n_off', LL)]
+                ('n_off', LL), ('step_dev', C.c_void_p)]
 
 
 class ScoreMember(C.Structure):
@@ -136,6 +136,8 @@ SIGNATURES = {
     'dp_sumsq_partials': [_vp, _ll, _vp, _i, _vp],
     'dp_clip_coef': [_vp, _i, _f, _vp, _vp, _vp],
     'dp_adam_ema': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
+    'dp_set_step_scalars': [_vp, _f, _f, _f, C.c_uint, _vp],
+    'dp_adam_ema_dev': [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _f, _f, _f, _vp],
     'dp_ddim_step': [_vp, _vp, _vp, _f, _f, _f, _i, _f, _vp, _ll, _vp],
     'dp_ddpm_step': [_vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp, _ll, _vp],
     'dp_dropout_apply': [_vp, _ll, _vp, _ll, _i, _ll, _dr, _vp],

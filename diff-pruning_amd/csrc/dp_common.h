@@ -72,6 +72,7 @@ struct DpDrop {
     float scale;               // 1 / (1 - p)
     unsigned seed_lo, seed_hi, site, step;
     long long n_off;           // global index of this shard's first image
+    const unsigned* step_ptr;  // device counter read instead of `step` when set (replayed finetune steps)
 };
 
 __device__ __forceinline__ uint4 dp_philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
@@ -89,7 +90,8 @@ __device__ __forceinline__ uint4 dp_philox4x32_10(uint4 c, unsigned k0, unsigned
 // multipliers (0 or scale) of the 4 elements idx .. idx+3, idx % 4 == 0
 __device__ __forceinline__ float4 dp_drop4(const DpDrop& d, long long idx) {
     const unsigned long long q = (unsigned long long)idx >> 2;
-    const uint4 r = dp_philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.site, d.step), d.seed_lo, d.seed_hi);
+    const unsigned step = d.step_ptr ? *d.step_ptr : d.step;          // wave-uniform address: one scalar load
+    const uint4 r = dp_philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.site, step), d.seed_lo, d.seed_hi);
     return make_float4((r.x >> 8) >= d.thr24 ? d.scale : 0.f, (r.y >> 8) >= d.thr24 ? d.scale : 0.f,
                        (r.z >> 8) >= d.thr24 ? d.scale : 0.f, (r.w >> 8) >= d.thr24 ? d.scale : 0.f);
 }
@@ -110,6 +112,7 @@ static inline DpDrop dp_drop_host(const dp_dropout* d) {
         r.site = d->site;
         r.step = d->step;
         r.n_off = d->n_off;
+        r.step_ptr = d->step_dev;
     }
     return r;
 }

@@ -129,54 +129,63 @@ __device__ __forceinline__ void conv_epilogue_tile(const dp_conv_gemm_params& p,
                                                    float* __restrict__ optr, const float* __restrict__ rptr,
                                                    const float* __restrict__ tptr, int HoWo) {
     const int mb = mrow0 + 4 * (lane >> 5);
+    // round 5: four rows at a time with the loads of ALL optional operands of the four (up to 16) in flight before the first use
+    // -- round 1's form issued ONE operand's eight loads, waited, then the next operand's: four dependent round trips per half
+    // sub-tile, which is what the short-K 1x1 / projection launches spend their time in.  Same register footprint (the 128 x 128
+    // kernels sit at their 128-VGPR cap: eight rows x four operands spilled).
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float v[8];
-        int mc[8];
+    for (int h = 0; h < 4; ++h) {
+        float v[4], tb[4], tt[4], tr[4], tp[4];
+        int mc[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = h * 8 + q;
+        for (int q = 0; q < 4; ++q) {
+            const int r = h * 4 + q;
             const int m = mb + (r & 3) + 8 * (r >> 2);
             mc[q] = FULL ? m : min(m, p.M - 1);
             v[q] = p.alpha * acc[r];
+            tb[q] = tt[q] = tr[q] = tp[q] = 0.f;
         }
         if (p.bias) {
-            float t[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = p.bias[mc[q]];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += t[q];
+            for (int q = 0; q < 4; ++q) tb[q] = p.bias[mc[q]];
         }
         if (tptr) {
-            float t[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = tptr[mc[q]];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += t[q];
+            for (int q = 0; q < 4; ++q) tt[q] = tptr[mc[q]];
         }
         if (rptr) {
-            float t[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = rptr[(long long)mc[q] * HoWo];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += t[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] *= p.post_scale;
-        if (p.act == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            for (int q = 0; q < 4; ++q) tr[q] = rptr[(long long)mc[q] * HoWo];
         }
         if (p.accumulate) {
-            float t[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = optr[(long long)mc[q] * HoWo];
+            for (int q = 0; q < 4; ++q) tp[q] = optr[(long long)mc[q] * HoWo];
+        }
+        if (p.bias) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] += t[q];
+            for (int q = 0; q < 4; ++q) v[q] += tb[q];
+        }
+        if (tptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += tt[q];
+        }
+        if (rptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += tr[q];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = h * 8 + q;
+        for (int q = 0; q < 4; ++q) v[q] *= p.post_scale;
+        if (p.act == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (p.accumulate) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += tp[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = h * 4 + q;
             if (FULL || mb + (r & 3) + 8 * (r >> 2) < p.M) optr[(long long)mc[q] * HoWo] = v[q];
         }
     }
@@ -1082,8 +1091,64 @@ static bool conv_few_out_ok(const dp_conv_gemm_params& p) {
 }
 
 // the reduction launch of a split-K convolution (also used by dp_conv_wino): out = epilogue(sum_z ws[z][m][pix])
+// The same reduction for 4 consecutive pixels per thread (round 5): ksplit 16-byte loads per thread, eight of them in flight,
+// all branch-free (split indices past the end re-read the last slice and are not added) -- the scalar form above keeps eight
+// 4-byte loads in flight behind a branch each (8.6 us per launch x 3 981 launches of an LDM importance step).  Needs Ho*Wo % 4 == 0
+// (so the four pixels share an image and a row of the [M][NPIX] partials) and 16-byte aligned rows everywhere.  Same additions
+// in the same order per element -> the same bits.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const dp_conv_gemm_params p) {
+    const long long total4 = (long long)p.M * p.NPIX / 4;
+    const long long total = (long long)p.M * p.NPIX;
+    const int HoWo = p.g.Ho * p.g.Wo;
+    const int NPIX4 = p.NPIX / 4;
+    for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long long)gridDim.x * 256) {
+        const int m = (int)(i4 / NPIX4);
+        const int pix = (int)(i4 - (long long)m * NPIX4) * 4;
+        const float4* w4 = reinterpret_cast<const float4*>(p.ws) + i4;
+        const int img = pix / HoWo;
+        const int r_in = pix - img * HoWo;
+        // the epilogue operands go out with the first partials (a load per `if` after the reduction is a round trip each)
+        float4* o = reinterpret_cast<float4*>(p.out + (long long)img * p.o_img_stride + (long long)m * HoWo + r_in);
+        float b = 0.f, t = 0.f;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), prev = r;
+        if (p.bias) b = p.bias[m];
+        if (p.tadd) t = p.tadd[(long long)img * p.tadd_stride + m];
+        if (p.res) r = *reinterpret_cast<const float4*>(p.res + (long long)img * p.r_img_stride + (long long)m * HoWo + r_in);
+        if (p.accumulate) prev = *o;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < p.ksplit; z += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int zc = z + j < p.ksplit ? z + j : p.ksplit - 1;
+                v[j] = w4[(long long)zc * (total / 4)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (z + j < p.ksplit) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+        }
+        float4 v = make_float4(p.alpha * a.x, p.alpha * a.y, p.alpha * a.z, p.alpha * a.w);
+        if (p.bias) { v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (p.tadd) { v.x += t; v.y += t; v.z += t; v.w += t; }
+        if (p.res) { v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        v.x *= p.post_scale; v.y *= p.post_scale; v.z *= p.post_scale; v.w *= p.post_scale;
+        if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.accumulate) { v.x += prev.x; v.y += prev.y; v.z += prev.z; v.w += prev.w; }
+        *o = v;
+    }
+}
+
 extern "C" int dp_conv_splitk_epilogue(const dp_conv_gemm_params* pp, void* stream) {
     const dp_conv_gemm_params& p = *pp;
+    const int HoWo = p.g.Ho * p.g.Wo;
+    const bool v4 = HoWo % 4 == 0 && p.NPIX % 4 == 0 && ((uintptr_t)p.ws | (uintptr_t)p.out | (uintptr_t)p.res) % 16 == 0 &&
+                    p.o_img_stride % 4 == 0 && (!p.res || p.r_img_stride % 4 == 0) && !getenv("DP_NO_EPI4");
+    if (v4) {
+        long long nb = ((long long)p.M * p.NPIX / 4 + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        DP_LAUNCH(conv_splitk_epilogue4_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+        return DP_LAUNCH_CHECK();
+    }
     long long nb = ((long long)p.M * p.NPIX + 255) / 256;
     if (nb > 8192) nb = 8192;
     DP_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
@@ -1607,9 +1672,56 @@ __global__ __launch_bounds__(256) void splitk_reduce_taps_kernel(const float* __
     }
 }
 
+// One thread per (m, c), all NT taps (round 5): the tap planes ws[s][tap][mc] are read coalesced (consecutive threads = consecutive
+// mc), 4 splits x NT taps = up to 36 independent loads in flight per thread (the scalar form above: eight behind a branch each and
+// 4-byte stores 4 * ntaps bytes apart), and the NT sums of a thread leave as one contiguous run of out[(m*C + c)*NT ..].  Per
+// element the same ascending-split additions as dp_splitk_sum -> the same bits.  [21.8 us x 104 launches per finetune step]
+template <int NT>
+__global__ __launch_bounds__(256) void splitk_reduce_taps_mc_kernel(const float* __restrict__ ws, long long stride, int splits,
+                                                                    float* __restrict__ out, long long mc, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mc) return;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    const float* w = ws + i;
+    for (int z = 0; z < splits; z += 4) {
+        float v[4][NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int zc = z + j < splits ? z + j : splits - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[j][t] = w[(long long)zc * stride + (long long)t * mc];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (z + j < splits) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] += v[j][t];
+            }
+    }
+    float* o = out + i * NT;
+    if (accumulate) {
+        float prev[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) prev[t] = o[t];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = prev[t] + acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[t] = acc[t];
+}
+
 extern "C" int dp_splitk_reduce_taps(const float* ws, long long stride, int splits, float* out, long long mc, int ntaps,
                                      int accumulate, void* stream) {
     if (mc <= 0 || ntaps <= 0) return 0;
+    const bool no_mc = getenv("DP_NO_REDUCE_MC") != nullptr;        // read per call: the parity test flips it
+    if (!no_mc && (ntaps == 9 || ntaps == 4)) {
+        const unsigned nbm = (unsigned)((mc + 255) / 256);
+        if (ntaps == 9) DP_LAUNCH((splitk_reduce_taps_mc_kernel<9>), dim3(nbm), dim3(256), 0, (hipStream_t)stream, ws, stride, splits, out, mc, accumulate);
+        else            DP_LAUNCH((splitk_reduce_taps_mc_kernel<4>), dim3(nbm), dim3(256), 0, (hipStream_t)stream, ws, stride, splits, out, mc, accumulate);
+        return DP_LAUNCH_CHECK();
+    }
     long long nb = (mc * ntaps + 255) / 256;
     if (nb > 4096) nb = 4096;
     DP_LAUNCH(splitk_reduce_taps_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, ws, stride, splits,

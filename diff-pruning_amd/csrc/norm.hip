@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnSrc src, const float* __r
     }
 }
 
-// float4 variant (HW % 4 == 0, 16-byte aligned planes): a float4 never straddles a channel.
+// float4 variant (HW % 4 == 0, 16-byte aligned planes): a float4 never straddles a channel.  NI = cached float4 per thread (1, 2,
+// 4, 8: groups of up to 1024 / 2048 / 4096 / 8192 elements; no dead iterations), 0 = the streaming form for larger groups.
+template <int NI>
 __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C, int HW, int G, float eps,
                                                           int silu, float* __restrict__ y, long long y_img_stride,
@@ -112,20 +114,26 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
     const long long didx0 = ((drop.n_off + n) * C + (long long)g * cpg) * HW;
     const int HW4 = HW / 4;
     const int tid = threadIdx.x;
-    const bool cached = cnt4 <= 256 * (GN_CACHE / 4);
+    constexpr bool cached = NI > 0;
+    constexpr int NC = NI > 0 ? NI : 1;
     const int c_base = g * cpg;
-    float4 xr[GN_CACHE / 4];
-    float s = 0.f;
+    float4 xr[NC];
+    float gac[NC], bec[NC];          // gamma / beta of the channel each cached float4 belongs to (round 5: loaded
+    float s = 0.f;                                       // with the data, not one dependent L2 round trip per store in the apply loop)
     if (cached) {
 #pragma unroll
-        for (int i = 0; i < GN_CACHE / 4; ++i) {
+        for (int i = 0; i < NC; ++i) {         // branch-free: lanes past the end read the group's last float4, zeroed below
             const int e = tid + 256 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < cnt4) {
-                const int cl = e / HW4;
-                v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
-            }
-            xr[i] = v;
+            const int ec = e < cnt4 ? e : cnt4 - 1;
+            const int cl = ec / HW4;
+            xr[i] = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[ec - cl * HW4];
+            gac[i] = gamma[c_base + cl];
+            bec[i] = beta[c_base + cl];
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (tid + 256 * i >= cnt4) xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = xr[i];
             s += (v.x + v.y) + (v.z + v.w);
         }
     } else {
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
     float q = 0.f;
     if (cached) {
 #pragma unroll
-        for (int i = 0; i < GN_CACHE / 4; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int e = tid + 256 * i;
             if (e < cnt4) {
                 const float4 v = xr[i];
@@ -162,28 +170,27 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
         stats[(long long)blockIdx.x * 2 + 1] = rstd;
     }
     float4* yb = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c_base * HW);
-    auto apply = [&](float4 v, int c, int e4) {
-        const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
+    auto apply = [&](float4 v, float ga, float be, int e4) {
         float4 o;
-        o.x = (v.x - mean) * rstd * gamma[c] + beta[c];
-        o.y = (v.y - mean) * rstd * gamma[c] + beta[c];
-        o.z = (v.z - mean) * rstd * gamma[c] + beta[c];
-        o.w = (v.w - mean) * rstd * gamma[c] + beta[c];
-        (void)ga; (void)be;
+        o.x = (v.x - mean) * rstd * ga + be;
+        o.y = (v.y - mean) * rstd * ga + be;
+        o.z = (v.z - mean) * rstd * ga + be;
+        o.w = (v.w - mean) * rstd * ga + be;
         if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
         if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * e4); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
         return o;
     };
     if (cached) {
 #pragma unroll
-        for (int i = 0; i < GN_CACHE / 4; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int e = tid + 256 * i;
-            if (e < cnt4) yb[e] = apply(xr[i], c_base + e / HW4, e);
+            if (e < cnt4) yb[e] = apply(xr[i], gac[i], bec[i], e);
         }
     } else {
         for (int e = tid; e < cnt4; e += 256) {
             const int cl = e / HW4;
-            yb[e] = apply(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4], c_base + cl, e);
+            yb[e] = apply(reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4], gamma[c_base + cl],
+                          beta[c_base + cl], e);
         }
     }
 }
@@ -195,6 +202,10 @@ __global__ __launch_bounds__(256) void gn_fwd_vec4_kernel(GnSrc src, const float
 // FASTER on the workgroup kernel (54 vs 59 us) and stay there.]  Lane l holds float4 elements l, l + 64, ... of the group chunk
 // (coalesced 1 KB wave loads); same two-pass mean / variance as the workgroup kernels (shuffle tree instead of the LDS combine).
 #define GN_WAVE_NV 8
+// NV = float4 steps a lane takes (1, 2, 4 or 8: groups of up to 256 / 512 / 1024 / 2048 elements), so the 8 x 8 and 4 x 4 layers do
+// not walk dead iterations.  Loads are branch-free (lanes past the group's end read its last element and are masked afterwards):
+// hipcc does not hoist a load out of an exec-masked region, and a load per `if (live)` is a memory round trip per iteration.
+template <int NV>
 __global__ __launch_bounds__(256) void gn_fwd_wave_kernel(GnSrc src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C, int HW, int G, float eps,
                                                           int silu, float* __restrict__ y, long long y_img_stride,
@@ -209,23 +220,28 @@ __global__ __launch_bounds__(256) void gn_fwd_wave_kernel(GnSrc src, const float
     const int cnt4 = cpg * HW4;
     const int c_base = g * cpg;
     const long long didx0 = ((drop.n_off + n) * C + (long long)g * cpg) * HW;
-    float4 xr[GN_WAVE_NV];
+    float4 xr[NV];
+    float ga[NV], be[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < GN_WAVE_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < cnt4) {
-            const int cl = e / HW4;
-            v = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[e - cl * HW4];
-        }
-        xr[i] = v;
+        const int ec = e < cnt4 ? e : cnt4 - 1;
+        const int cl = ec / HW4;
+        xr[i] = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c_base + cl, HW))[ec - cl * HW4];
+        ga[i] = gamma[c_base + cl];
+        be[i] = beta[c_base + cl];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i >= cnt4) xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = xr[i];
         s += (v.x + v.y) + (v.z + v.w);
     }
     const float mean = dp_wave_sum(s) / (float)(cnt4 * 4);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < GN_WAVE_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if (lane + 64 * i < cnt4) {
             const float4 v = xr[i];
             const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
@@ -240,17 +256,15 @@ __global__ __launch_bounds__(256) void gn_fwd_wave_kernel(GnSrc src, const float
     }
     float4* yb = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c_base * HW);
 #pragma unroll
-    for (int i = 0; i < GN_WAVE_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         if (e < cnt4) {
-            const int c = c_base + e / HW4;
-            const float ga = gamma[c], be = beta[c];
             const float4 v = xr[i];
             float4 o;
-            o.x = (v.x - mean) * rstd * ga + be;
-            o.y = (v.y - mean) * rstd * ga + be;
-            o.z = (v.z - mean) * rstd * ga + be;
-            o.w = (v.w - mean) * rstd * ga + be;
+            o.x = (v.x - mean) * rstd * ga[i] + be[i];
+            o.y = (v.y - mean) * rstd * ga[i] + be[i];
+            o.z = (v.z - mean) * rstd * ga[i] + be[i];
+            o.w = (v.w - mean) * rstd * ga[i] + be[i];
             if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
             if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * e); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
             yb[e] = o;
@@ -270,11 +284,27 @@ extern "C" int dp_groupnorm_silu_fwd(const float* x1, const float* x2, int c_spl
                       (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0);
     static const bool no_wave = getenv("DP_NO_GN_WAVE") != nullptr;
     if (vec4 && !no_wave && (long long)(C / G) * HW <= 256 * GN_WAVE_NV && N * G >= 1024)      // <= 512 float4 per group
-        DP_LAUNCH(gn_fwd_wave_kernel, dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
-                           silu, y, y_img_stride, stats, dd, N * G);
-    else if (vec4)
-        DP_LAUNCH(gn_fwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps,
-                           silu, y, y_img_stride, stats, dd);
+    {
+        const int cnt4 = (C / G) * (HW / 4);
+#define GN_FWD_WAVE(NV_) DP_LAUNCH((gn_fwd_wave_kernel<NV_>), dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, \
+                                   beta, C, HW, G, eps, silu, y, y_img_stride, stats, dd, N * G)
+        if (cnt4 <= 64) GN_FWD_WAVE(1);
+        else if (cnt4 <= 128) GN_FWD_WAVE(2);
+        else if (cnt4 <= 256) GN_FWD_WAVE(4);
+        else GN_FWD_WAVE(8);
+#undef GN_FWD_WAVE
+    }
+    else if (vec4) {
+        const long long cnt4 = (long long)(C / G) * (HW / 4);
+#define GN_FWD_V4(NI_) DP_LAUNCH((gn_fwd_vec4_kernel<NI_>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, \
+                                 eps, silu, y, y_img_stride, stats, dd)
+        if (cnt4 <= 256) GN_FWD_V4(1);
+        else if (cnt4 <= 512) GN_FWD_V4(2);
+        else if (cnt4 <= 1024) GN_FWD_V4(4);
+        else if (cnt4 <= 2048) GN_FWD_V4(8);
+        else GN_FWD_V4(0);
+#undef GN_FWD_V4
+    }
     else
         DP_LAUNCH(gn_fwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, C, HW, G, eps, silu,
                            y, y_img_stride, stats, dd);
@@ -488,7 +518,10 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4_kernel(GnSrc src, const float
 // order of gn_bwd_vec4_kernel, so the per-channel sums, the group terms and dx are the same expressions on the same values; what
 // goes away is the second pass's re-read of x and dz (through L2, behind the barrier) and its second evaluation of silu' (two
 // exponentials and a division per element).
-template <int NCH>
+// Round 5: loads branch-free and batched (hipcc keeps a load inside its `if (i < HW4)` region and waits for it there: the ISA
+// read two loads per wait in pass 1 and eight scalarized dword loads per store in pass 2); the addends' presence is a template
+// parameter and their loads go out BEFORE the barrier, so their latency hides behind the wait for the other wavefronts' sums.
+template <int NCH, bool A1, bool A2>
 __global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ stats,
                                                            const float* __restrict__ dz, long long dz_img_stride, int C,
@@ -510,27 +543,37 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const floa
     const float* dzb = dz + (long long)n * dz_img_stride;
     const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
     float4 xh[NCH][4], dd[NCH][4];
+    float gak[NCH], bek[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {                             // every load of the workgroup's pass 1 in flight before the first use
+        const int cl = wave + 4 * k;
+        const int c = c_base + (cl < cpg ? cl : cpg - 1);
+        const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
+        const float4* dp = reinterpret_cast<const float4*>(dzb + (long long)c * HW);
+        gak[k] = gamma[c];
+        bek[k] = beta[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            const int ic = i < HW4 ? i : HW4 - 1;
+            xh[k][j] = xp[ic];
+            dd[k][j] = dp[ic];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int cl = wave + 4 * k;
         if (cl < cpg) {
             const int c = c_base + cl;
-            const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW));
-            const float4* dp = reinterpret_cast<const float4*>(dzb + (long long)c * HW);
-            const float ga = gamma[c], be = beta[c];
-            float4 xv[4], dv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                       // all loads of the channel in flight before the first use
-                const int i = lane + 64 * j;
-                if (i < HW4) { xv[j] = xp[i]; dv[j] = dp[i]; }
-            }
+            const float ga = gak[k], be = bek[k];
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = lane + 64 * j;
                 if (i < HW4) {
-                    float4 h, d = dv[j];
-                    h.x = (xv[j].x - mean) * rstd; h.y = (xv[j].y - mean) * rstd; h.z = (xv[j].z - mean) * rstd; h.w = (xv[j].w - mean) * rstd;
+                    const float4 xv = xh[k][j];
+                    float4 h, d = dd[k][j];
+                    h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
                     if (drop.thr24) {
                         const float4 m = dp_drop4(drop, didx0 + 4 * ((long long)cl * HW4 + i));
                         d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
@@ -555,6 +598,21 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const floa
             }
         }
     }
+    const float4* a1b = A1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
+    const float4* a2b = A2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
+    float4 t1[NCH][4], t2[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int cl = wave + 4 * k;
+        const int clc = cl < cpg ? cl : cpg - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            const int ec = clc * HW4 + (i < HW4 ? i : HW4 - 1);
+            if (A1) t1[k][j] = a1b[ec];
+            if (A2) t2[k][j] = a2b[ec];
+        }
+    }
     __syncthreads();
     float a = 0.f, b = 0.f;
     for (int cl = 0; cl < cpg; ++cl) {
@@ -566,27 +624,25 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const floa
     a *= invM;
     b *= invM;
     float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
-    const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
-    const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int cl = wave + 4 * k;
         if (cl < cpg) {
-            const float ga = gamma[c_base + cl];
+            const float ga = gak[k];
             float r = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = lane + 64 * j;
                 if (i < HW4) {
                     const int e = cl * HW4 + i;
-                    const float4 t1 = a1b ? a1b[e] : zero4, t2 = a2b ? a2b[e] : zero4;
+                    const float4 u1 = A1 ? t1[k][j] : zero4, u2 = A2 ? t2[k][j] : zero4;
                     const float4 d = dd[k][j], h = xh[k][j];
                     float4 v;
-                    v.x = rstd * (ga * d.x - a - h.x * b) + t1.x + t2.x;
-                    v.y = rstd * (ga * d.y - a - h.y * b) + t1.y + t2.y;
-                    v.z = rstd * (ga * d.z - a - h.z * b) + t1.z + t2.z;
-                    v.w = rstd * (ga * d.w - a - h.w * b) + t1.w + t2.w;
+                    v.x = rstd * (ga * d.x - a - h.x * b) + u1.x + u2.x;
+                    v.y = rstd * (ga * d.y - a - h.y * b) + u1.y + u2.y;
+                    v.z = rstd * (ga * d.z - a - h.z * b) + u1.z + u2.z;
+                    v.w = rstd * (ga * d.w - a - h.w * b) + u1.w + u2.w;
                     dxb[e] = v;
                     r += (v.x + v.y) + (v.z + v.w);
                 }
@@ -602,6 +658,13 @@ __global__ __launch_bounds__(256) void gn_bwd_vec4c_kernel(GnSrc src, const floa
 // Backward, one wavefront per (image, group): HW / 4 is a power of two <= 64, so every wave-wide float4 step covers 64 / HW4
 // whole channels and the per-channel sums are segmented xor-shuffle reductions over HW4 lanes.  x-hat and dy stay in registers
 // between the two phases (the workgroup kernel re-reads them through L2 behind a barrier).  Fixed shuffle order: deterministic.
+// Round 5: the ISA of the round-3 kernel read `load, s_waitcnt vmcnt(0), load, s_waitcnt vmcnt(0), ...` -- hipcc does not hoist a
+// load out of an `if (live)` region, and the `ptr ? ptr[e] : 0` form of the optional addends became four dword loads each --
+// i.e. ~25 serialized memory round trips per wavefront (1.6 TB/s, 20 % of the HBM roofline by the PMC bytes).  Now: NV (float4 steps
+// per lane) and the presence of the addends are template parameters, every load is branch-free (lanes past the end of the group
+// read its last element and are zeroed afterwards) and issued before the first use; the segmented reductions of all steps advance
+// together (2 NV independent shuffles per level instead of NV dependent chains).  Same assignment, expressions and summation order.
+template <int NV, bool A1, bool A2>
 __global__ __launch_bounds__(256) void gn_bwd_wave_kernel(GnSrc src, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const float* __restrict__ dz, long long dz_img_stride, int C,
@@ -616,73 +679,113 @@ __global__ __launch_bounds__(256) void gn_bwd_wave_kernel(GnSrc src, const float
     const int g = wid - n * G;
     const int cpg = C / G;
     const int HW4 = HW / 4;
+    const int lg4 = 31 - __builtin_clz(HW4);
     const int cnt4 = cpg * HW4;
     const int c_base = g * cpg;
     const float mean = stats[(long long)wid * 2 + 0];
     const float rstd = stats[(long long)wid * 2 + 1];
     const long long didx0 = ((drop.n_off + n) * C + c_base) * (long long)HW;
     const float4* dzc = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c_base * HW);
+    const float4* a1b = A1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
+    const float4* a2b = A2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
     const bool leader = (lane & (HW4 - 1)) == 0;
-    float4 xh[GN_WAVE_NV], dv[GN_WAVE_NV];
-    float gam[GN_WAVE_NV];
-    float a = 0.f, b = 0.f;
+    constexpr bool EARLY = NV <= 4;              // the addends' loads go out with the operands' (registers allow it up to 4 steps)
+    float4 xh[NV], dv[NV], t1[NV], t2[NV];
+    float gam[NV], bet[NV];
+    // ---- phase 0: every load of the wavefront in flight
 #pragma unroll
-    for (int i = 0; i < GN_WAVE_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        const int ec = e < cnt4 ? e : cnt4 - 1;
+        const int cl = ec >> lg4;
+        const int c = c_base + cl;
+        xh[i] = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[ec - (cl << lg4)];
+        dv[i] = dzc[ec];
+        gam[i] = gamma[c];
+        bet[i] = beta[c];
+        if (A1 && EARLY) t1[i] = a1b[ec];
+        if (A2 && EARLY) t2[i] = a2b[ec];
+    }
+    // ---- phase 1: dy, x-hat, per-channel sums
+    float s1[NV], s2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         const bool live = e < cnt4;
-        const int cl = live ? e / HW4 : 0;
-        const int c = c_base + cl;
-        float4 xv = make_float4(mean, mean, mean, mean), d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            xv = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW))[e - cl * HW4];
-            d = dzc[e];
-        }
-        const float ga = gamma[c], be = beta[c];
+        const float ga = gam[i], be = bet[i];
+        const float4 xv = xh[i];
+        float4 d = dv[i];
         float4 h;
         h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
-        if (drop.thr24 && live) { const float4 m = dp_drop4(drop, didx0 + 4ll * e); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * (live ? e : cnt4 - 1)); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
         if (silu) {
             d.x *= dp_silu_grad(h.x * ga + be); d.y *= dp_silu_grad(h.y * ga + be);
             d.z *= dp_silu_grad(h.z * ga + be); d.w *= dp_silu_grad(h.w * ga + be);
         }
-        xh[i] = h; dv[i] = d; gam[i] = ga;
-        float s1 = (d.x + d.y) + (d.z + d.w);
-        float s2 = (d.x * h.x + d.y * h.y) + (d.z * h.z + d.w * h.w);
-        for (int o = HW4 >> 1; o > 0; o >>= 1) {                     // per-channel sums: segments of HW4 lanes
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
+        if (!live) { h = make_float4(0.f, 0.f, 0.f, 0.f); d = h; }
+        xh[i] = h; dv[i] = d;
+        s1[i] = (d.x + d.y) + (d.z + d.w);
+        s2[i] = (d.x * h.x + d.y * h.y) + (d.z * h.z + d.w * h.w);
+    }
+    for (int o = HW4 >> 1; o > 0; o >>= 1) {                         // per-channel sums: segments of HW4 lanes, all steps together
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s1[i] += __shfl_xor(s1[i], o, 64);
+            s2[i] += __shfl_xor(s2[i], o, 64);
         }
-        if (live && leader) {
-            pws[((long long)n * C + c) * 2 + 0] = s1;
-            pws[((long long)n * C + c) * 2 + 1] = s2;
-            a += ga * s1;
-            b += ga * s2;
+    }
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = lane + 64 * i;
+        if (e < cnt4 && leader) {
+            const int c = c_base + (e >> lg4);
+            pws[((long long)n * C + c) * 2 + 0] = s1[i];
+            pws[((long long)n * C + c) * 2 + 1] = s2[i];
+            a += gam[i] * s1[i];
+            b += gam[i] * s2[i];
+        }
+    }
+    if (!EARLY) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            const int ec = e < cnt4 ? e : cnt4 - 1;
+            if (A1) t1[i] = a1b[ec];
+            if (A2) t2[i] = a2b[ec];
         }
     }
     const float invM = 1.0f / (float)(cpg * HW);
     a = dp_wave_sum(a) * invM;
     b = dp_wave_sum(b) * invM;
+    // ---- phase 2: dx (+ addends), its per-channel sums
     float4* dxb = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c_base * HW);
-    const float4* a1b = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c_base * HW) : nullptr;
-    const float4* a2b = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c_base * HW) : nullptr;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float r[NV];
 #pragma unroll
-    for (int i = 0; i < GN_WAVE_NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = lane + 64 * i;
         const bool live = e < cnt4;
-        const float4 t1 = (a1b && live) ? a1b[e] : zero4, t2 = (a2b && live) ? a2b[e] : zero4;
+        const float4 u1 = A1 ? t1[i] : zero4, u2 = A2 ? t2[i] : zero4;
         const float ga = gam[i];
         const float4 d = dv[i], h = xh[i];
         float4 v;
-        v.x = rstd * (ga * d.x - a - h.x * b) + t1.x + t2.x;
-        v.y = rstd * (ga * d.y - a - h.y * b) + t1.y + t2.y;
-        v.z = rstd * (ga * d.z - a - h.z * b) + t1.z + t2.z;
-        v.w = rstd * (ga * d.w - a - h.w * b) + t1.w + t2.w;
+        v.x = rstd * (ga * d.x - a - h.x * b) + u1.x + u2.x;
+        v.y = rstd * (ga * d.y - a - h.y * b) + u1.y + u2.y;
+        v.z = rstd * (ga * d.z - a - h.z * b) + u1.z + u2.z;
+        v.w = rstd * (ga * d.w - a - h.w * b) + u1.w + u2.w;
         if (live) dxb[e] = v;
-        if (rows) {
-            float r = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
-            for (int o = HW4 >> 1; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-            if (live && leader) rows[(long long)n * C + c_base + e / HW4] = r;
+        r[i] = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    }
+    if (rows) {
+        for (int o = HW4 >> 1; o > 0; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r[i] += __shfl_xor(r[i], o, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = lane + 64 * i;
+            if (e < cnt4 && leader) rows[(long long)n * C + c_base + (e >> lg4)] = r[i];
         }
     }
 }
@@ -704,18 +807,30 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
     const int HW4 = HW / 4;
     if (vec4 && !no_wave && HW4 >= 1 && HW4 <= 64 && (HW4 & (HW4 - 1)) == 0 && (long long)(C / G) * HW <= 256 * GN_WAVE_NV &&
         N * G >= 1024)
-        DP_LAUNCH(gn_bwd_wave_kernel, dim3((N * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
-                           dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                           pws, dd, rows, N * G);
+    {
+        const int cnt4 = (C / G) * HW4;
+#define GN_BWD_WAVE(NV_, A1_, A2_) DP_LAUNCH((gn_bwd_wave_kernel<NV_, A1_, A2_>), dim3((N * G + 3) / 4), dim3(256), 0,       \
+                                             (hipStream_t)stream, s, gamma, beta, stats, dz, dz_img_stride, C, HW, G, silu, dx,  \
+                                             dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, pws, dd, rows, N * G)
+#define GN_BWD_WAVE_A(NV_) do { if (add1 && add2) GN_BWD_WAVE(NV_, true, true); else if (add1) GN_BWD_WAVE(NV_, true, false);   \
+                                else if (add2) GN_BWD_WAVE(NV_, false, true); else GN_BWD_WAVE(NV_, false, false); } while (0)
+        if (cnt4 <= 64) GN_BWD_WAVE_A(1);
+        else if (cnt4 <= 128) GN_BWD_WAVE_A(2);
+        else if (cnt4 <= 256) GN_BWD_WAVE_A(4);
+        else GN_BWD_WAVE_A(8);
+#undef GN_BWD_WAVE_A
+#undef GN_BWD_WAVE
+    }
     else if (vec4 && HW4 <= 256 && C / G <= 8 && !getenv("DP_NO_GN_CACHE")) {
-        if (C / G <= 4)
-            DP_LAUNCH((gn_bwd_vec4c_kernel<1>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
-                               dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                               pws, dd, rows);
-        else
-            DP_LAUNCH((gn_bwd_vec4c_kernel<2>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
-                               dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
-                               pws, dd, rows);
+#define GN_BWD_C(NCH_, A1_, A2_) DP_LAUNCH((gn_bwd_vec4c_kernel<NCH_, A1_, A2_>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, s,  \
+                                           gamma, beta, stats, dz, dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1,           \
+                                           add1_img_stride, add2, add2_img_stride, pws, dd, rows)
+#define GN_BWD_C_A(NCH_) do { if (add1 && add2) GN_BWD_C(NCH_, true, true); else if (add1) GN_BWD_C(NCH_, true, false);              \
+                              else if (add2) GN_BWD_C(NCH_, false, true); else GN_BWD_C(NCH_, false, false); } while (0)
+        if (C / G <= 4) GN_BWD_C_A(1);
+        else GN_BWD_C_A(2);
+#undef GN_BWD_C_A
+#undef GN_BWD_C
     } else if (vec4)
         DP_LAUNCH(gn_bwd_vec4_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, s, gamma, beta, stats, dz,
                            dz_img_stride, C, HW, G, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride,
@@ -736,20 +851,43 @@ extern "C" int dp_groupnorm_silu_bwd(const float* x1, const float* x2, int c_spl
 //             apply -> dx
 // All vec4 (HW % 4 == 0, 16-byte aligned planes); slice length = HW / S floats, a multiple of 4.
 // ------------------------------------------------------------------------------------------------
+// Round 5: the slice (<= 1024 float4 for every slicing ops._gn_slices chooses) is read ONCE, four branch-free 16-byte loads per
+// thread in flight together (the loop form kept one load per wavefront outstanding and re-read the slice for the variance).
 __global__ __launch_bounds__(256) void gn_split_part_fwd_kernel(GnSrc src, int C, int HW, int S, float* __restrict__ part) {
     __shared__ float red[4];
     const int nc = blockIdx.x, sl = blockIdx.y;
     const int n = nc / C, c = nc - n * C;
     const int len4 = HW / S / 4;
     const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < len4; i += 256) { const float4 v = xp[i]; s += (v.x + v.y) + (v.z + v.w); }
-    const float mean = dp_block_sum_256(s, red) / (float)(len4 * 4);
-    float q = 0.f;
-    for (int i = threadIdx.x; i < len4; i += 256) {
-        const float4 v = xp[i];
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += (a * a + b * b) + (cc * cc + d * d);
+    float s = 0.f, q = 0.f, mean;
+    if (len4 <= 1024) {
+        float4 xr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            xr[k] = xp[i < len4 ? i : len4 - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (threadIdx.x + 256 * k >= len4) xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
+        }
+        mean = dp_block_sum_256(s, red) / (float)(len4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (threadIdx.x + 256 * k < len4) {
+                const float a = xr[k].x - mean, b = xr[k].y - mean, cc = xr[k].z - mean, d = xr[k].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < len4; i += 256) { const float4 v = xp[i]; s += (v.x + v.y) + (v.z + v.w); }
+        mean = dp_block_sum_256(s, red) / (float)(len4 * 4);
+        for (int i = threadIdx.x; i < len4; i += 256) {
+            const float4 v = xp[i];
+            const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
     }
     q = dp_block_sum_256(q, red);
     if (threadIdx.x == 0) {
@@ -789,14 +927,24 @@ __global__ __launch_bounds__(256) void gn_split_apply_fwd_kernel(GnSrc src, cons
     const int len4 = HW / S / 4;
     const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
     float4* yp = reinterpret_cast<float4*>(y + (long long)n * y_img_stride + (long long)c * HW) + (long long)sl * len4;
-    for (int i = threadIdx.x; i < len4; i += 256) {
-        const float4 v = xp[i];
-        float4 o;
-        o.x = (v.x - mean) * rstd * ga + be; o.y = (v.y - mean) * rstd * ga + be;
-        o.z = (v.z - mean) * rstd * ga + be; o.w = (v.w - mean) * rstd * ga + be;
-        if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
-        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-        yp[i] = o;
+    for (int i0 = threadIdx.x; i0 < len4; i0 += 1024) {          // four branch-free loads in flight per thread
+        float4 xr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            xr[k] = xp[i < len4 ? i : len4 - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            const float4 v = xr[k];
+            float4 o;
+            o.x = (v.x - mean) * rstd * ga + be; o.y = (v.y - mean) * rstd * ga + be;
+            o.z = (v.z - mean) * rstd * ga + be; o.w = (v.w - mean) * rstd * ga + be;
+            if (silu) { o.x = dp_silu(o.x); o.y = dp_silu(o.y); o.z = dp_silu(o.z); o.w = dp_silu(o.w); }
+            if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+            if (i < len4) yp[i] = o;
+        }
     }
 }
 
@@ -835,17 +983,31 @@ __global__ __launch_bounds__(256) void gn_split_part_bwd_kernel(GnSrc src, const
     const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + (long long)sl * len4;
     const float4* dp = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c * HW) + (long long)sl * len4;
     float a1 = 0.f, a2 = 0.f;
-    for (int i = threadIdx.x; i < len4; i += 256) {
-        const float4 xv = xp[i];
-        float4 d = dp[i];
-        const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
-        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
-        if (silu) {
-            d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
-            d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+    for (int i0 = threadIdx.x; i0 < len4; i0 += 1024) {          // eight branch-free loads in flight per thread (round 5)
+        float4 xr[4], dr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            const int ic = i < len4 ? i : len4 - 1;
+            xr[k] = xp[ic];
+            dr[k] = dp[ic];
         }
-        a1 += (d.x + d.y) + (d.z + d.w);
-        a2 += (d.x * hx + d.y * hy) + (d.z * hz + d.w * hw);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < len4) {
+                const float4 xv = xr[k];
+                float4 d = dr[k];
+                const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+                if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+                if (silu) {
+                    d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
+                    d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+                }
+                a1 += (d.x + d.y) + (d.z + d.w);
+                a2 += (d.x * hx + d.y * hy) + (d.z * hz + d.w * hw);
+            }
+        }
     }
     a1 = dp_block_sum_256(a1, red);
     a2 = dp_block_sum_256(a2, red);
@@ -878,6 +1040,7 @@ __global__ void gn_split_combine_bwd_kernel(const float* __restrict__ part, cons
     ab[(long long)i * 2 + 1] = b * invM;
 }
 
+template <bool A1, bool A2>
 __global__ __launch_bounds__(256) void gn_split_apply_bwd_kernel(GnSrc src, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ stats,
                                                                  const float* __restrict__ ab, const float* __restrict__ dz,
@@ -898,23 +1061,39 @@ __global__ __launch_bounds__(256) void gn_split_apply_bwd_kernel(GnSrc src, cons
     const float4* xp = reinterpret_cast<const float4*>(gn_chan_ptr(src, n, c, HW)) + off4;
     const float4* dp = reinterpret_cast<const float4*>(dz + (long long)n * dz_img_stride + (long long)c * HW) + off4;
     float4* op = reinterpret_cast<float4*>(dx + (long long)n * dx_img_stride + (long long)c * HW) + off4;
-    const float4* a1p = add1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c * HW) + off4 : nullptr;
-    const float4* a2p = add2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c * HW) + off4 : nullptr;
-    for (int i = threadIdx.x; i < len4; i += 256) {
-        const float4 xv = xp[i];
-        float4 d = dp[i];
-        const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
-        if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
-        if (silu) {
-            d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
-            d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+    const float4* a1p = A1 ? reinterpret_cast<const float4*>(add1 + (long long)n * add1_s + (long long)c * HW) + off4 : nullptr;
+    const float4* a2p = A2 ? reinterpret_cast<const float4*>(add2 + (long long)n * add2_s + (long long)c * HW) + off4 : nullptr;
+    // round 5: two slice positions per thread and round, every operand of both (x, dz, addends: up to eight 16-byte loads) in
+    // flight before the first use; the loop form waited for x / dz, then for add1, then for add2 -- three round trips per position
+    for (int i0 = threadIdx.x; i0 < len4; i0 += 512) {
+        float4 xr[2], dr[2], t1[2], t2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = i0 + 256 * k;
+            const int ic = i < len4 ? i : len4 - 1;
+            xr[k] = xp[ic];
+            dr[k] = dp[ic];
+            if (A1) t1[k] = a1p[ic];
+            if (A2) t2[k] = a2p[ic];
         }
-        float4 v;
-        v.x = rstd * (ga * d.x - a - hx * b); v.y = rstd * (ga * d.y - a - hy * b);
-        v.z = rstd * (ga * d.z - a - hz * b); v.w = rstd * (ga * d.w - a - hw * b);
-        if (a1p) { const float4 t = a1p[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        if (a2p) { const float4 t = a2p[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        op[i] = v;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = i0 + 256 * k;
+            const float4 xv = xr[k];
+            float4 d = dr[k];
+            const float hx = (xv.x - mean) * rstd, hy = (xv.y - mean) * rstd, hz = (xv.z - mean) * rstd, hw = (xv.w - mean) * rstd;
+            if (drop.thr24) { const float4 m = dp_drop4(drop, didx0 + 4ll * i); d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w; }
+            if (silu) {
+                d.x *= dp_silu_grad(hx * ga + be); d.y *= dp_silu_grad(hy * ga + be);
+                d.z *= dp_silu_grad(hz * ga + be); d.w *= dp_silu_grad(hw * ga + be);
+            }
+            float4 v;
+            v.x = rstd * (ga * d.x - a - hx * b); v.y = rstd * (ga * d.y - a - hy * b);
+            v.z = rstd * (ga * d.z - a - hz * b); v.w = rstd * (ga * d.w - a - hw * b);
+            if (A1) { const float4 t = t1[k]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (A2) { const float4 t = t2[k]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (i < len4) op[i] = v;
+        }
     }
 }
 
@@ -937,8 +1116,14 @@ extern "C" int dp_groupnorm_silu_bwd_split(const float* x1, const float* x2, int
                        C, HW, G, slices, silu, ws, dd);
     DP_LAUNCH(gn_split_combine_bwd_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, ws, gamma, N * G, G, C, slices, HW,
                        pws, ab);
-    DP_LAUNCH(gn_split_apply_bwd_kernel, dim3(N * C, slices), dim3(256), 0, st, s, gamma, beta, stats, ab, dz,
-                       dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1, add1_img_stride, add2, add2_img_stride, dd);
+#define GN_SPLIT_APPLY(A1_, A2_) DP_LAUNCH((gn_split_apply_bwd_kernel<A1_, A2_>), dim3(N * C, slices), dim3(256), 0, st, s, gamma,  \
+                                           beta, stats, ab, dz, dz_img_stride, C, HW, G, slices, silu, dx, dx_img_stride, add1,    \
+                                           add1_img_stride, add2, add2_img_stride, dd)
+    if (add1 && add2) GN_SPLIT_APPLY(true, true);
+    else if (add1) GN_SPLIT_APPLY(true, false);
+    else if (add2) GN_SPLIT_APPLY(false, true);
+    else GN_SPLIT_APPLY(false, false);
+#undef GN_SPLIT_APPLY
     return DP_LAUNCH_CHECK();
 }
 

@@ -240,23 +240,57 @@ __global__ __launch_bounds__(256, (BK == 16 || TM == 2) ? 3 : 4) void conv_wino_
     float* optr = p.out + (long long)img * p.o_img_stride + r_in;
     const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
     const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
+    // Eight rows at a time, and EVERY operand load of the eight (bias, per-image addend, residual, the accumulate read: up to 32
+    // loads) in flight before the first use.  Round 4's form -- a null test, a load and a wait per operand and row -- read on the ISA
+    // as 64 dependent memory round trips per wavefront behind a K loop of ~25 us (hipcc neither hoists a load out of its `if` nor
+    // over the store in front of it).  Rows >= M of a partial tile load from the last row and skip the store.  Same expressions
+    // and order per element.
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * (32 * TM) + 32 * t + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-        if (m >= p.M) continue;
-        float y0 = p.alpha * ((acc[t][0][r] + acc[t][1][r]) + acc[t][2][r]);
-        float y1 = p.alpha * ((acc[t][1][r] - acc[t][2][r]) - acc[t][3][r]);
-        if (p.bias) { const float b = p.bias[m]; y0 += b; y1 += b; }
-        if (tptr) { const float t = tptr[m]; y0 += t; y1 += t; }
-        if (rptr) { const float2 t = *reinterpret_cast<const float2*>(rptr + (long long)m * HW); y0 += t.x; y1 += t.y; }
-        y0 *= p.post_scale;
-        y1 *= p.post_scale;
-        if (p.act == 1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-        float2* o = reinterpret_cast<float2*>(optr + (long long)m * HW);
-        if (p.accumulate) { const float2 t = *o; y0 += t.x; y1 += t.y; }
-        *o = make_float2(y0, y1);
+    for (int h = 0; h < 2; ++h) {
+        int mc[8];
+        float tb[8], tt[8];
+        float2 tr[8], tp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * h + q;
+            const int m = m0 + wr * (32 * TM) + 32 * t + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+            mc[q] = m < p.M ? m : p.M - 1;
+            tb[q] = tt[q] = 0.f;
+            tr[q] = tp[q] = make_float2(0.f, 0.f);
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tb[q] = p.bias[mc[q]];
+        }
+        if (tptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tt[q] = tptr[mc[q]];
+        }
+        if (rptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tr[q] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q] * HW);
+        }
+        if (p.accumulate) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tp[q] = *reinterpret_cast<const float2*>(optr + (long long)mc[q] * HW);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * h + q;
+            const int m = m0 + wr * (32 * TM) + 32 * t + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+            float y0 = p.alpha * ((acc[t][0][r] + acc[t][1][r]) + acc[t][2][r]);
+            float y1 = p.alpha * ((acc[t][1][r] - acc[t][2][r]) - acc[t][3][r]);
+            if (p.bias) { y0 += tb[q]; y1 += tb[q]; }
+            if (tptr) { y0 += tt[q]; y1 += tt[q]; }
+            if (rptr) { y0 += tr[q].x; y1 += tr[q].y; }
+            y0 *= p.post_scale;
+            y1 *= p.post_scale;
+            if (p.act == 1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+            if (p.accumulate) { y0 += tp[q].x; y1 += tp[q].y; }
+            if (m < p.M) *reinterpret_cast<float2*>(optr + (long long)m * HW) = make_float2(y0, y1);
+        }
     }
 }
 

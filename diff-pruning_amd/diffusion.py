@@ -313,6 +313,22 @@ class _PipelineBase:
         return [Image.fromarray(a) for a in arr]
 
 
+def _sampling_forward(unet, shape, n_calls):
+    """`f(sample, t) -> eps` for a sampling loop: the model's own captured / pinned forward (UNet2DModel.sampling_forward) or, for
+    a foreign model object, a plain call."""
+    sf = getattr(unet, 'sampling_forward', None)
+    if sf is not None:
+        return sf(shape, n_calls)
+
+    class _Plain:
+        def __call__(self, sample, t):
+            return unet(sample, t).sample
+
+        def close(self):
+            pass
+    return _Plain()
+
+
 def _image_shape(unet, batch_size):
     ss = unet.config.sample_size
     return (batch_size, unet.config.in_channels) + ((ss, ss) if isinstance(ss, int) else tuple(ss))
@@ -334,12 +350,17 @@ class DDPMPipeline(_PipelineBase):
 
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, output_type='pil', return_dict=True):
-        image = randn_tensor(_image_shape(self.unet, batch_size), generator=generator, device=self.device)
+        shape = _image_shape(self.unet, batch_size)
+        image = randn_tensor(shape, generator=generator, device=self.device)
         self.scheduler.set_timesteps(num_inference_steps)
-        with self.unet.pin_weights():                       # sampling never writes weights: pack the operands once
-            for t in self.progress_bar(self.scheduler.timesteps):
-                model_output = self.unet(image, t).sample
+        ts = [int(t) for t in self.scheduler.timesteps.tolist()]              # one read-back instead of one per step
+        fwd = _sampling_forward(self.unet, shape, len(ts))  # weights pinned; the forward replayed natively where it pays
+        try:
+            for t in self.progress_bar(ts):
+                model_output = fwd(image, t)
                 image = self.scheduler.step(model_output, t, image, generator=generator).prev_sample
+        finally:
+            fwd.close()
         return _to_output(self, image, output_type, return_dict)
 
 
@@ -359,8 +380,12 @@ class DDIMPipeline(_PipelineBase):
                              % (len(generator), batch_size))
         image = randn_tensor(shape, generator=generator, device=self.device, dtype=self.unet.dtype)
         self.scheduler.set_timesteps(num_inference_steps)
-        with self.unet.pin_weights():                       # sampling never writes weights: pack the operands once
-            for t in self.progress_bar(self.scheduler.timesteps):
-                model_output = self.unet(image, t).sample
+        ts = [int(t) for t in self.scheduler.timesteps.tolist()]
+        fwd = _sampling_forward(self.unet, shape, len(ts))
+        try:
+            for t in self.progress_bar(ts):
+                model_output = fwd(image, t)
                 image = self.scheduler.step(model_output, t, image, eta=eta, generator=generator).prev_sample
+        finally:
+            fwd.close()
         return _to_output(self, image, output_type, return_dict)

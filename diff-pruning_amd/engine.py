@@ -177,13 +177,18 @@ class UNetEngine:
         self.P = params
         self.G = grads
 
-    def set_dropout(self, table, seed=0, step=0, n_off=0):
+    def set_dropout(self, table, seed=0, step=0, n_off=0, step_dev=None):
+        """step_dev: data_ptr of a device uint32 the kernels read instead of `step` (train.FinetuneEngine's replayed step)."""
         self.dropout = table if table else None
         self.drop_seed, self.drop_step, self.drop_n_off = seed, step, n_off
+        self.drop_step_dev = step_dev
 
     def _drop(self, site):
         if not self.dropout:
             return None
+        sd = getattr(self, 'drop_step_dev', None)
+        if sd is not None:
+            return ops.dropout_desc(self.dropout.get(site, 0.0), self.drop_seed, site, self.drop_step, self.drop_n_off, step_dev=sd)
         return ops.dropout_desc(self.dropout.get(site, 0.0), self.drop_seed, site, self.drop_step, self.drop_n_off)
 
     def _colsum(self, ws, N, C, wstride, woff, out):

@@ -903,8 +903,9 @@ def _gn_slices(N, G, HW, tensors, strides):
     return s
 
 
-def dropout_desc(p, seed, site, step, n_off=0):
-    """dp_dropout descriptor (include/dp_hip.h) or None when p == 0.  `site`: layer name (hashed with crc32) or an int."""
+def dropout_desc(p, seed, site, step, n_off=0, step_dev=None):
+    """dp_dropout descriptor (include/dp_hip.h) or None when p == 0.  `site`: layer name (hashed with crc32) or an int.
+    step_dev: a device uint32 the kernels read INSTEAD of `step` (replayed finetune steps: see step_scalars)."""
     if not p:
         return None
     if not 0.0 < p < 1.0:
@@ -917,6 +918,7 @@ def dropout_desc(p, seed, site, step, n_off=0):
     d.site = (zlib.crc32(site.encode()) if isinstance(site, str) else int(site)) & 0xFFFFFFFF
     d.step = int(step) & 0xFFFFFFFF
     d.n_off = int(n_off)
+    d.step_dev = None if step_dev is None else int(step_dev)
     return d
 
 
@@ -1278,6 +1280,20 @@ def adam_ema(p_, g, m, v, ema, coef, lr, b1, b2, eps, step, ema_decay):
                                ema_decay, _stream()), 'dp_adam_ema')
 
 
+def set_step_scalars(hyper, lr, b1, b2, step):
+    """hyper (device, 4 floats) <- {lr, 1 - b1^step, 1 - b2^step, step as uint32}: the one launch of a replayed finetune step that
+    carries the per-step scalars by value (include/dp_hip.h dp_set_step_scalars)."""
+    assert hyper.is_cuda and hyper.dtype == _f32 and hyper.numel() >= 4 and hyper.is_contiguous()
+    L.check(_lib().dp_set_step_scalars(_p(hyper), lr, 1.0 - b1 ** step, 1.0 - b2 ** step, int(step) & 0xFFFFFFFF, _stream()),
+            'dp_set_step_scalars')
+
+
+def adam_ema_dev(p_, g, m, v, ema, coef, hyper, b1, b2, eps, ema_decay):
+    """adam_ema with {lr, bc1, bc2} read from the device buffer set_step_scalars fills."""
+    L.check(_lib().dp_adam_ema_dev(_p(p_), _p(g), _p(m), _p(v), _p(ema), p_.numel(), _p(coef), _p(hyper), b1, b2, eps, ema_decay,
+                                   _stream()), 'dp_adam_ema_dev')
+
+
 def ddim_step(x, eps, a_t, a_prev, std=0.0, vnoise=None, clip=True, out=None, clip_range=1.0):
     if out is None:
         out = torch.empty_like(x)
@@ -1396,3 +1412,45 @@ class ReplayList:
                 self.handle = None
         except Exception:
             pass
+
+
+class CapturedCall:
+    """`fn()` recorded once by a HIP stream capture and re-issued from the library's C loop (ReplayList) -- the host side of a
+    launch-bound step without Python / ctypes per launch.  `fn` must only enqueue work (no host read-back), read its inputs from
+    tensors that outlive the capture (static buffers the caller refills before every `launch()`), and have run once eagerly
+    (code objects loaded, packed operands and lazily created streams in place).  `result` is whatever `fn` returned inside the
+    capture: tensors of the graph's private pool, overwritten by every launch.
+    A captured step that forks onto the engine's weight-gradient stream replays onto `side_stream`; a capture whose nodes the
+    list cannot re-issue (hipErrorNotSupported) falls back to hipGraphLaunch."""
+
+    def __init__(self, fn, side_stream=None):
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph(keep_graph=True)
+            native = True
+        except TypeError:                              # a torch without keep_graph: no raw graph to read back
+            g, native = torch.cuda.CUDAGraph(), False
+        with torch.cuda.graph(g):
+            self.result = fn()
+        self.graph, self.replay, self.side_stream = g, None, side_stream
+        if native:
+            try:
+                self.replay = ReplayList(g)
+            except L.DpHipError as e:
+                if e.code != 801:                      # anything but hipErrorNotSupported is a real error of the build
+                    raise
+                import warnings
+                warnings.warn('native replay refused the captured step (a node it cannot re-issue): falling back to hipGraphLaunch')
+                g.instantiate()
+
+    @property
+    def info(self):
+        return self.replay.info if self.replay is not None else {}
+
+    def launch(self):
+        if self.replay is not None:
+            self.replay.launch(self.side_stream)
+        else:
+            self.graph.replay()
+        return self.result
+

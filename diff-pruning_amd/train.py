@@ -136,9 +136,17 @@ def _require_hip_device(dev):
 
 class FinetuneEngine:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, ema_decay=0.9999, max_grad_norm=1.0,
-                 use_ema=True, group=None, dropout=None, lr_scheduler=None, dropout_seed=0):
+                 use_ema=True, group=None, dropout=None, lr_scheduler=None, dropout_seed=0, replay=None):
         """dropout: None keeps whatever `set_dropout(model, p)` has set on the nn.Dropout holders; a float sets it.
-        lr_scheduler: a `LambdaLR` from `get_scheduler` (its base_lr is the learning rate) or None (constant `lr`)."""
+        lr_scheduler: a `LambdaLR` from `get_scheduler` (its base_lr is the learning rate) or None (constant `lr`).
+        replay: True / False / None (automatic: single-process steps on a cuda device, DP_FINETUNE_REPLAY=0 disables) -- the step is
+        stream-captured ONCE (second call; the first runs eagerly) and afterwards re-issued from the library's C loop
+        (ops.CapturedCall): ~750 launches without Python / ctypes per launch.  What changes from step to step lives on the device:
+        inputs and timesteps in static buffers, {lr, Adam bias corrections, optimizer step (= the dropout masks' step)} in a
+        4-word buffer written by ONE by-value launch per step (ops.set_step_scalars); the weight re-packing is part of the
+        captured step.  Same kernels, arguments and order as the eager step -> the same bits."""
+        self.replay = replay
+        self._cap = None
         if dropout is not None:
             set_dropout(model, float(dropout))
         self.model, self.scheduler = model, scheduler
@@ -210,6 +218,74 @@ class FinetuneEngine:
         self._stash = None
         self._weights_changed()
 
+    REPLAY_OVERLAP = None        # weight-gradient side stream inside the captured step: None = the engine's own rule (by step size)
+
+    def _replay_wanted(self, use_dist, dev):
+        import os
+        if use_dist or dev.type != 'cuda' or getattr(ops, 'IS_MOCK', False) or not hasattr(ops, 'CapturedCall'):
+            return False                                 # the data-parallel step interleaves collectives with the backward pass
+        if self.replay is None:
+            return os.environ.get('DP_FINETUNE_REPLAY', '1') != '0'
+        return bool(self.replay)
+
+    def _step_replayed(self, clean, noise, timesteps, gb, image_offset):
+        """One optimizer step through the captured step (built on first use for this batch shape)."""
+        import os
+        model, dev = self.model, self.flat_p.device
+        table = getattr(model, 'dropout_table', dict)()
+        key = (tuple(clean.shape), int(image_offset), int(gb), tuple(sorted(table.items())))
+        cap = self._cap
+        if cap is None or cap['key'] != key:
+            hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+            st = dict(key=key, hyper=hyper, clean=ops.empty_act(tuple(clean.shape), dev), noise=ops.empty_act(tuple(noise.shape), dev),
+                      t=torch.zeros(clean.shape[0], dtype=torch.long, device=dev))
+            eng = model.engine()
+            P = {n: p.detach() for n, p in model.named_parameters()}
+            G = {n: p.grad for n, p in model.named_parameters()}
+            ov = os.environ.get('DP_FINETUNE_REPLAY_OVERLAP')
+            overlap = self.REPLAY_OVERLAP if ov is None else (ov != '0')
+
+            def body():
+                eng.bind(P, G)
+                eng.set_dropout(table, self.dropout_seed, 0, image_offset, step_dev=hyper.data_ptr() + 12)
+                if overlap is not None:
+                    eng.overlap_wgrad = overlap
+                eng.prepare_packs()                       # the optimizer update of the previous replay invalidated every operand
+                noisy = ops.add_noise(st['clean'], st['noise'], self.acp, st['t'])
+                self.flat_g.zero_()
+                out = eng.forward(noisy, st['t'], save=True)
+                loss, dout = ops.mse_fwd_bwd(out, st['noise'], 2.0 / gb, 1.0 / gb)
+                eng.backward(dout)
+                nc = ops.clip_coef(ops.sumsq_partials(self.flat_g), self.max_grad_norm)
+                ops.adam_ema_dev(self.flat_p, self.flat_g, self.m, self.v, self.ema, nc[1:2], hyper, self.betas[0], self.betas[1],
+                                 self.eps, self.ema_decay)
+                eng.packs.clear()                         # host bookkeeping: nothing packed here outlives the step
+                return loss, nc
+            saved_overlap = eng.overlap_wgrad
+            try:
+                st['call'] = ops.CapturedCall(body, side_stream=eng.replay_side_stream(dev))
+            finally:
+                eng.overlap_wgrad = saved_overlap
+                eng.set_dropout(None)
+            self._cap = cap = st
+        if clean.data_ptr() != cap['clean'].data_ptr():
+            cap['clean'].copy_(clean)
+        if noise.data_ptr() != cap['noise'].data_ptr():
+            cap['noise'].copy_(noise)
+        cap['t'].copy_(timesteps)
+        self.step_count += 1
+        lr = self.lr_scheduler.get_last_lr()[0] if self.lr_scheduler is not None else self.lr
+        self.last_lr = lr
+        ops.set_step_scalars(cap['hyper'], lr, self.betas[0], self.betas[1], self.step_count)
+        loss, nc = cap['call'].launch()
+        self.last_grad_norm = nc[0:1]
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()                       # ddpm_train.py:464
+        eng = getattr(model, '_engine', None)
+        if eng is not None:
+            eng.packs.clear()
+        return loss.clone()                                # the captured tensor is overwritten by the next step
+
     def step(self, clean, noise, timesteps, global_batch=None, image_offset=None):
         """Returns the (local share of the) loss as a [1] device tensor; no host synchronisation.
         image_offset: global index of this rank's first image (default rank * B): the dropout masks are functions of the
@@ -223,6 +299,9 @@ class FinetuneEngine:
         model = self.model
         model.train()                                     # ddpm_train.py:430
         dev = self.flat_p.device
+        if self.step_count >= 1 and self._replay_wanted(use_dist, dev):     # the first step runs eagerly (lazy operands, streams)
+            return self._step_replayed(clean.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
+                                       timesteps.to(device=dev, dtype=torch.long).contiguous(), gb, image_offset)
         clean = clean.to(dev, torch.float32).contiguous()
         noise = noise.to(dev, torch.float32).contiguous()
         eng = model.engine()

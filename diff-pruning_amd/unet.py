@@ -274,6 +274,20 @@ class UNet2DModel(nn.Module):
         """Context manager: the weights are frozen inside the block (sweep, sampling loop) -> keep the packed operands."""
         return _PinnedWeights(self)
 
+    def sampling_forward(self, shape, n_calls, replay=None):
+        """The no-grad forward of a sampling loop (pipeline_ddim.py:101-116, pipeline_ddpm.py:87-96) as a callable
+        `f(sample, t: int) -> eps` plus `f.close()`.  The weights are frozen for the lifetime of `f` (`pin_weights`).
+        With `replay` (default: automatic -- a cuda model in eval mode without foreign forward hooks, called at least
+        REPLAY_MIN_CALLS times; DP_SAMPLE_REPLAY=0 disables) the forward is captured ONCE at `shape` and every call re-issues its
+        ~180 launches from the library's C loop (ops.CapturedCall, csrc/replay.hip): same kernels, same arguments, same order ->
+        the same bits as the eager call, without ~10 ms of Python / ctypes per UNet forward."""
+        import os
+        if replay is None:
+            replay = (os.environ.get('DP_SAMPLE_REPLAY', '1') != '0' and n_calls >= REPLAY_MIN_CALLS and not self.training
+                      and self.conv_in.weight.device.type == 'cuda' and self._leaf_hook_owner() is None
+                      and not self.__dict__.get('_structure_tracing') and hasattr(torch.cuda, 'CUDAGraph'))
+        return _CapturedForward(self, shape) if replay else _EagerForward(self)
+
     def _timesteps(self, sample, timestep):
         t = timestep
         if not torch.is_tensor(t):
@@ -431,6 +445,60 @@ class UNet2DModel(nn.Module):
         if not return_dict:
             return (out,)
         return UNet2DOutput(sample=out)
+
+
+REPLAY_MIN_CALLS = 8          # a capture costs about two eager forwards
+
+
+class _EagerForward:
+    def __init__(self, model):
+        self.model = model
+        self._pin = model.pin_weights()                    # sampling never writes weights: pack the operands once
+        self._pin.__enter__()
+
+    def __call__(self, sample, t):
+        return self.model(sample, t).sample
+
+    def close(self):
+        if self._pin is not None:
+            self._pin.__exit__(None, None, None)
+            self._pin = None
+
+
+class _CapturedForward:
+    """One captured no-grad forward at a fixed [B, C, H, W], replayed natively (UNet2DModel.sampling_forward)."""
+
+    def __init__(self, model, shape):
+        from . import ops
+        self.model = model
+        self._pin = model.pin_weights()
+        self._pin.__enter__()
+        try:
+            dev = model.device
+            eng = self._pin.eng
+            self.x = ops.empty_act(tuple(shape), dev)
+            self.x.zero_()
+            self.t = torch.zeros(shape[0], dtype=torch.long, device=dev)
+            with torch.no_grad():
+                eng.forward(self.x, self.t, save=False)              # eager once: code objects, Winograd operands asked for
+                eng.prepare_packs()                                  # nothing is packed inside the capture
+                self.call = ops.CapturedCall(lambda: eng.forward(self.x, self.t, save=False))
+        except BaseException:
+            self.close()
+            raise
+
+    def __call__(self, sample, t):
+        self.x.copy_(sample)
+        if torch.is_tensor(t) and t.dim() > 0 and t.numel() > 1:
+            self.t.copy_(t)
+        else:
+            self.t.fill_(int(t))
+        return self.call.launch()          # a tensor of the capture's pool: valid until the next call
+
+    def close(self):
+        if self._pin is not None:
+            self._pin.__exit__(None, None, None)
+            self._pin = None
 
 
 class _StructureTracing:

@@ -135,6 +135,8 @@ int dp_pack_weight(const float* W, int Co, int Ci, int taps, int mode, float* ds
  * image (masks do not depend on how the batch is sharded over ranks). */
 typedef struct dp_dropout {
     unsigned thr24; float scale; unsigned long long seed; unsigned site; unsigned step; long long n_off;
+    const unsigned* step_dev;   /* optional DEVICE counter read instead of `step`: a captured / replayed finetune step must not bake
+                                 * the optimizer step into its kernel arguments (dp_set_step_scalars writes it) */
 } dp_dropout;
 
 /* Standalone forms: y[i] = x[i] * m(i) (in place allowed; forward and backward are the same map), and the bare mask
@@ -324,6 +326,13 @@ int dp_slice_batch(const dp_slice_item* items, int n, const int64_t* keep, void*
 /* Fused finetune update over flat buffers (ddpm_train.py:462-469, training_utils.py:201-216):
  *   g *= clip_coef (clip_coef read from device: min(1, max_norm/(norm+1e-6)));  Adam;  EMA with constant decay. */
 int dp_sumsq_partials(const float* x, long long n, float* partial, int nblocks, void* stream);
+/* The per-step scalars of a REPLAYED finetune step live on the device: hyper[0..2] = {lr, bc1 = 1 - b1^step, bc2 = 1 - b2^step}
+ * (floats, the values the host computes for dp_adam_ema), hyper[3] = the optimizer step as an unsigned (the dropout masks'
+ * `step`, read through dp_dropout.step_dev).  dp_set_step_scalars is the ONE launch per step that carries them by value;
+ * dp_adam_ema_dev is dp_adam_ema reading {lr, bc1, bc2} from hyper.  (ddpm_train.py:462-469; LR schedule: optimization.py:282) */
+int dp_set_step_scalars(float* hyper, float lr, float bc1, float bc2, unsigned step, void* stream);
+int dp_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* clip_coef,
+                    const float* hyper, float b1, float b2, float eps, float ema_decay, void* stream);
 int dp_clip_coef(const float* partial, int n, float max_norm, float* norm_out, float* coef_out, void* stream);
 int dp_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* clip_coef,
                 float lr, float b1, float b2, float eps, float bc1, float bc2, float ema_decay, void* stream);

@@ -108,7 +108,7 @@ def main():
                                          latent_shape=(3, 16, 16), class_rng=random.Random(3), seed=11)
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
     out['uneven'] = dict(losses=res['losses'], steps=res['steps'], accumulated=res['accumulated'], shard=res['shard'],
-                         grads=grads, masks=masks_of(model))
+                         grads=grads, masks=masks_of(model), sampler_rows=res['sampler_rows'])
     torch.save(out, os.path.join(outdir, 'ldm_r%d_w%d.pt' % (rank, world)))
     if world > 1:
         dist.barrier()

@@ -94,6 +94,19 @@ def run_all(forced):
                                          class_rng=random.Random(3), seed=11)
     torch.cuda.synchronize()
     out['ldm'] = dict(steps=res['steps'], accumulated=res['accumulated'], losses=res['losses'], grads=res['flat_grads'].clone())
+    if forced:
+        # (4b) round 5: the sampler sharded by CFG rows (what 4 ranks x 6 latents run: 3 rows each) -- here the one rank owns all
+        # 2 n rows, so every DDIM step's eps exchange goes through RCCL and the result must equal the latent-split pass closely
+        # (row-batched forwards instead of the shared-stem CFG pair: fp32 re-association only)
+        lm2 = ldm.UNetModel(**lcfg)
+        gc.det_init_(lm2, 9)
+        lm2 = lm2.to(DEV).eval()
+        res2 = ldm_sweep.ldm_importance_sweep(lm2, emb, num_steps=4, thr=0.5, n_samples=3, ddim_steps=4, latent_shape=(3, 16, 16),
+                                              class_rng=random.Random(3), seed=11, sampler_shard='rows')
+        torch.cuda.synchronize()
+        assert tuple(res2['sampler_rows']) == (0, 6)
+        out['ldm_rows'] = dict(steps=res2['steps'], accumulated=res2['accumulated'], losses=res2['losses'],
+                               grads=res2['flat_grads'].clone())
     # (5) FID statistics: all_gather of the has-data flags, broadcast of the shift, ONE all-reduce of (n, s1, s2)
     st = metrics.FeatureStats(24, torch.device(DEV))
     feats = torch.from_numpy(np.random.default_rng(4).standard_normal((40, 24)).astype(np.float32)).to(DEV)
@@ -154,6 +167,10 @@ def main():
     same('finetune/ema', forced['finetune']['ema'], plain['finetune']['ema'], exact=False, tol=1e-6)
     for k in ('steps', 'accumulated', 'losses', 'grads'):
         same('ldm/' + k, forced['ldm'][k], plain['ldm'][k])
+    same('ldm_rows/steps', forced['ldm_rows']['steps'], plain['ldm']['steps'])
+    same('ldm_rows/accumulated', forced['ldm_rows']['accumulated'], plain['ldm']['accumulated'])
+    same('ldm_rows/losses', torch.tensor(forced['ldm_rows']['losses']), torch.tensor(plain['ldm']['losses']), exact=False, tol=1e-5)
+    same('ldm_rows/grads', forced['ldm_rows']['grads'], plain['ldm']['grads'], exact=False, tol=5e-5)
     assert forced['fid']['reduced'] and not plain['fid']['reduced']
     same('fid/mu', forced['fid']['mu'], plain['fid']['mu'], exact=False, tol=1e-9)
     same('fid/sigma', forced['fid']['sigma'], plain['fid']['sigma'], exact=False, tol=1e-9)

@@ -1051,6 +1051,56 @@ def test_conv_splitk_fold_under_concurrent_streams(ops, report, monkeypatch):
     assert n_bad == 0
 
 
+@pytest.mark.parametrize('taps,mc,splits,acc', [(9, 192 * 192, 28, True), (9, 96 * 179, 3, False), (4, 256 * 256, 9, True), (9, 37, 1, True),
+                                                (4, 1000, 64, False)], ids=str)
+def test_splitk_reduction_kernels_round5_equal_scalar_forms(ops, report, monkeypatch, taps, mc, splits, acc):
+    """Round 5 rewrote the split-K reduction launches for memory-level parallelism (one thread per (m, c) with all taps and 36
+    loads in flight; four pixels per thread in the convolution epilogue): per element they perform the additions of the scalar
+    forms in the same order, so the outputs must be BIT-identical (DP_NO_REDUCE_MC / DP_NO_EPI4 select the scalar forms)."""
+    import ctypes as C
+    lib = ops._lib()
+    ws = rnd(splits, taps, mc, seed=3)
+    base = rnd(mc * taps, seed=4)
+    outs = []
+    for env in (None, '1'):
+        if env is None:
+            monkeypatch.delenv('DP_NO_REDUCE_MC', raising=False)
+        else:
+            monkeypatch.setenv('DP_NO_REDUCE_MC', env)
+        out = base.clone()
+        assert lib.dp_splitk_reduce_taps(C.c_void_p(ws.data_ptr()), taps * mc, splits, C.c_void_p(out.data_ptr()), mc, taps,
+                                         1 if acc else 0, ops._stream()) == 0
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = ws.double().sum(0).view(taps, mc).t().reshape(-1) + (base.double() if acc else 0)
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(outs[0], ref) < 1e-5
+
+
+@pytest.mark.parametrize('N,C,Cout,H', [(12, 960, 960, 8), (6, 576, 384, 16), (4, 192, 200, 8)], ids=str)
+def test_conv_splitk_epilogue4_equals_scalar_epilogue(ops, monkeypatch, N, C, Cout, H):
+    """dp_conv_splitk_epilogue with four pixels per thread against the one-element form: bit-identical with every epilogue operand."""
+    import os
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    x, w = rnd(N, C, H, H, seed=1), rnd(Cout, C, 3, 3, seed=2, scale=0.02)
+    b, tadd, res = rnd(Cout, seed=4), rnd(N, Cout, seed=6), rnd(N, Cout, H, H, seed=7)
+    wp, ld = ops.pack_weight(w, 0)
+    monkeypatch.setattr(ops, 'SPLITK_FOLD', False)                 # the reduction launch, not the in-kernel fold
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 1 << 30)
+    got = []
+    for env in (None, '1'):
+        if env is None:
+            monkeypatch.delenv('DP_NO_EPI4', raising=False)
+        else:
+            monkeypatch.setenv('DP_NO_EPI4', env)
+        y = ops.conv_forward(x, None, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, relu=True)
+        acc = res.clone()
+        ops.conv_forward(x, None, wp, ld, Cout, spec, out=acc, accumulate=True)
+        got.append((y.clone(), acc))
+    torch.cuda.synchronize()
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
 def test_pack_weight_batch_equals_per_layer_pack(ops):
     """dp_pack_weight_batch (every layer of a finetune step in a few launches) against dp_pack_weight, element for element:
     3x3 / 1x1 convolutions and a Linear, both operand layouts, widths that need the ld padding (90 -> 92)."""

@@ -20,8 +20,11 @@ def timeit(fn, iters=20, warm=3):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tot_f = tot_b = 0.0
-for C, H, cnt in ((128, 32, 8), (256, 32, 2), (384, 32, 1), (128, 16, 1), (256, 16, 6), (384, 16, 1), (512, 16, 2), (256, 8, 7),
-                  (512, 8, 3), (256, 4, 11), (512, 4, 3)):
+CIFAR = ((128, 32, 8), (256, 32, 2), (384, 32, 1), (128, 16, 1), (256, 16, 6), (384, 16, 1), (512, 16, 2), (256, 8, 7),
+         (512, 8, 3), (256, 4, 11), (512, 4, 3))
+BEDROOM = ((128, 256, 10), (256, 256, 2), (128, 128, 8), (256, 128, 4), (256, 64, 12), (512, 64, 3), (256, 32, 12), (512, 32, 3),
+           (512, 16, 14), (1024, 16, 3), (512, 8, 12), (1024, 8, 3))     # python tools/bench_gn.py 4 bedroom: the split kernels
+for C, H, cnt in (BEDROOM if len(sys.argv) > 2 and sys.argv[2] == 'bedroom' else CIFAR):
     x = ops.empty_act((B, C, H, H), 'cuda'); x.normal_()
     dz = ops.empty_act((B, C, H, H), 'cuda'); dz.normal_()
     add = ops.empty_act((B, C, H, H), 'cuda'); add.normal_()
