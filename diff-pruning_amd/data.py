@@ -7,7 +7,8 @@ per-pixel work on the device.
                      image folders = Resize(256) + RandomCrop(256) + the same three
   ddpm_exp/datasets/__init__.py:30-60,176-192   Resize + flip + ToTensor, then data_transform (uniform dequantization, 2x - 1)
   ddpm_exp/datasets/__init__.py:60-152, celeba.py:50-139   config-driven datasets -> dataset_from_config (CIFAR10, CELEBA: split
-                     file, 128 x 128 crop window, resize; LSUN / FFHQ are LMDB databases: refused, lmdb is not in this environment)
+                     file, 128 x 128 crop window, resize); LSUN / FFHQ (datasets/lsun.py, ffhq.py: LMDB environments) -> Lsun / FfhqLmdb over
+                     lmdb_reader.Environment, a pure-Python reader of the data.mdb format
   utils.py:41-49     CIFAR-100              -> Cifar100Batches
   ddpm_train.py:313-318   DataLoader(shuffle=True)  -> DeviceLoader
 
@@ -122,6 +123,131 @@ class CelebAAligned:
         img = img.crop(CELEBA_WINDOW)
         if img.size != (self.image_size, self.image_size):
             img = img.resize((self.image_size, self.image_size), Image.BILINEAR)
+        return np.asarray(img, dtype=np.uint8)
+
+
+def center_crop(size):
+    """transforms.CenterCrop(size) on a PIL image (the image is at least `size` on both sides after Resize(size)): torchvision's
+    rounding, top = round((h - size) / 2), left = round((w - size) / 2)."""
+    def f(img):
+        w, h = img.size
+        left, top = int(round((w - size) / 2.0)), int(round((h - size) / 2.0))
+        return img.crop((left, top, left + size, top + size))
+    return f
+
+
+LSUN_CATEGORIES = ('bedroom', 'bridge', 'church_outdoor', 'classroom', 'conference_room', 'dining_room', 'kitchen', 'living_room',
+                   'restaurant', 'tower')
+
+
+class LsunClassLmdb:
+    """One `<category>_<split>_lmdb` environment of LSUN (ddpm_exp/datasets/lsun.py:11-52): values are encoded images, the item
+    order is the key order of the environment -- cached, as the reference caches it, in the pickle `_cache_<dir name>` next to the
+    directory.  Items are uint8 HWC arrays after `transform` (PIL -> PIL).  Read through lmdb_reader.Environment."""
+
+    def __init__(self, root, transform=None):
+        from .lmdb_reader import Environment
+        self.root, self.transform = root, transform
+        self.env = Environment(root)
+        self.length = self.env.stat()['entries']
+        parts = root.rstrip('/').split('/')
+        cache_file = os.path.join('/'.join(parts[:-1]), '_cache_' + parts[-1])
+        if os.path.isfile(cache_file):
+            with open(cache_file, 'rb') as f:
+                self.keys = pickle.load(f)
+        else:
+            self.keys = self.env.keys()
+            try:
+                with open(cache_file, 'wb') as f:
+                    pickle.dump(self.keys, f)
+            except OSError:
+                pass                                    # a read-only dataset directory: the key walk is repeated next time
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        import io
+        from PIL import Image
+        buf = self.env.get(self.keys[idx])
+        if buf is None:
+            raise KeyError(self.keys[idx])
+        img = Image.open(io.BytesIO(buf)).convert('RGB')
+        if self.transform is not None:
+            img = self.transform(img)
+        return np.asarray(img, dtype=np.uint8)
+
+
+class Lsun:
+    """ddpm_exp/datasets/lsun.py:55-173: `classes` is 'train' / 'val' (every category), 'test', or a list such as
+    ['bedroom_train']; item i belongs to the first class database whose cumulative length exceeds i.  The category label the
+    reference returns next to the image is discarded by the diffusion runners and not produced here."""
+
+    def __init__(self, root, classes='train', transform=None):
+        self.classes = self._verify_classes(classes)
+        self.dbs = [LsunClassLmdb(root + '/' + c + '_lmdb', transform) for c in self.classes]
+        self.indices, count = [], 0
+        for db in self.dbs:
+            count += len(db)
+            self.indices.append(count)
+        self.length = count
+
+    @staticmethod
+    def _verify_classes(classes):
+        splits = ('train', 'val', 'test')
+        if isinstance(classes, str):
+            if classes not in splits:
+                raise ValueError("Unknown value '%s' for argument classes. Valid values are {%s}." % (classes, ', '.join(splits)))
+            return [classes] if classes == 'test' else [c + '_' + classes for c in LSUN_CATEGORIES]
+        out = list(classes)
+        for c in out:
+            if not isinstance(c, str):
+                raise ValueError('Expected type str for elements in argument classes, but got type %s.' % type(c))
+            category, _, split = c.rpartition('_')
+            if category not in LSUN_CATEGORIES:
+                raise ValueError("Unknown value '%s' for LSUN class. Valid values are {%s}." % (category, ', '.join(LSUN_CATEGORIES)))
+            if split not in splits:
+                raise ValueError("Unknown value '%s' for postfix. Valid values are {%s}." % (split, ', '.join(splits)))
+        return out
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        sub, which = 0, 0
+        for ind in self.indices:
+            if index < ind:
+                break
+            which += 1
+            sub = ind
+        return self.dbs[which][index - sub]
+
+
+class FfhqLmdb:
+    """ddpm_exp/datasets/ffhq.py:8-40: one environment holding every resolution; `length` under the key b'length', image i of
+    resolution r under b'<r>-<i zero-filled to 5 digits>'."""
+
+    def __init__(self, path, resolution=8, transform=None):
+        from .lmdb_reader import Environment
+        self.env = Environment(path)
+        n = self.env.get(b'length')
+        if n is None:
+            raise IOError('Cannot open lmdb dataset', path)
+        self.length, self.resolution, self.transform = int(n.decode('utf-8')), int(resolution), transform
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        import io
+        from PIL import Image
+        key = ('%d-%s' % (self.resolution, str(index).zfill(5))).encode('utf-8')
+        buf = self.env.get(key)
+        if buf is None:
+            raise KeyError(key)
+        img = Image.open(io.BytesIO(buf)).convert('RGB')
+        if self.transform is not None:
+            img = self.transform(img)
         return np.asarray(img, dtype=np.uint8)
 
 
@@ -251,8 +377,8 @@ def dataset_from_config(data, root='data', train=True):
     """ddpm_exp/datasets/__init__.py:30-152 for the `data:` block of a ddpm_exp config (dict): returns (dataset, DeviceLoader
     keywords).  The host side produces uint8 images of `image_size`; flip (`random_flip`), ToTensor, `uniform_dequantization` and
     `rescaled` (2x - 1) are the device kernel's job (data_transform, :160-174).  CIFAR10 and CELEBA read the files torchvision
-    reads; LSUN and FFHQ are LMDB databases and `lmdb` is not part of this environment: they raise instead of guessing --
-    export them to an image folder and use UnlabeledImageFolder."""
+    reads; LSUN and FFHQ are LMDB environments read by this package's own pure-Python reader (lmdb_reader.py: `lmdb` is not part of
+    this environment; format restated from LMDB 0.9, unpinned)."""
     name = str(data['dataset']).upper()
     size = int(data.get('image_size', 32))
     if data.get('gaussian_dequantization') or data.get('logit_transform'):
@@ -266,9 +392,15 @@ def dataset_from_config(data, root='data', train=True):
         return ds, kw
     if name == 'CELEBA':
         return CelebAAligned(os.path.join(root, 'celeba'), 'train' if train else 'test', size), kw
-    if name in ('LSUN', 'FFHQ'):
-        raise NotImplementedError('%s is an LMDB database (ddpm_exp/datasets/lsun.py, ffhq.py); the lmdb module is not available '
-                                  'here -- export the images to a folder and pass it to UnlabeledImageFolder' % name)
+    if name == 'LSUN':                               # __init__.py:109-140: <category>_train / _val, Resize + CenterCrop
+        def tf(img, _r=resize_shorter_side(size), _c=center_crop(size)):
+            return _c(_r(img))
+        return Lsun(os.path.join(root, 'lsun'), ['%s_%s' % (data['category'], 'train' if train else 'val')], tf), kw
+    if name == 'FFHQ':                               # __init__.py:142-157: the stored resolution, no resize
+        if not train:
+            raise NotImplementedError('the reference splits FFHQ 90 / 10 with a seeded numpy permutation (datasets/__init__.py:159-170): '
+                                      'build the Subset over FfhqLmdb with those indices')
+        return FfhqLmdb(os.path.join(root, 'FFHQ'), size), kw
     raise ValueError('unknown dataset %r' % (data['dataset'],))
 
 

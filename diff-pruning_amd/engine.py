@@ -24,6 +24,7 @@ UPS_COPY = not os.environ.get('DP_NO_UPS_COPY')
 UPS_SUBPIXEL = not os.environ.get('DP_NO_UPS_SUBPIXEL')      # upsample convolutions as four 2x2 convolutions at low resolution
 _UPS_SPECS = ops.UPS_CLASS_SPECS
 S2_PARITY = not os.environ.get('DP_NO_S2_PARITY')
+FUSE_QKV_WGRAD = not os.environ.get('DP_NO_FUSED_QKV_WGRAD')      # to_q / to_k / to_v weight gradients as one M = 3C contraction
 OVERLAP_MIN_WORK = 4_000_000     # images x pixels x base width from which the weight-gradient side stream pays (UNetEngine.__init__)
 
 # parameter-name suffixes of a residual block: Diffusers ResnetBlock2D / CompVis ResBlock (openaimodel.py:163-275)
@@ -578,6 +579,34 @@ class UNetEngine:
             save[pre] = (x, st, n, q, k, v, p, o, scale, rescale, heads, drop, fused)
         return out
 
+    def _qkv_param_grads(self, pre, d_qkv, n, widths):
+        """Weight / bias gradients of to_q, to_k, to_v in ONE contraction (round 5): the three projections read the same normalised
+        input n, and their output gradients are the channel slices of d_qkv -- so dW_cat[3C, C] = d_qkv (x) n is one M = 3C launch
+        (a third of the split-K partial traffic per weight, three times the K range per workgroup: the M = 256 1x1 weight gradients
+        ran at 62 TFLOP/s, 20 launches per timestep) whose row blocks are then added to the three gradients; one row-sum pass over
+        d_qkv gives the three bias gradients.  Same products, the pixel sum re-associated by the different split-K partition."""
+        names = ('.to_q', '.to_k', '.to_v')
+        has_bias = (pre + '.to_q.bias') in self.P
+
+        def work():
+            gcat = torch.empty((sum(widths), n.shape[1]), dtype=torch.float32, device=n.device)
+            ops.conv_wgrad(d_qkv, n, None, gcat, _SPEC1, accumulate=False)
+            rows = ops.rowsum_nc(d_qkv) if has_bias else None
+            o = 0
+            for name, c in zip(names, widths):
+                gw = self.G[pre + name + '.weight']
+                ops.axpby(gcat[o:o + c].reshape(-1), 1.0, gw.view(-1), 1.0)
+                if has_bias:
+                    self._colsum(rows[:, o:o + c], rows.shape[0], c, 1, 0, self.G[pre + name + '.bias'])
+                o += c
+
+        side = self._side_stream(d_qkv, n)
+        if side is None:
+            work()
+        else:
+            with torch.cuda.stream(side):
+                work()
+
     def attn_bwd(self, pre, dout, extra=None):
         x, st, n, q, k, v, p, o, scale, rescale, heads, drop, fused = self.ctx.pop(pre)
         P, cfg = self.P, self.cfg
@@ -603,8 +632,11 @@ class UNetEngine:
             ds = ops.softmax_bwd(p, dp, scale, out=dp)
             ops.bmm_nt(k.view(N, ck, T), ds, out=sl[0].view(N, cq, T))
             ops.bmm_nn(q.view(N, cq, T), ds, out=sl[1].view(N, ck, T))
-            for dproj, name in zip(sl, ('.to_q', '.to_k', '.to_v')):
-                self._conv_bwd(pre + name, dproj, n, None, _SPEC1, hw, need_dx=False)       # weight / bias gradients only
+            if FUSE_QKV_WGRAD:
+                self._qkv_param_grads(pre, d_qkv, n, (cq, ck, cv))
+            else:
+                for dproj, name in zip(sl, ('.to_q', '.to_k', '.to_v')):
+                    self._conv_bwd(pre + name, dproj, n, None, _SPEC1, hw, need_dx=False)       # weight / bias gradients only
             dn = ops.conv_dgrad(d_qkv, wd, ldd, n.shape[1], _SPEC1, hw)
         else:
             dv = ops.bmm_nn(do3, p)

@@ -315,8 +315,12 @@ class LdmEngine(UNetEngine):
             ds = ops.softmax_bwd(p, dp, scale, out=dp)
             ops.bmm_nt(k.view(N, ck, T), ds, out=sl[0].view(N, cq, T))
             ops.bmm_nn(q.view(N, cq, T), ds, out=sl[1].view(N, ck, T))
-            for dproj, name in zip(sl, ('.attn1.to_q', '.attn1.to_k', '.attn1.to_v')):
-                self._conv_bwd(tb + name, dproj, l1, None, _SPEC1, hw, need_dx=False)       # weight gradients only
+            from .engine import FUSE_QKV_WGRAD
+            if FUSE_QKV_WGRAD and hasattr(self, '_qkv_param_grads'):
+                self._qkv_param_grads(tb + '.attn1', d_qkv, l1, (cq, ck, cv))              # one M = 3 x inner weight-gradient launch
+            else:
+                for dproj, name in zip(sl, ('.attn1.to_q', '.attn1.to_k', '.attn1.to_v')):
+                    self._conv_bwd(tb + name, dproj, l1, None, _SPEC1, hw, need_dx=False)       # weight gradients only
             dl1 = ops.conv_dgrad(d_qkv, wd, ldd, l1.shape[1], _SPEC1, hw)
         else:
             dv = ops.bmm_nn(do3, p)

@@ -392,9 +392,17 @@ def _conv_wino(p, wino, act_bytes):
         p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
         return False
     wr = 1 if (p.g.Wo > 128 or -(-p.M // 32) * 32 < -(-p.M // 64) * 64) else 2          # the launcher's tile rule (csrc/winograd.hip)
-    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), 'conv_wino_kernel<%d, %d, 1>' % (bk, wr), 2.0 * p.M * p.NPIX * p.C * 6,
+    L.check(_run(lambda: _lib().dp_conv_wino(C.byref(p), _stream()), _wino_name(p, bk, wr), 2.0 * p.M * p.NPIX * p.C * 6,
                  act_bytes + 4.0 * U.numel()), 'dp_conv_wino')
     return True
+
+
+def _wino_name(p, bk, wr):
+    return 'conv_wino_kernel<%d, %d, 1>' % (bk, wr)
+
+
+def _wgrad_wino_name(p, bt):
+    return 'wgrad_wino_kernel<%d, %d>' % ((3, 3) if bt == 96 else (2, 2))
 
 
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
@@ -621,13 +629,13 @@ def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     flops = 2.0 * Cout * Cin * 6 * P
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel<%d, %d>' % ((3, 3) if bt == 96 else (2, 2)), flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), _wgrad_wino_name(p, bt), flops), 'dp_wgrad_wino')
     else:
         n = Cout * Cin * 9
         ws = _workspace(splits * n, dy.device)
         p.out, p.o_bs, p.accumulate = _p(ws), n, 0
         p.ldo, p.o_col_stride, p.o_tap_stride = Cin, 1, Cout * Cin          # tap-major partials [split][tap][Cout][Cin]
-        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), 'wgrad_wino_kernel<%d, %d>' % ((3, 3) if bt == 96 else (2, 2)), flops), 'dp_wgrad_wino')
+        L.check(_run(lambda: _lib().dp_wgrad_wino(C.byref(p), _stream()), _wgrad_wino_name(p, bt), flops), 'dp_wgrad_wino')
         L.check(_lib().dp_splitk_reduce_taps(_p(ws), n, splits, _p(gw), Cout * Cin, 9, 1 if accumulate else 0, _stream()),
                 'dp_splitk_reduce_taps')
     return gw

@@ -146,3 +146,114 @@ def inception_state_dict(seed):
 def zlib_crc(s):
     import zlib
     return zlib.crc32(s.encode())
+
+
+def write_lmdb(path, items, psize=4096, max_leaf_keys=None):
+    """Write `items` ({bytes key: bytes value}) as an LMDB 0.9 environment file `path`/data.mdb following the on-disk structure
+    definitions of mdb.c (the same ones diff-pruning_amd/lmdb_reader.py restates): two meta pages, a B+tree of leaf / branch pages
+    in ascending key order, values larger than a quarter page on overflow page runs (F_BIGDATA).  Test infrastructure: liblmdb is
+    not available here, so this is a second, independent walk over the format (writer vs reader), not liblmdb's own output."""
+    import os
+    import struct
+    os.makedirs(path, exist_ok=True)
+    keys = sorted(items)
+    pages = {}                                      # pgno -> bytes
+    next_pg = [2]
+
+    def alloc(n=1):
+        p = next_pg[0]
+        next_pg[0] += n
+        return p
+
+    def page(pgno, flags, nodes):
+        """nodes: list of encoded node bytes; placed from the page end downwards, offsets table after the header."""
+        buf = bytearray(psize)
+        upper = psize
+        offs = []
+        for nd in nodes:
+            nd = nd + b'\0' * (len(nd) & 1)          # nodes are 2-byte aligned
+            upper -= len(nd)
+            buf[upper:upper + len(nd)] = nd
+            offs.append(upper)
+        lower = 16 + 2 * len(nodes)
+        assert lower <= upper, 'page overflow in the test writer'
+        struct.pack_into('<QHHHH', buf, 0, pgno, 0, flags, lower, upper)
+        for i, o in enumerate(offs):
+            struct.pack_into('<H', buf, 16 + 2 * i, o)
+        pages[pgno] = bytes(buf)
+
+    n_overflow = 0
+    leaf_nodes = []
+    for k in keys:
+        v = items[k]
+        if len(v) > psize // 4:                      # an overflow run: header on its first page, payload contiguous behind it
+            npg = (16 + len(v) + psize - 1) // psize
+            pg = alloc(npg)
+            buf = bytearray(npg * psize)
+            struct.pack_into('<QHHI', buf, 0, pg, 0, 0x04, npg)
+            buf[16:16 + len(v)] = v
+            for i in range(npg):
+                pages[pg + i] = bytes(buf[i * psize:(i + 1) * psize])
+            n_overflow += npg
+            nd = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, 0x01, len(k)) + k + struct.pack('<Q', pg)
+        else:
+            nd = struct.pack('<HHHH', len(v) & 0xFFFF, len(v) >> 16, 0, len(k)) + k + v
+        leaf_nodes.append((k, nd))
+    # leaves
+    level, cur, used = [], [], 16
+    for k, nd in leaf_nodes:
+        need = len(nd) + (len(nd) & 1) + 2
+        if cur and (used + need > psize or (max_leaf_keys and len(cur) >= max_leaf_keys)):
+            level.append(cur)
+            cur, used = [], 16
+        cur.append((k, nd))
+        used += need
+    if cur:
+        level.append(cur)
+    n_leaf, n_branch, depth = len(level), 0, 1 if level else 0
+    children = []
+    for grp in level:
+        pg = alloc()
+        page(pg, 0x02, [nd for _, nd in grp])
+        children.append((grp[0][0], pg))
+    while len(children) > 1:                          # branch levels: first node of a page has an empty key
+        depth += 1
+        nxt, cur, used = [], [], 16
+        groups = []
+        for k, pg in children:
+            kk = b'' if not cur else k
+            nd = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, len(kk)) + kk
+            need = len(nd) + (len(nd) & 1) + 2
+            if cur and (used + need > psize or (max_leaf_keys and len(cur) >= max_leaf_keys)):
+                groups.append(cur)
+                cur, used = [], 16
+                nd = struct.pack('<HHHH', pg & 0xFFFF, (pg >> 16) & 0xFFFF, (pg >> 32) & 0xFFFF, 0)
+                need = len(nd) + 2
+            cur.append((k, nd))
+            used += need
+        groups.append(cur)
+        for grp in groups:
+            pg = alloc()
+            page(pg, 0x01, [nd for _, nd in grp])
+            nxt.append((grp[0][0], pg))
+            n_branch += 1
+        children = nxt
+    root = children[0][1] if children else (1 << 64) - 1
+    last_pg = next_pg[0] - 1
+
+    def meta(pgno, txnid, root_pg):
+        buf = bytearray(psize)
+        struct.pack_into('<QHHHH', buf, 0, pgno, 0, 0x08, 0, 0)
+        struct.pack_into('<IIQQ', buf, 16, 0xBEEFC0DE, 1, 0, 1 << 30)
+        struct.pack_into('<IHHQQQQQ', buf, 16 + 24, psize, 0, 0, 0, 0, 0, 0, (1 << 64) - 1)                     # free DB: pad = page size
+        struct.pack_into('<IHHQQQQQ', buf, 16 + 24 + 48, 0, 0, depth if root_pg != (1 << 64) - 1 else 0, n_branch, n_leaf,
+                         n_overflow, len(keys) if root_pg != (1 << 64) - 1 else 0, root_pg)
+        struct.pack_into('<QQ', buf, 16 + 24 + 96, last_pg, txnid)
+        return bytes(buf)
+
+    with open(os.path.join(path, 'data.mdb'), 'wb') as f:
+        f.write(meta(0, 1, (1 << 64) - 1))          # the older transaction: an empty tree (the reader must pick the newer meta)
+        f.write(meta(1, 2, root))
+        for pg in range(2, next_pg[0]):
+            f.write(pages.get(pg, b'\0' * psize))
+

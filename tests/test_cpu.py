@@ -431,7 +431,7 @@ def test_multi_head_engine_logic_matches_oracle_on_mocked_kernels(mocked, monkey
 
 def test_celeba_cifar100_and_config_datasets(tmp_path):
     """SURVEY §8(f) rank 4, host side: the CelebA split file + crop window + resize of ddpm_exp/datasets (celeba.py:50-107,
-    __init__.py:60-93), CIFAR-100's pickle (utils.py:41-49) and the `data:` block dispatch; LSUN / FFHQ (LMDB) refuse."""
+    __init__.py:60-93), CIFAR-100's pickle (utils.py:41-49) and the `data:` block dispatch (LSUN / FFHQ: test_lsun_ffhq_lmdb_datasets)."""
     import pickle
     from PIL import Image
     data = pkg('data')
@@ -470,9 +470,6 @@ def test_celeba_cifar100_and_config_datasets(tmp_path):
     assert isinstance(dsc, data.CelebAAligned) and len(dsc) == 3
     assert kw == dict(mode=data.RESCALE, flip_p=0.5, dequant=False, crop=None)
     assert data.dataset_from_config(cfg, root=str(tmp_path), train=False)[1]['flip_p'] == 0.0
-    for name in ('LSUN', 'FFHQ'):
-        with pytest.raises(NotImplementedError, match='LMDB'):
-            data.dataset_from_config(dict(cfg, dataset=name), root=str(tmp_path))
     x = torch.tensor([-1.5, -1.0, 0.0, 1.0, 2.0])
     assert torch.equal(data.inverse_data_transform(x), torch.tensor([0.0, 0.0, 0.5, 1.0, 1.0]))
 
@@ -2101,3 +2098,80 @@ def test_winograd_refuses_activations_within_a_row_of_2gib():
     assert conv(4 << 20) == 16 and conv(lim - 4) == 16 and conv(lim) == 0 and conv((1 << 31) - 4) == 0
     assert conv(4 << 20, 4 << 20) == 16 and conv(4 << 20, lim) == 0
     assert wgrad(4 << 20) == 1 and wgrad(lim - 4) == 1 and wgrad(lim) == 0
+
+
+def test_lsun_ffhq_lmdb_datasets(tmp_path):
+    """SURVEY §8(f) rank 4, the LSUN / FFHQ half (ddpm_exp/datasets/lsun.py:11-173, ffhq.py:8-40, __init__.py:109-157): LMDB
+    environments read by the package's own pure-Python reader (lmdb_reader.py; `lmdb` is not in this image).  The environments are
+    built by tests/helpers.write_lmdb from the same published structure definitions -- multi-level trees, overflow pages, a stale
+    second meta page -- so what is pinned is reader == writer over the format and the reference's dataset SEMANTICS (key-order
+    item order + its pickle cache, `<category>_<split>_lmdb` directories, cumulative class indices, the FFHQ key scheme, Resize +
+    CenterCrop), not liblmdb's own bytes (format parity unpinned, stated in the module)."""
+    import io
+    import pickle
+    from PIL import Image
+    from helpers import write_lmdb
+    data, lm = pkg('data'), pkg('lmdb_reader')
+    rng = np.random.default_rng(3)
+    # (1) the reader on trees of depth 1, 2 and 3 with inline and overflow values
+    for n_items, max_keys in ((5, None), (300, None), (700, 9)):
+        items = {('k%05d' % (i * 7919 % 100003)).encode(): bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)) if i % 11 else 9000,
+                                                                                dtype=np.uint8)) for i in range(n_items)}
+        d = str(tmp_path / ('env%d' % n_items))
+        write_lmdb(d, items, max_leaf_keys=max_keys)
+        with lm.Environment(d) as env:
+            assert env.stat()['entries'] == n_items and env.depth == (1 if n_items == 5 else 2 if n_items == 300 else 3)
+            assert env.keys() == sorted(items)                                   # cursor order = byte-wise key order
+            assert all(env.get(k) == v for k, v in items.items())
+            assert env.get(b'k') is None and env.get(b'zzz') is None and env.get(b'k00000x') is None
+            assert dict(env.items()) == items
+    with pytest.raises(lm.LmdbError):
+        (tmp_path / 'junk').mkdir()
+        (tmp_path / 'junk' / 'data.mdb').write_bytes(b'\0' * 8192)
+        lm.Environment(str(tmp_path / 'junk'))
+    # (2) LSUN: two class environments of PNG-encoded images (lossless stand-ins for the WEBP values)
+    def png(arr):
+        b = io.BytesIO()
+        Image.fromarray(arr).save(b, format='PNG')
+        return b.getvalue()
+    root = tmp_path / 'data' / 'lsun'
+    imgs = {}
+    for cls, n in (('bedroom_train', 6), ('church_outdoor_train', 4), ('bedroom_val', 2)):
+        arrs = {('%040x' % int(rng.integers(0, 1 << 62))).encode(): rng.integers(0, 256, size=(40 + 3 * j, 56 - 2 * j, 3), dtype=np.uint8)
+                for j in range(n)}
+        write_lmdb(str(root / (cls + '_lmdb')), {k: png(a) for k, a in arrs.items()})
+        imgs[cls] = [arrs[k] for k in sorted(arrs)]
+    ds = data.Lsun(str(root), ['bedroom_train', 'church_outdoor_train'])
+    assert len(ds) == 10 and ds.indices == [6, 10]
+    assert np.array_equal(ds[0], imgs['bedroom_train'][0]) and np.array_equal(ds[5], imgs['bedroom_train'][5])
+    assert np.array_equal(ds[6], imgs['church_outdoor_train'][0]) and np.array_equal(ds[9], imgs['church_outdoor_train'][3])
+    cache = root / '_cache_bedroom_train_lmdb'                                    # lsun.py:29-36: the key list is pickled once
+    assert pickle.load(open(cache, 'rb')) == data.LsunClassLmdb(str(root / 'bedroom_train_lmdb')).keys
+    with pytest.raises(ValueError, match='LSUN class'):
+        data.Lsun(str(root), ['garage_train'])
+    with pytest.raises(ValueError, match='postfix'):
+        data.Lsun(str(root), ['bedroom_training'])
+    cfg = dict(dataset='LSUN', category='bedroom', image_size=32, random_flip=True, rescaled=True, uniform_dequantization=False)
+    dsc, kw = data.dataset_from_config(cfg, root=str(tmp_path / 'data'))
+    assert isinstance(dsc, data.Lsun) and len(dsc) == 6 and kw['flip_p'] == 0.5 and kw['mode'] == data.RESCALE
+    for i in (0, 3):          # e.g. 40 x 56: Resize(32) -> 32 x 44 (shorter side, bilinear), CenterCrop(32) -> columns 6 .. 37
+        a0 = imgs['bedroom_train'][i]
+        h, w = a0.shape[:2]
+        rw, rh = (32, int(32 * h / w)) if w < h else (int(32 * w / h), 32)
+        r = np.asarray(Image.fromarray(a0).resize((rw, rh), Image.BILINEAR))
+        top, left = int(round((rh - 32) / 2.0)), int(round((rw - 32) / 2.0))
+        assert dsc[i].shape == (32, 32, 3) and np.array_equal(dsc[i], r[top:top + 32, left:left + 32])
+    assert len(data.dataset_from_config(cfg, root=str(tmp_path / 'data'), train=False)[0]) == 2
+    # (3) FFHQ: one environment, b'length' + b'<resolution>-<index:05d>'
+    ff = {b'length': b'3'}
+    fimgs = {}
+    for r in (8, 16):
+        for i in range(3):
+            fimgs[(r, i)] = rng.integers(0, 256, size=(r, r, 3), dtype=np.uint8)
+            ff[('%d-%05d' % (r, i)).encode()] = png(fimgs[(r, i)])
+    write_lmdb(str(tmp_path / 'data' / 'FFHQ'), ff)
+    f16, kw = data.dataset_from_config(dict(cfg, dataset='FFHQ', image_size=16), root=str(tmp_path / 'data'))
+    assert len(f16) == 3 and np.array_equal(f16[2], fimgs[(16, 2)]) and np.array_equal(data.FfhqLmdb(str(tmp_path / 'data' / 'FFHQ'), 8)[1], fimgs[(8, 1)])
+    loader = data.DeviceLoader if hasattr(data, 'DeviceLoader') else None
+    assert loader is not None
+
