@@ -124,68 +124,62 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ As, const fl
 // tested once per half sub-tile and the 8 loads of an operand are issued before the first use: a null test plus a
 // load + wait per element made the epilogue a chain of ~64 dependent memory latencies per lane.  Rows >= M (partial
 // tiles) load from a clamped row and skip the store.
+// [round 5, measured] four rows x ALL operands per batch (one wait per quarter sub-tile instead of one per operand and half): the
+// 128 x 128 kernels fell from 107.9 to 103-105 TFLOP/s -- most launches carry 0-2 operands, for which that form waits four times
+// per sub-tile instead of two; eight rows x all operands spills at the 128-VGPR cap.  Kept as it was.
 template <bool FULL>
 __device__ __forceinline__ void conv_epilogue_tile(const dp_conv_gemm_params& p, const f32x16& acc, int mrow0, int lane,
                                                    float* __restrict__ optr, const float* __restrict__ rptr,
                                                    const float* __restrict__ tptr, int HoWo) {
     const int mb = mrow0 + 4 * (lane >> 5);
-    // round 5: four rows at a time with the loads of ALL optional operands of the four (up to 16) in flight before the first use
-    // -- round 1's form issued ONE operand's eight loads, waited, then the next operand's: four dependent round trips per half
-    // sub-tile, which is what the short-K 1x1 / projection launches spend their time in.  Same register footprint (the 128 x 128
-    // kernels sit at their 128-VGPR cap: eight rows x four operands spilled).
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        float v[4], tb[4], tt[4], tr[4], tp[4];
-        int mc[4];
+    for (int h = 0; h < 2; ++h) {
+        float v[8];
+        int mc[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = h * 4 + q;
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
             const int m = mb + (r & 3) + 8 * (r >> 2);
             mc[q] = FULL ? m : min(m, p.M - 1);
             v[q] = p.alpha * acc[r];
-            tb[q] = tt[q] = tr[q] = tp[q] = 0.f;
         }
         if (p.bias) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tb[q] = p.bias[mc[q]];
+            for (int q = 0; q < 8; ++q) t[q] = p.bias[mc[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
         }
         if (tptr) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tt[q] = tptr[mc[q]];
+            for (int q = 0; q < 8; ++q) t[q] = tptr[mc[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
         }
         if (rptr) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tr[q] = rptr[(long long)mc[q] * HoWo];
-        }
-        if (p.accumulate) {
+            for (int q = 0; q < 8; ++q) t[q] = rptr[(long long)mc[q] * HoWo];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tp[q] = optr[(long long)mc[q] * HoWo];
-        }
-        if (p.bias) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += tb[q];
-        }
-        if (tptr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += tt[q];
-        }
-        if (rptr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += tr[q];
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] *= p.post_scale;
+        for (int q = 0; q < 8; ++q) v[q] *= p.post_scale;
         if (p.act == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
         }
         if (p.accumulate) {
+            float t[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += tp[q];
+            for (int q = 0; q < 8; ++q) t[q] = optr[(long long)mc[q] * HoWo];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += t[q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = h * 4 + q;
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
             if (FULL || mb + (r & 3) + 8 * (r >> 2) < p.M) optr[(long long)mc[q] * HoWo] = v[q];
         }
     }

@@ -10,7 +10,9 @@ Engine notes.  Tokens stay channel-major ([N][C][T]), so proj_in / q,k,v / FF pr
 kernel as the 1x1 convolutions and LayerNorm reduces over the strided channel axis with one thread per token.
 Cross-attention (`attn2`) over the ONE class-embedding token (attention.py:168-193 with context [B,1,512]): the softmax
 over a single key is identically 1, so its output is to_out(to_v(context)) broadcast over the tokens; norm2, to_q and
-to_k receive exactly-zero gradients (as under autograd in the reference) and are not evaluated.
+to_k receive exactly-zero gradients (as under autograd in the reference) and are not evaluated.  A context of L > 1 tokens
+(attention.py:152-193 takes any; no configuration the reference prunes has one) takes the general form: the context as
+channel-major tokens [B, D, 1, L], K / V as 1x1 projections of it, and the three launches of the self-attention (round 5).
 """
 import torch
 import torch.nn as nn
@@ -239,16 +241,39 @@ class LdmEngine(UNetEngine):
             p = ops.softmax_fwd(s, out=s)
             o = ops.bmm_nt(v.view(N, ai, T), p)
         h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, ai, H, W), None, _SPEC1, res=h)
-        # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
         hit = self._ctx_cache.get(pre) if self._ctx_cache is not None else None
-        if hit is not None:
-            v2, o2 = hit                              # sampling loop: same context and weights at every DDIM step
+        x2 = None
+        if ctx2d is not None:
+            # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
+            if hit is not None:
+                v2, o2 = hit                          # sampling loop: same context and weights at every DDIM step
+            else:
+                v2 = self._linear(tb + '.attn2.to_v', ctx2d)
+                o2 = self._linear(tb + '.attn2.to_out.0', v2).contiguous()
+                if self._ctx_cache is not None:
+                    self._ctx_cache[pre] = (v2, o2)
+            h2 = ops.add_rowvec(h1, o2)
         else:
-            v2 = self._linear(tb + '.attn2.to_v', ctx2d)
-            o2 = self._linear(tb + '.attn2.to_out.0', v2).contiguous()
-            if self._ctx_cache is not None:
-                self._ctx_cache[pre] = (v2, o2)
-        h2 = ops.add_rowvec(h1, o2)
+            # attn2 over L > 1 context tokens (ldm/modules/attention.py:152-193, general form): the context as channel-major
+            # "tokens" [N, D, 1, L] makes to_k / to_v 1x1 convolutions whose outputs K, V [N, inner, L] are the operands of the
+            # same three launches as the self-attention: S = Q^T K [T, L], softmax over the L keys, O = V P^T.
+            cx = self._ctx_cm                         # [N, D, 1, L]
+            L_ = cx.shape[3]
+            l2, ls2 = ops.layernorm_fwd(h1, P[tb + '.norm2.weight'], P[tb + '.norm2.bias'])
+            q2 = self._conv(tb + '.attn2.to_q', l2, None, _SPEC1)
+            if hit is not None:
+                k2, v2 = hit
+            else:
+                k2 = self._conv(tb + '.attn2.to_k', cx, None, _SPEC1)
+                v2 = self._conv(tb + '.attn2.to_v', cx, None, _SPEC1)
+                if self._ctx_cache is not None:
+                    self._ctx_cache[pre] = (k2, v2)
+            a2 = q2.shape[1]
+            s2 = ops.bmm_tn(q2.view(N, a2, T), k2.view(N, a2, L_), alpha=scale)
+            p2 = ops.softmax_fwd(s2, out=s2)
+            o2 = ops.bmm_nt(v2.view(N, a2, L_), p2)
+            h2 = self._conv(tb + '.attn2.to_out.0', o2.view(N, a2, H, W), None, _SPEC1, res=h1)
+            x2 = (l2, ls2, q2, k2, p2, o2, cx)
         # feed-forward (GEGLU)
         l3, ls3 = ops.layernorm_fwd(h2, P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
         pr = self._conv(tb + '.ff.net.0.proj', l3, None, _SPEC1)
@@ -256,7 +281,7 @@ class LdmEngine(UNetEngine):
         h3 = self._conv(tb + '.ff.net.2', gg, None, _SPEC1, res=h2)
         out = self._conv(pre + '.proj_out', h3, None, _SPEC1, res=x)
         if save is not None:
-            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused)
+            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused, x2)
         return out
 
     # The cross-attention branch of every transformer block depends on the context token and the weights only
@@ -284,7 +309,7 @@ class LdmEngine(UNetEngine):
         self._colsum(pws, N, C, 2, 0, self.G[name + '.bias'])
 
     def st_bwd(self, pre, dout, extra=None):
-        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused) = self.ctx.pop(pre)
+        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused, x2) = self.ctx.pop(pre)
         P = self.P
         N, C, H, W = x.shape
         T = H * W
@@ -298,10 +323,31 @@ class LdmEngine(UNetEngine):
         dl3 = self._conv_bwd(tb + '.ff.net.0.proj', dpr, l3, None, _SPEC1, hw)
         dh2, pws = ops.layernorm_bwd(h2, P[tb + '.norm3.weight'], ls3, dl3, add=dh3)
         self._ln_param_grads(tb + '.norm3', pws)
-        # attn2 (context token): d o2[n, c] = sum_t dh2
-        rows = ops.rowsum_nc(dh2)
-        dv2 = self._linear_bwd(tb + '.attn2.to_out.0', rows, v2)
-        self._linear_bwd(tb + '.attn2.to_v', dv2, ctx2d, need_dx=False)
+        if x2 is None:
+            # attn2 (context token): d o2[n, c] = sum_t dh2
+            rows = ops.rowsum_nc(dh2)
+            dv2 = self._linear_bwd(tb + '.attn2.to_out.0', rows, v2)
+            self._linear_bwd(tb + '.attn2.to_v', dv2, ctx2d, need_dx=False)
+            dh1 = dh2                                  # h2 = h1 + (a row vector that does not depend on h1)
+        else:
+            # attn2 over L > 1 context tokens: the self-attention backward with K, V projected from the context; norm2 / to_q get
+            # gradients now (over a single key the softmax is constant and they are exactly zero), the context itself gets none
+            # (the importance pass differentiates the UNet's parameters only)
+            l2, ls2, q2, k2, p2, o2, cx = x2
+            a2, L_ = q2.shape[1], cx.shape[3]
+            do2 = self._conv_bwd(tb + '.attn2.to_out.0', dh2, o2.view(N, a2, H, W), None, _SPEC1, hw)
+            do23 = do2.view(N, a2, T)
+            dv2 = ops.bmm_nn(do23, p2)                                         # [N, a2, L]
+            dp2 = ops.bmm_tn(do23, v2.view(N, a2, L_))                         # [N, T, L]
+            ds2 = ops.softmax_bwd(p2, dp2, scale, out=dp2)
+            dq2 = ops.bmm_nt(k2.view(N, a2, L_), ds2)                          # [N, a2, T]
+            dk2 = ops.bmm_nn(q2.view(N, a2, T), ds2)                           # [N, a2, L]
+            self._conv_bwd(tb + '.attn2.to_k', dk2.view(N, a2, 1, L_), cx, None, _SPEC1, (1, L_), need_dx=False)
+            self._conv_bwd(tb + '.attn2.to_v', dv2.view(N, a2, 1, L_), cx, None, _SPEC1, (1, L_), need_dx=False)
+            dl2 = self._conv_bwd(tb + '.attn2.to_q', dq2.view(N, a2, H, W), l2, None, _SPEC1, hw)
+            dh1, pws2 = ops.layernorm_bwd(h1, P[tb + '.norm2.weight'], ls2, dl2, add=dh2)
+            self._ln_param_grads(tb + '.norm2', pws2)
+        dh2 = dh1
         # attn1
         do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, ai, H, W), None, _SPEC1, hw)
         do3 = do.view(N, ai, T)
@@ -350,11 +396,15 @@ class LdmEngine(UNetEngine):
         batch B and its output and skip tensors are duplicated where the first context-dependent block starts (5.8 of the
         104.2 GMAC per latent forward, for half of the batch).  Returns the 2B outputs [uncond; cond]."""
         P, cfg = self.P, self.cfg
-        if context is None or context.dim() != 3 or context.shape[1] != 1:
-            raise NotImplementedError('context must be [B, 1, context_dim] (the class-embedding token of cin256-v2)')
+        if context is None or context.dim() != 3:
+            raise NotImplementedError('context must be [B, L, context_dim] (cin256-v2: the one class-embedding token, L = 1)')
         if cfg_pair and (save or context.shape[0] != 2 * x.shape[0]):
             raise ValueError('cfg_pair: a no-grad forward of B images against 2B context tokens')
-        ctx2d = context.reshape(context.shape[0], context.shape[2]).contiguous().float()
+        if context.shape[1] == 1:                      # every configuration the reference prunes: the closed form of st_fwd
+            ctx2d = context.reshape(context.shape[0], context.shape[2]).contiguous().float()
+        else:                                          # L > 1 tokens: [B, L, D] -> channel-major [B, D, 1, L] for the 1x1 projections
+            ctx2d = None
+            self._ctx_cm = context.float().transpose(1, 2).contiguous().view(context.shape[0], context.shape[2], 1, context.shape[1])
         inp, out, mid = ldm_blocks(cfg)
         ctx = {} if save else None
         if save:

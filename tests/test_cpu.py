@@ -1034,6 +1034,53 @@ def test_ldm_engine_backward_graph_matches_oracle(mocked, monkeypatch):
             assert float(grads[k].abs().max()) < 1e-6, k        # norm2 / attn2.to_q / attn2.to_k: exactly zero
 
 
+@pytest.mark.parametrize('L_ctx', [3, 5])
+def test_ldm_engine_general_cross_attention_matches_oracle(mocked, monkeypatch, L_ctx):
+    """Round 5: cross-attention over L > 1 context tokens (ldm/modules/attention.py:152-193 takes any context; the configurations
+    the reference prunes pass ONE class token, for which the engine keeps its closed form).  LdmEngine's general attn2 -- context
+    as channel-major tokens, K / V 1x1 projections, the three attention launches, norm2 / to_q / to_k now with gradients --
+    against autograd of the oracle (whose cross_attention is the reference's einsum form, pinned bit-identical to the reference's
+    UNetModel for L = 1), kernels replaced by CPU stand-ins: forward, loss and every parameter gradient; then a no-grad CFG pair
+    (shared stem) and the context cache of a sampling loop against the plain forward."""
+    from oracle import ldm_ref as L
+    ldm = pkg('ldm')
+    monkeypatch.setattr(ldm, 'ops', mocked)
+    cfg = gc.LDM_TINY_CFG
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    eng = ldm.LdmEngine(model.config)
+    grads = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    eng.bind({n: p.detach() for n, p in model.named_parameters()}, grads)
+    x, ctx1, noise, t = _ldm_inputs()
+    ctx = torch.from_numpy(gc.det_noise((x.shape[0], L_ctx, ctx1.shape[2]), 123))
+    y = eng.forward(x, t, ctx, save=True)
+    n = y.numel()
+    loss, dout = mocked.mse_fwd_bwd(y, noise, 2.0 / n, 1.0 / n)
+    eng.backward(dout)
+    P = {k: torch.from_numpy(gc.det_param(k, s, 9)).requires_grad_(True) for k, s in L.ldm_param_shapes(cfg).items()}
+    yo = L.ldm_unet_forward(P, cfg, x, t, ctx)
+    lo = (yo - noise).square().mean(dim=(1, 2, 3)).mean()
+    lo.backward()
+    assert float((y - yo.detach()).abs().max()) < 1e-5
+    assert abs(float(loss) - float(lo.detach())) < 1e-6
+    nonzero = 0
+    for k in P:
+        ref = P[k].grad
+        if float(ref.abs().max()) > 1e-7:
+            assert relerr(grads[k], ref) < 5e-5, k
+            nonzero += ('attn2.to_q' in k or 'attn2.to_k' in k or '.norm2.' in k)
+        else:
+            assert float(grads[k].abs().max()) < 1e-6, k
+    assert nonzero > 0                                  # with L > 1 keys the softmax is not constant any more
+    # CFG pair (the context-free stem evaluated once) and the per-sampling-loop context cache == two plain forwards
+    ctx2 = torch.cat([torch.from_numpy(gc.det_noise(tuple(ctx.shape), 124)), ctx])
+    plain = eng.forward(torch.cat([x, x]), torch.cat([t, t]), ctx2, save=False)
+    with eng.context_cache(ctx2):
+        pair_a = eng.forward(x, t, ctx2, save=False, cfg_pair=True)
+        pair_b = eng.forward(x, t, ctx2, save=False, cfg_pair=True)          # second call: K / V of every block from the cache
+    assert float((pair_a - plain).abs().max()) < 1e-5 and torch.equal(pair_a, pair_b)
+
+
 def _ldm_sweep_fixture(steps=3, n=2):
     emb_w = torch.from_numpy(gc.det_noise((1001, 16), 77))
     rng = np.random.default_rng(5)

@@ -1565,3 +1565,54 @@ def test_sampling_forward_replayed_natively_equals_eager(report, monkeypatch):
         out[name] = float(np.abs(imgs['1']).mean())
     report['e2e/sampling_replay'] = out
 
+
+@pytest.mark.parametrize('L_ctx', [3, 5, 77])
+def test_ldm_general_cross_attention_matches_oracle(report, L_ctx):
+    """Round 5: cross-attention over L > 1 context tokens on the HIP kernels (ldm/modules/attention.py:152-193, general form; 77 = a
+    CLIP text context; 3 and 5: odd key counts on the general contraction kernels) against the oracle on the host: forward, loss,
+    every parameter gradient -- incl. norm2 / attn2.to_q / attn2.to_k, which are exactly zero for one token -- and the CFG pair +
+    context cache of a sampling loop against two plain forwards."""
+    from oracle import ldm_ref as L
+    ldm, ops = pkg('ldm'), pkg('ops')
+    cfg = gc.LDM_TINY_CFG
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    model = model.to(DEV).eval()
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 31))
+    ctx = torch.from_numpy(gc.det_noise((2, L_ctx, 16), 123))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 33))
+    t = torch.tensor([7, 640])
+    eng = model.engine()
+    grads = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    eng.bind(eng.P, grads)
+    y = eng.forward(x.to(DEV), t.to(DEV), ctx.to(DEV), save=True)
+    n = y.numel()
+    loss, dout = ops.mse_fwd_bwd(y, noise.to(DEV), 2.0 / n, 1.0 / n)
+    eng.backward(dout)
+    P = {k: torch.from_numpy(gc.det_param(k, s_, 9)).requires_grad_(True) for k, s_ in L.ldm_param_shapes(cfg).items()}
+    yo = L.ldm_unet_forward(P, cfg, x, t, ctx)
+    lo = (yo - noise).square().mean(dim=(1, 2, 3)).mean()
+    lo.backward()
+    e_f = float((y.cpu() - yo.detach()).abs().max())
+    e_l = abs(float(loss) - float(lo.detach())) / float(lo.detach())
+    worst, nonzero = 0.0, 0
+    for k in P:
+        ref = P[k].grad
+        if float(ref.abs().max()) > 1e-7:
+            worst = max(worst, relerr(grads[k], ref))
+            nonzero += ('attn2.to_q' in k or 'attn2.to_k' in k or '.norm2.' in k)
+        else:
+            assert float(grads[k].abs().max()) < 1e-6, k
+    ctx2 = torch.cat([torch.from_numpy(gc.det_noise(tuple(ctx.shape), 124)), ctx]).to(DEV)
+    x2, t2 = x.to(DEV), t.to(DEV)
+    with torch.no_grad(), model.pin_weights() as pinned:
+        plain = model(torch.cat([x2, x2]), torch.cat([t2, t2]), context=ctx2)
+        with pinned._engine.context_cache(ctx2):
+            pa = model.forward_cfg_pair(x2, t2, ctx2)
+            pb = model.forward_cfg_pair(x2, t2, ctx2)
+    e_pair = float((pa - plain).abs().max())
+    report['e2e/ldm_cross_attention_L%d' % L_ctx] = dict(fwd_abs=e_f, loss_rel=e_l, grad_rel_worst=worst, cfg_pair_abs=e_pair,
+                                                       attn2_q_k_norm2_grads_nonzero=nonzero)
+    assert e_f < 1e-5 and e_l < 1e-5 and worst < 2e-5 and nonzero > 0
+    assert e_pair < 1e-5 and torch.equal(pa, pb)
+
