@@ -435,7 +435,7 @@ def kernel_switches(ops):
     eng, sweep = pkg('engine'), pkg('sweep')
     return {'wino': bool(ops.WINO), 'wgrad_wino': bool(ops.WINO and ops.WGRAD_WINO), 'wino_min_tiles': ops.WINO_MIN_TILES,
             'splitk_fold': bool(ops.SPLITK_FOLD), 'splitk_fold_max': ops.SPLITK_FOLD_MAX,
-            'wgrad_splitk_fold': bool(getattr(ops, 'WGRAD_FOLD', False)),
+            'wino43_no_grad_forwards': getattr(ops, 'WINO43', False),
             'fused_attn': ops.FUSED_ATTN, 'ups_subpixel': bool(eng.UPS_SUBPIXEL), 's2_parity': bool(eng.S2_PARITY),
             'timestep_pipelines_default': sweep.TIMESTEP_PIPELINES,
             'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('DP_')}}

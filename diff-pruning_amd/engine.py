@@ -73,7 +73,9 @@ class _Packs:
         hit = self._c.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1], hit[2]
-        if isinstance(mode, tuple) and mode[0] == 'wino':    # ('wino', 0 | 1): Winograd F(2, 3) operand (ops.pack_weight_wino)
+        if isinstance(mode, tuple) and mode[0] == 'wino43':  # ('wino43', 0): Winograd F(4, 3) operand of the no-grad forwards
+            buf, ld = ops.pack_weight_wino43(w)
+        elif isinstance(mode, tuple) and mode[0] == 'wino':    # ('wino', 0 | 1): Winograd F(2, 3) operand (ops.pack_weight_wino)
             buf, ld = ops.pack_weight_wino(w, mode[1])
         elif isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
             weff = self.get_weff(name, w)
@@ -144,6 +146,7 @@ class UNetEngine:
         # this stack (~80 per timestep): CIFAR UNet batch 4: 15.4 ms per timestep with the side stream, 11.2 without; batch 16:
         # 16.1 / 12.0; batch 64: 24.4 / 25.4; LDM UNet, 6 latents: 51.1 / 55.8.  overlap_wgrad = None (default) decides per
         # backward pass from the work of the step (images x pixels x base width >= OVERLAP_MIN_WORK); True / False force it.
+        self._nograd = False
         self.overlap_wgrad = False if os.environ.get('DP_NO_OVERLAP') else (True if os.environ.get('DP_OVERLAP') else None)
         self._overlap_now = True
         self._side, self._side_dev = None, None
@@ -338,9 +341,14 @@ class UNetEngine:
         w = self.P[name + '.weight']
         wp, ld = self.packs.get(name, w, 0)
         # 3x3 / stride 1 / pad 1 layers with a grid worth it: Winograd F(2, 3) along W, 2/3 of the multiplies (csrc/winograd.hip)
-        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and ops.wino_wanted(
-                w.shape[0], (x.shape[1],) + ((x2.shape[1],) if x2 is not None else ()), x.shape[0], x.shape[2], x.shape[3], spec):
-            kw['wino'] = self._wino_pack(name, w, 0)
+        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted'):
+            cs = (x.shape[1],) + ((x2.shape[1],) if x2 is not None else ())
+            if ops.wino_wanted(w.shape[0], cs, x.shape[0], x.shape[2], x.shape[3], spec):
+                kw['wino'] = self._wino_pack(name, w, 0)
+            # a forward that keeps nothing for a backward (sampling loops, the LDM importance pass's CFG sampler): F(4, 3), half the
+            # multiplies at ~1e-6 instead of ~3e-7 fp32 error -- never for a scored forward (csrc/winograd43.hip)
+            if self._nograd and hasattr(ops, 'wino43_wanted') and ops.wino43_wanted(w.shape[0], cs, x.shape[0], x.shape[2], x.shape[3], spec):
+                kw['wino43'] = self.packs.get(name, w, ('wino43', 0))
         return ops.conv_forward(x, x2, wp, ld, w.shape[0], spec, bias=self.P.get(name + '.bias'), **kw)
 
     def _linear(self, name, x2d):
@@ -662,6 +670,7 @@ class UNetEngine:
         Lr = cfg['layers_per_block']
         nb = len(boc)
         ctx = {} if save else None
+        self._nograd = not save                                  # F(4, 3) convolutions only where nothing is kept for a backward
         self._wino_gen = getattr(self, '_wino_gen', 0) + 1       # one generation per forward pass (see prepare_packs)
         if save:
             self.decide_overlap(sample)

@@ -407,6 +407,7 @@ class LdmEngine(UNetEngine):
             self._ctx_cm = context.float().transpose(1, 2).contiguous().view(context.shape[0], context.shape[2], 1, context.shape[1])
         inp, out, mid = ldm_blocks(cfg)
         ctx = {} if save else None
+        self._nograd = not save                        # F(4, 3) convolutions in the sampler's forwards only (UNetEngine._conv)
         if save:
             self.decide_overlap(x)
         x = x.contiguous()

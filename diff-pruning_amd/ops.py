@@ -367,6 +367,72 @@ def pack_weight_wino(w, mode):
     return dst, ld
 
 
+# ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------
+# 'auto': where tools/bench_wino.py measured it faster than F(2, 3) (see WINO43_MIN_TILES); '1': every supported no-grad launch;
+# '0': never.  The engines only offer the operand for save=False forwards (UNetEngine._conv).
+_w43 = os.environ.get('DP_WINO43', 'auto')
+WINO43 = {'0': False, '': False, '1': True}.get(_w43, 'auto')
+WINO43_MIN_TILES = int(os.environ.get('DP_WINO43_MIN_TILES', '512'))      # 64 x 256-pixel tiles (with split-K for smaller grids)
+
+
+def wino43_wanted(M, C_sources, N, H, W, spec):
+    """Host-side mirror of wino43_ok (csrc/winograd43.hip) + the grid rule: a no-grad 3x3 / stride 1 / pad 1 convolution that
+    should go to dp_conv_wino43."""
+    if not WINO43 or not WINO or getattr(spec, 'keep', False) or getattr(spec, 'sym', False):
+        return False
+    if not (spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad_h == 1 and spec.pad_w == 1 and not spec.ups):
+        return False
+    if W < 4 or W > 256 or (W & (W - 1)) or ((H * W) & 3) or any(c % 8 for c in C_sources) or M < 16:
+        return False
+    tiles = -(-M // 64) * -(-(N * H * W) // 256)
+    if tiles >= WINO43_MIN_TILES:
+        return True
+    n_iter = 3 * (sum(C_sources) // 8)
+    ks = min(WINO43_MIN_TILES // max(tiles, 1), n_iter // 8)
+    return ks >= 2 and tiles * ks >= WINO43_MIN_TILES // 2
+
+
+def pack_weight_wino43(w):
+    """U[(ky*6 + pos)*Ci + c][ld] for dp_conv_wino43 from a [Co, Ci, 3, 3] weight (forward flavour only)."""
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.is_cuda and w.dtype == _f32 and w.is_contiguous()
+    Co, Ci = w.shape[0], w.shape[1]
+    ld = roundup4(Co)
+    dst = torch.empty(18 * Ci * ld, dtype=_f32, device=w.device)
+    L.check(_lib().dp_pack_weight_wino43(_p(w), Co, Ci, _p(dst), ld, _stream()), 'dp_pack_weight_wino43')
+    return dst, ld
+
+
+def _wino43_name(p):
+    return 'conv_wino43_kernel'
+
+
+def _conv_wino43(p, wino43, act_bytes):
+    """Run the filled parameter block through dp_conv_wino43 when the kernel takes the shape and the grid is big enough (split-K
+    for small grids, like _conv_wino); False = the caller goes on to F(2, 3) / the direct form."""
+    if not WINO43:
+        return False
+    U, ld = wino43
+    tiles = -(-p.M // 64) * -(-p.NPIX // 256)
+    ks = 1
+    if tiles < WINO43_MIN_TILES:
+        n_iter = 3 * (p.C // 8)
+        ks = min(WINO43_MIN_TILES // max(tiles, 1), n_iter // 8)
+        if ks < 2 or tiles * ks < WINO43_MIN_TILES // 2:
+            return False
+    A0, lda0, ab0 = p.A, p.lda, p.a_bytes
+    p.A, p.lda, p.a_bytes = _p(U), ld, U.numel() * 4
+    if ks > 1:
+        ws_t = _workspace(ks * p.M * p.NPIX, U.device)
+        p._keep = (ws_t,)
+        p.ksplit, p.ws, p.tile_counters = ks, _p(ws_t), None
+    if not _lib().dp_conv_wino43_supported(C.byref(p)):
+        p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
+        return False
+    L.check(_run(lambda: _lib().dp_conv_wino43(C.byref(p), _stream()), _wino43_name(p), 2.0 * p.M * p.NPIX * p.C * 4.5,
+                 act_bytes + 4.0 * U.numel()), 'dp_conv_wino43')
+    return True
+
+
 def _conv_wino(p, wino, act_bytes):
     """Run the filled parameter block through dp_conv_wino when the kernel takes the shape and the grid is big enough; False =
     the caller launches the direct form."""
@@ -406,7 +472,7 @@ def _wgrad_wino_name(p, bt):
 
 
 def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, post_scale=1.0, alpha=1.0, out=None,
-                 accumulate=False, relu=False, wino=None):
+                 accumulate=False, relu=False, wino=None, wino43=None):
     """out[N, Cout, Ho, Wo] = conv(cat(x, x2)) (+bias) (+tadd[n, co]) (+res) ; * post_scale.
     wp/ld: pack_weight(w, 0).  tadd: [N, Cout] per-image per-channel addend (time-embedding projection).
     wino: pack_weight_wino(w, 0) -- the launch goes to the Winograd F(2, 3) kernel when it takes the shape (see _conv_wino)."""
@@ -443,6 +509,8 @@ def conv_forward(x, x2, wp, ld, Cout, spec, *, bias=None, tadd=None, res=None, p
         p.res, p.r_img_stride = _p(res), _chk_act(res)
         assert res.shape == out.shape
     p.accumulate = 1 if accumulate else 0
+    if wino43 is not None and _conv_wino43(p, wino43, 4.0 * (N * Cin * Hs * Ws + out.numel())):
+        return out
     if wino is not None and _conv_wino(p, wino, 4.0 * (N * Cin * Hs * Ws + out.numel())):
         return out
     _conv_ksplit(p, x.device)

@@ -78,6 +78,17 @@ int dp_conv_splitk_epilogue(const dp_conv_gemm_params* p, void* stream);
  * dst holds 12 * K * ld floats. */
 int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);
 
+/* The same convolution as Winograd F(4, 3) along W (csrc/winograd43.hip): HALF the multiplies of dp_conv_gemm (6 per 4 outputs x 3
+ * taps), for the forwards that keep nothing for a backward -- the sampling loops (diffusers/pipelines/ddim/pipeline_ddim.py:101-116,
+ * pipelines/ddpm/pipeline_ddpm.py:87-96) and the CFG sampler of the LDM importance pass (ldm_exp/prune_ldm.py:111-118,
+ * ldm/models/diffusion/ddim.py:165-203).  fp32 error vs fp64 ~1e-6 (F(2, 3): ~3e-7): not used for scored gradients.  Same parameter
+ * block, epilogue and split-K contract as dp_conv_wino; A is dp_pack_weight_wino43's operand U[(ky*6 + pos)*C + c][lda]
+ * (forward flavour only; dst holds 18 * Ci * ld floats).  Takes W a power of two in 4..256, channel counts per concat source in
+ * multiples of 8, pixel count / image strides in multiples of 4, 16-byte aligned tensors. */
+int dp_conv_wino43(const dp_conv_gemm_params* p, void* stream);
+int dp_conv_wino43_supported(const dp_conv_gemm_params* p);
+int dp_pack_weight_wino43(const float* W, int Co, int Ci, float* dst, int ld, void* stream);
+
 /* D[m][c][tap] = alpha * sum_pix A[m][pix] * X(pix, c, tap)  -- weight gradients (split over pixels, one kernel tap
  * per workgroup) and the k-contiguous batched products of attention (P.V, dQ).  Replaces the weight-gradient half of
  * ConvolutionBackward / AddmmBackward reached from loss.backward() (ddpm_prune.py:102) and torch.bmm

@@ -2063,7 +2063,8 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
     csrc = os.path.join(ROOT, 'diff-pruning_amd', 'csrc')
-    want = {'gemm.hip': ('conv_gemm_fast_kernel', 'nt_gemm_fast_kernel'), 'winograd.hip': ('conv_wino_kernel', 'wgrad_wino_kernel')}
+    want = {'gemm.hip': ('conv_gemm_fast_kernel', 'nt_gemm_fast_kernel'), 'winograd.hip': ('conv_wino_kernel', 'wgrad_wino_kernel'),
+            'winograd43.hip': ('conv_wino43_kernel',)}
     checked = 0
     for src, kernels in want.items():
         out = str(tmp_path / (src + '.s'))

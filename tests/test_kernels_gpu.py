@@ -1114,6 +1114,44 @@ def test_pack_weight_batch_equals_per_layer_pack(ops):
 
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
+                                             (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (1, 32, 0, 48, 256),
+                                             (12, 384, 0, 384, 32), (6, 192, 192, 100, 16)], ids=str)
+def test_conv_winograd_f43_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
+    """dp_conv_wino43 (3x3 / stride 1 / pad 1 as a one-dimensional Winograd F(4, 3) implicit GEMM: half the multiplies; the no-grad
+    forwards only) against the fp64 convolution: two concat sources, bias, per-image addend, residual, scale, ReLU-free and
+    accumulate forms, output-channel tails, 8-channel K chunks, W = 4 ... 256, tiles spanning several images, split-K -- next to
+    F(2, 3)'s and the direct kernel's error on the same inputs.  Bar: 5e-6 of the output scale (the verdict's gate), run-to-run
+    bit-identical."""
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+    monkeypatch.setattr(ops, 'WINO43', True)
+    monkeypatch.setattr(ops, 'WINO43_MIN_TILES', 0)
+    xa, xb = rnd(N, C1, H, H, seed=1), (rnd(N, C2, H, H, seed=2) if C2 else None)
+    w = rnd(Cout, C1 + C2, 3, 3, seed=3, scale=0.05)
+    b, tadd, res = rnd(Cout, seed=4), rnd(N, Cout, seed=6), rnd(N, Cout, H, H, seed=7)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    U2, U4 = ops.pack_weight_wino(w, 0), ops.pack_weight_wino43(w)
+    x = torch.cat([xa, xb], 1) if C2 else xa
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    ref = (ref + tadd.double().cpu()[:, :, None, None] + res.double().cpu()) * 0.7
+    launched = []
+    real = ops._conv_wino43
+    monkeypatch.setattr(ops, '_conv_wino43', lambda *a: (lambda r: (launched.append(bool(r)), r)[1])(real(*a)))
+    y4 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino43=U4)
+    y4b = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino43=U4)
+    y2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U2)
+    yd = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7)
+    acc = res.clone()
+    ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc, accumulate=True, alpha=0.5, wino43=U4)
+    ref_acc = res.double().cpu() + 0.5 * torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    assert launched == [True, True, True], launched            # the kernel took every launch (incl. the split-K ones of small grids)
+    e4, e2, ed, ea = relerr(y4, ref), relerr(y2, ref), relerr(yd, ref), relerr(acc, ref_acc)
+    report['conv/winograd_f43/%d+%d_%d_%d_%d' % (C1, C2, Cout, H, N)] = dict(f43=e4, f23=e2, direct=ed, accumulate=ea)
+    assert torch.equal(y4, y4b)
+    assert e4 < 5e-6 and ea < 5e-6, (e4, ea)
+
+
+@pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
                                              (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (1, 32, 0, 48, 256)], ids=str)
 def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_conv_wino (3x3 / stride 1 / pad 1 as a one-dimensional Winograd F(2, 3) implicit GEMM) against the fp64 convolution,

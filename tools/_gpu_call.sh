@@ -1,18 +1,15 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out
-python -m pytest tests/test_e2e_gpu.py -q -x -k "general_cross_attention or multi_head or tiny_sweep or cifar_c1 or ldm_unet or ldm_prune or ldm_importance or bedroom_topology or autograd_bridge or two_timesteps or hipgraph" --durations=5 2>&1 | tail -8
-python -m pytest tests/test_rccl_gpu.py -q 2>&1 | tail -2
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/r5_bench_c.json 2> $O/r5_bench_c.err
-DP_NO_FUSED_QKV_WGRAD=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $O/r5_bench_c_noqkv.json 2>/dev/null
-python bench.py --config c4_finetune --no-roofline > $O/r5_c4_c.json 2>/dev/null
-python bench.py --config bedroom256 --no-roofline --no-cpu-baseline > $O/r5_bedroom_c.json 2>/dev/null
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "f43" 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_e2e_gpu.py -q -x -k "winograd_f43" 2>&1 | tail -8
+python tools/bench_wino.py 2>&1 | grep -v amdgpu.ids > $O/r5_winograd_gate.txt; cat $O/r5_winograd_gate.txt
+for v in 0 1; do
+DP_WINO43=$v python bench.py --config ddim --no-roofline > $O/r5_ddim_w43_$v.json 2>/dev/null
+DP_WINO43=$v python bench.py --config ldm --steps 2 --warmup 1 --no-roofline > $O/r5_ldm_w43_$v.json 2>/dev/null
+done
 python - <<'PY'
 import json
-for f in ('r5_bench_c','r5_bench_c_noqkv','r5_c4_c','r5_bedroom_c'):
+for f in ('r5_ddim_w43_0','r5_ddim_w43_1','r5_ldm_w43_0','r5_ldm_w43_1'):
     try:
-        d=json.load(open('gpurun_out/%s.json'%f)); c=d['config']
-        print(f, round(d['value'],1), d['unit'], 'ms/step', round(d['ms_per_step'],2), 'launches', c.get('kernel_launches_per_step'))
-        r=d.get('roofline')
-        if r:
-            for k,v in sorted(r['kernels'].items(), key=lambda kv:-kv[1]['ms'])[:8]: print('      %-55s %4d %7.2f ms %6.1f TF/s'%(k,v['launches'],v['ms'],v['tflops']))
-    except Exception as e: print(f, 'ERR', e)
+        d=json.load(open('gpurun_out/%s.json'%f)); print(f, round(d['value'],2), d['unit'], 'ms/step', round(d['ms_per_step'],2))
+    except Exception as e: print(f,'ERR',e)
 PY

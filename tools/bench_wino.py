@@ -21,7 +21,8 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n
 
 
-print('shape                     direct ms (TF/s)    winograd ms (ref-eq TF/s, executed TF/s)   speedup   max rel diff')
+ops.WINO43, ops.WINO43_MIN_TILES = True, 0
+print('shape                     direct ms (TF/s)    winograd ms (ref-eq TF/s, executed TF/s)   speedup   max rel diff   [fwd: F(4, 3) ms (ref-eq TF/s), vs F(2, 3), max rel diff]')
 for (ci, c2, co, h) in [(256, 0, 256, 16), (128, 0, 128, 32), (128, 128, 128, 32), (256, 0, 256, 8), (192, 0, 192, 16), (96, 0, 96, 32), (384, 0, 384, 32)]:
     bb = B if ci < 384 else 12
     x = ops.empty_act((bb, ci, h, h), torch.device('cuda')).normal_()
@@ -56,5 +57,11 @@ for (ci, c2, co, h) in [(256, 0, 256, 16), (128, 0, 128, 32), (128, 128, 128, 32
         td, tw = timeit(f_d), timeit(f_w)
         fl = 2.0 * bb * h * h * (ci + c2) * co * 9
         diff = float((y1 - y2).abs().max() / y1.abs().max())
-        print('%-5s %3d+%-3d->%3d @%2dx%-2d  %.3f (%.1f)   %.3f (%.1f, %.1f)   %.2fx   %.1e' % (name, ci, c2, co, h, h, td, fl / td / 1e9, tw, fl / tw / 1e9,
-              fl * 2 / 3 / tw / 1e9, td / tw, diff))
+        extra = ''
+        if mode == 0:                         # the go / no-go gate of round 4's verdict, item 5: F(4, 3) forward against F(2, 3)
+            U4 = ops.pack_weight_wino43(w)
+            y3 = ops.empty_act((bb, co, h, h), x.device)
+            t4 = timeit(lambda: ops.conv_forward(x, x2, wp, ld, co, spec, out=y3, wino43=U4))
+            extra = '   [%.3f (%.1f)  %.2fx  %.1e]' % (t4, fl / t4 / 1e9, tw / t4, float((y1 - y3).abs().max() / y1.abs().max()))
+        print('%-5s %3d+%-3d->%3d @%2dx%-2d  %.3f (%.1f)   %.3f (%.1f, %.1f)   %.2fx   %.1e%s' % (name, ci, c2, co, h, h, td, fl / td / 1e9, tw, fl / tw / 1e9,
+              fl * 2 / 3 / tw / 1e9, td / tw, diff, extra))

@@ -27,6 +27,7 @@ cg, nt = ops._cg_name, ops._nt_name
 ops._cg_name = lambda p: 'cg M=%d C=%d N=%d taps=%d ks=%d z=%d' % (p.M, p.C, p.NPIX, p.ntaps, p.ksplit, p.batches)
 ops._nt_name = lambda p: 'nt M=%d NC=%d P=%d taps=%d sp=%d z=%d' % (p.M, p.NCOLS, p.P, p.ntaps, p.splits, p.batches)
 ops._wino_name = lambda p, bk, wr: 'wino M=%d C=%d N=%d W=%d ks=%d bk=%d wr=%d' % (p.M, p.C, p.NPIX, p.g.Wo, p.ksplit, bk, wr)
+ops._wino43_name = lambda p: 'wino43 M=%d C=%d N=%d W=%d ks=%d' % (p.M, p.C, p.NPIX, p.g.Wo, p.ksplit)
 ops._wgrad_wino_name = lambda p, bt: 'wgwino M=%d NC=%d P=%d sp=%d bt=%d' % (p.M, p.NCOLS, p.P, p.splits, bt)
 dev = torch.device('cuda')
 B = args.batch
