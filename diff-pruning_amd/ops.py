@@ -368,10 +368,14 @@ def pack_weight_wino(w, mode):
 
 
 # ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------
-# 'auto': where tools/bench_wino.py measured it faster than F(2, 3) (see WINO43_MIN_TILES); '1': every supported no-grad launch;
-# '0': never.  The engines only offer the operand for save=False forwards (UNetEngine._conv).
-_w43 = os.environ.get('DP_WINO43', 'auto')
-WINO43 = {'0': False, '': False, '1': True}.get(_w43, 'auto')
+# DEFAULT OFF -- the go / no-go gate of the round-4 verdict (item 5) came out NO-GO [measured, profiles/round5_winograd_gate.txt]:
+# against F(2, 3), forward, batch 256: 128 -> 128 @ 32 x 32 1.23x, 192 -> 192 @ 16 x 16 1.20x, 128 + 128 -> 128 @ 32 x 32 1.20x, but
+# 256 -> 256 @ 16 x 16 1.04x (1024 workgroups of 64 x 256 pixels on 768 resident slots: a round and a third), 96 -> 96 @ 32 x 32
+# 0.92x (64-row tiles fill 75 %), 384 -> 384 @ 32 x 32 at 12 latents 0.84x; fp32 error 4-7e-6 of the output scale (gate: 5e-6).
+# End to end with every supported no-grad launch on it: DDIM step 13.72 -> 13.18 ms, LDM importance step 505.8 -> 496.7 ms.
+# DP_WINO43=1: every supported no-grad launch (the engines only offer the operand for save=False forwards, UNetEngine._conv).
+_w43 = os.environ.get('DP_WINO43', '0')
+WINO43 = {'0': False, '': False, '1': True}.get(_w43, False)
 WINO43_MIN_TILES = int(os.environ.get('DP_WINO43_MIN_TILES', '512'))      # 64 x 256-pixel tiles (with split-K for smaller grids)
 
 
