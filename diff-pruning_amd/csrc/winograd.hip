@@ -320,27 +320,19 @@ extern "C" int dp_conv_wino(const dp_conv_gemm_params* pp, void* stream) {
     if (p.M <= 0 || p.NPIX <= 0) return 0;
     int bk = wino_bk(p);
     if (!bk) return (int)hipErrorInvalidValue;
-    static const char* force = getenv("DP_WINO_BK");
-    if (force && atoi(force) == 8) bk = 8;
-    // 32-row tiles when they pad fewer rows than 64-row tiles (M = 96, 288, ...)
-    static const char* fwr = getenv("DP_WINO_WR");
-    const bool wr1 = p.g.Wo > 128 || (fwr ? atoi(fwr) == 1 : ((p.M + 31) / 32) * 32 < ((p.M + 63) / 64) * 64);
+    // 32-row tiles when they pad fewer rows than 64-row tiles (M = 96, 288, ...).  Settled A/Bs, no run-time switch any more (DESIGN.md
+    // section 5): 8-channel chunks where 16 apply (round 4: +-2 % by shape; round 5 per shape, profiles/round5_winograd_gate.txt: 16
+    // equal or better everywhere), the 64-row WAVE tile <8, 2, 2> (round 4: +2 % on the largest grids, -10 ... -35 % on the small ones).
+    const bool wr1 = p.g.Wo > 128 || ((p.M + 31) / 32) * 32 < ((p.M + 63) / 64) * 64;
     hipStream_t st = (hipStream_t)stream;
     if (wr1) {
         dim3 grid((p.NPIX + 255) / 256, (p.M + 31) / 32, p.ksplit > 1 ? p.ksplit : 1);
         if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 1>), grid, dim3(256), 0, st, p);
         else          DP_LAUNCH((conv_wino_kernel<8, 1>), grid, dim3(256), 0, st, p);
     } else {
-        static const char* ftm = getenv("DP_WINO_TM");
-        const int tm_want = ftm ? atoi(ftm) : 1;
-        if (tm_want == 2 && p.M % 128 == 0) {
-            dim3 grid((p.NPIX + 127) / 128, p.M / 128, p.ksplit > 1 ? p.ksplit : 1);
-            DP_LAUNCH((conv_wino_kernel<8, 2, 2>), grid, dim3(256), 0, st, p);
-        } else {
-            dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : 1);
-            if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
-            else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
-        }
+        dim3 grid((p.NPIX + 127) / 128, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : 1);
+        if (bk == 16) DP_LAUNCH((conv_wino_kernel<16, 2>), grid, dim3(256), 0, st, p);
+        else          DP_LAUNCH((conv_wino_kernel<8, 2>), grid, dim3(256), 0, st, p);
     }
     const int e = DP_LAUNCH_CHECK();
     if (e || p.ksplit <= 1) return e;

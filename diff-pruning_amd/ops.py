@@ -167,10 +167,11 @@ def pick_tile(M, N, z=1):
 
 
 CONV_SPLITK_BLOCKS = int(os.environ.get('DP_CONV_SPLITK_BLOCKS', '512'))      # split the K loop of forward / dgrad convolutions when the 128x128 grid is smaller
-CONV_SPLITK_MID = not os.environ.get('DP_NO_SPLITK_MID')
-_n64 = os.environ.get('DP_CONV_N64', '0')         # default off: measured null (118.7 vs 124.4 TFLOP/s in isolation, 87.4 = 87.4 ms per step)
-CONV_N64_MAXK = int(os.environ.get('DP_CONV_N64_MAXK', '1000000'))      # ... and only K loops of at most this many K tiles
-CONV_N64_TILES = tuple(int(v) for v in _n64.split(',')) if _n64 not in ('0', '') else None      # [lo, hi) 128x128-tile counts run as 128x64
+# Settled A/Bs of earlier rounds, kept as module constants (no environment switch any more; history in DESIGN.md section 5):
+CONV_SPLITK_MID = True           # split K for one-to-two-round grids (256 < tiles < 512)  [round 3: LDM CFG forward 29.7 -> 26.8 ms]
+CONV_N64_MAXK = 1000000
+CONV_N64_TILES = None            # [lo, hi) 128x128-tile counts that would run as 128x64 tiles: measured null in round 2 (118.7 vs 124.4
+                                 # TFLOP/s in isolation, 87.4 = 87.4 ms per step); the kernel variant stays for tests/test_cpu.py's name mirror
 
 
 def _conv_ksplit(p, device):
@@ -178,7 +179,7 @@ def _conv_ksplit(p, device):
     layers, small batches): big tiles keep the MFMA efficiency, the K loop supplies the parallelism."""
     p.ksplit, p.ws = 1, None
     tiles = -(-p.M // 128) * -(-p.NPIX // 128)
-    # Experiment knob (DP_CONV_N64=lo,hi): launches of fewer than two rounds of 128x128 workgroups run as 128x64 tiles -- twice
+    # Round-2 experiment (CONV_N64_TILES = (lo, hi)): launches of fewer than two rounds of 128x128 workgroups run as 128x64 tiles -- twice
     # the workgroups, so that the ramp / store burst of one round overlaps the K loop of the other.  Measured null: the
     # narrower tile loses in the K loop what the second round gains (DESIGN.md section 4).
     if (CONV_N64_TILES and p.tile == 0 and p.batches <= 1 and CONV_N64_TILES[0] <= tiles < CONV_N64_TILES[1]
