@@ -1,2 +1,1 @@
-bash tools/run_evidence.sh pmc 2>&1 | tail -8
-ls -la gpurun_out/round5_pmc*
+bash tools/run_evidence.sh tests 2>&1 | tail -30
