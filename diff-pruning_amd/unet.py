@@ -278,12 +278,13 @@ class UNet2DModel(nn.Module):
         """The no-grad forward of a sampling loop (pipeline_ddim.py:101-116, pipeline_ddpm.py:87-96) as a callable
         `f(sample, t: int) -> eps` plus `f.close()`.  The weights are frozen for the lifetime of `f` (`pin_weights`).
         With `replay` (default: automatic -- a cuda model in eval mode without foreign forward hooks, called at least
-        REPLAY_MIN_CALLS times; DP_SAMPLE_REPLAY=0 disables) the forward is captured ONCE at `shape` and every call re-issues its
-        ~180 launches from the library's C loop (ops.CapturedCall, csrc/replay.hip): same kernels, same arguments, same order ->
-        the same bits as the eager call, without ~10 ms of Python / ctypes per UNet forward."""
+        REPLAY_MIN_CALLS times; DP_SAMPLE_REPLAY=0 never, =1 from the first call) the forward is captured ONCE at `shape` and every
+        call re-issues its ~180 launches from the library's C loop (ops.CapturedCall, csrc/replay.hip): same kernels, same
+        arguments, same order -> the same bits as the eager call, without ~10 ms of Python / ctypes per UNet forward."""
         import os
         if replay is None:
-            replay = (os.environ.get('DP_SAMPLE_REPLAY', '1') != '0' and n_calls >= REPLAY_MIN_CALLS and not self.training
+            env = os.environ.get('DP_SAMPLE_REPLAY')
+            replay = (env != '0' and n_calls >= (1 if env == '1' else REPLAY_MIN_CALLS) and not self.training
                       and self.conv_in.weight.device.type == 'cuda' and self._leaf_hook_owner() is None
                       and not self.__dict__.get('_structure_tracing') and hasattr(torch.cuda, 'CUDAGraph'))
         return _CapturedForward(self, shape) if replay else _EagerForward(self)
@@ -447,7 +448,10 @@ class UNet2DModel(nn.Module):
         return UNet2DOutput(sample=out)
 
 
-REPLAY_MIN_CALLS = 8          # a capture costs about two eager forwards
+# A capture costs an eager forward + the capture pass + the node read-back (~35 ms for the 195 nodes of the CIFAR UNet) and the packed
+# operands are only valid for ONE pinned scope (the next pipeline call captures again), while a GPU-bound step gains ~0.6 ms from
+# the replay (batch 256: 14.12 -> 13.54 ms) and a host-bound one several ms: from 32 calls on it pays in both regimes.
+REPLAY_MIN_CALLS = 32
 
 
 class _EagerForward:

@@ -1542,7 +1542,7 @@ def test_finetune_step_replayed_natively_equals_eager(report, monkeypatch, overl
 
 def test_sampling_forward_replayed_natively_equals_eager(report, monkeypatch):
     """Round 5 (verdict item 2a): the UNet forward of a DDIM / DDPM sampling loop captured once and re-issued natively
-    (UNet2DModel.sampling_forward, used by both pipelines from 8 steps on): images BIT-identical to the eager loop."""
+    (UNet2DModel.sampling_forward; automatic from 32 steps on, forced here with DP_SAMPLE_REPLAY=1): images BIT-identical to the eager loop."""
     diffusion, unet = pkg('diffusion'), pkg('unet')
     model = make_model(gc.TINY_CFG, 5)
     out = {}
