@@ -70,8 +70,12 @@ else:
             with torch.no_grad():
                 model(clean, tt)
     else:
-        step = sweep.HipSweepStep(model, diffusion.DDPMScheduler(), clean, noise, B * 3 * H * H, 'mse', B)
-        step.eng.overlap_wgrad = False          # one kernel on the GPU at a time: clean per-shape durations
+        # ONE timestep pipeline and no weight-gradient side stream: one kernel on the GPU at a time, clean per-shape durations.  (Until
+        # round 5 this tool inherited the sweep's default of two timesteps in flight for big shards: consecutive steps ran on two
+        # streams and stretched each other's event-timed kernels -- the tables of rounds 3-5 UNDERSTATE the big shapes' TFLOP/s by
+        # 10-25 %; an isolated loop of the same launch, profiles/round5_wino_isolated.txt, is the cross-check.)
+        step = sweep.HipSweepStep(model, diffusion.DDPMScheduler(), clean, noise, B * 3 * H * H, 'mse', B, timestep_pipelines=1)
+        step.eng.overlap_wgrad = False
 step(0); step(1)
 torch.cuda.synchronize()
 agg = {}
