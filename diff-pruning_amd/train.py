@@ -233,7 +233,9 @@ class FinetuneEngine:
         import os
         model, dev = self.model, self.flat_p.device
         table = getattr(model, 'dropout_table', dict)()
-        key = (tuple(clean.shape), int(image_offset), int(gb), tuple(sorted(table.items())))
+        # everything the captured launches carry as immediate arguments: a change of any of them builds a new capture
+        key = (tuple(clean.shape), int(image_offset), int(gb), tuple(sorted(table.items())),
+               self.max_grad_norm, self.eps, self.ema_decay, tuple(self.betas))
         cap = self._cap
         if cap is None or cap['key'] != key:
             hyper = torch.zeros(4, dtype=torch.float32, device=dev)
