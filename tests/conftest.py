@@ -13,6 +13,11 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle legs are fp32 PyTorch on the HOST: 32 x 32-pixel convolutions at batch <= 128 are oversubscribed on the GPU box's 256
+    # cores (bench.py's cpu_baseline sweep, profiles/round5_bench_line.json: 52.6 images/s on 16 threads, 28.7 on 32, 6.3 on 128).
+    # DP_TEST_THREADS overrides; machines with fewer cores keep what they have.
+    import torch
+    torch.set_num_threads(min(int(os.environ.get('DP_TEST_THREADS', '16')), torch.get_num_threads()))
 
 
 @pytest.fixture(scope='session')

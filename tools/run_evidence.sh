@@ -23,7 +23,7 @@ pmc() {  # config suffix ('' = cifar256), counters..., -- bench arguments: one -
 }
 case "$1" in
 tests)
-  python -m pytest tests -m gpu -q --durations=12 > $O/${R}_gpu_tests.log 2>&1; tail -20 $O/${R}_gpu_tests.log
+  python -m pytest tests -m gpu -q --durations=25 > $O/${R}_gpu_tests.log 2>&1; tail -20 $O/${R}_gpu_tests.log
   cp $O/test_report.json $O/${R}_test_report.json ;;
 bench)
   python bench.py --steps 20 --warmup 5 > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 600 $O/${R}_bench_line.json
