@@ -1579,6 +1579,66 @@ def test_sampling_forward_replayed_natively_equals_eager(report, monkeypatch):
     report['e2e/sampling_replay'] = out
 
 
+def test_replay_at_the_benchmarked_sizes(report, monkeypatch):
+    """The replayed paths at the sizes `bench.py --config c4_finetune / ddim` times them (BASELINE.json configs[3] and the sampling of
+    its model): the ratio-0.3 pruned CIFAR UNet (19 851 157 parameters), (a) four optimizer steps at batch 128 with dropout 0.1 --
+    the first eager, three replayed natively with the engine's own stream rule -- against the eager engine: losses, gradient norms,
+    parameters, Adam moments and EMA weights BIT-identical; (b) a 40-step DDIM loop at batch 256, where the automatic rule (>= 32
+    calls) takes the captured forward, against DP_SAMPLE_REPLAY=0: images BIT-identical."""
+    train, diffusion, sweep, unet = pkg('train'), pkg('diffusion'), pkg('sweep'), pkg('unet')
+
+    def pruned():
+        model = make_model(gc.CIFAR_CFG, 0)
+        clean, noise = _inputs(4, 32)
+        _run_sweep(model, clean, noise, 8)
+        sweep.prune_model(model, 0.3)
+        for p in model.parameters():
+            p.grad = None
+        return model
+
+    B = 128
+    gen = torch.Generator().manual_seed(23)
+    batches = [(torch.from_numpy(gc.det_clean((B, 3, 32, 32), 70 + k)).to(DEV), torch.from_numpy(gc.det_noise((B, 3, 32, 32), 80 + k)).to(DEV),
+                train.antithetic_timesteps(B, 1000, gen).to(DEV)) for k in range(4)]
+    res = {}
+    for replay in (False, True):
+        model = pruned()
+        assert sum(p.numel() for p in model.parameters()) == 19851157
+        ft = train.FinetuneEngine(model, diffusion.DDPMScheduler(), lr=2e-4, dropout=0.1, dropout_seed=31, replay=replay)
+        out = []
+        for c, n, t in batches:
+            loss = ft.step(c, n, t)
+            out.append((float(loss), float(ft.last_grad_norm)))
+        torch.cuda.synchronize()
+        res[replay] = (ft, out, model)
+    (fe, oe, _), (fr, orr, m_r) = res[False], res[True]
+    assert fe._cap is None and fr._cap is not None and fr._cap['call'].replay is not None
+    assert oe == orr, (oe, orr)
+    assert torch.equal(fe.flat_p, fr.flat_p) and torch.equal(fe.ema, fr.ema) and torch.equal(fe.m, fr.m) and torch.equal(fe.v, fr.v)
+    info = fr._cap['call'].info
+    # (b) sampling with the finetuned weights of (a)
+    m_r.eval()
+    pipe = diffusion.DDIMPipeline(m_r, diffusion.DDIMScheduler())
+    imgs, kinds = {}, {}
+    real = unet.UNet2DModel.sampling_forward
+    for mode in (None, '0'):
+        if mode is None:
+            monkeypatch.delenv('DP_SAMPLE_REPLAY', raising=False)
+        else:
+            monkeypatch.setenv('DP_SAMPLE_REPLAY', mode)
+        made = []
+        monkeypatch.setattr(unet.UNet2DModel, 'sampling_forward',
+                            lambda self, *a, **k: (lambda f: (made.append(type(f).__name__), f)[1])(real(self, *a, **k)))
+        imgs[mode] = pipe(batch_size=256, generator=torch.Generator().manual_seed(5), num_inference_steps=40, eta=0.0,
+                          output_type='numpy').images
+        monkeypatch.setattr(unet.UNet2DModel, 'sampling_forward', real)
+        kinds[mode] = made
+    assert kinds[None] == ['_CapturedForward'] and kinds['0'] == ['_EagerForward'], kinds
+    assert np.array_equal(imgs[None], imgs['0'])
+    report['e2e/replay_at_bench_sizes'] = dict(finetune_losses=[a[0] for a in orr], finetune_replay=info,
+                                               ddim_steps=40, ddim_batch=256, image_mean=float(np.abs(imgs[None]).mean()))
+
+
 @pytest.mark.parametrize('L_ctx', [3, 5, 77])
 def test_ldm_general_cross_attention_matches_oracle(report, L_ctx):
     """Round 5: cross-attention over L > 1 context tokens on the HIP kernels (ldm/modules/attention.py:152-193, general form; 77 = a
