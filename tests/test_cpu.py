@@ -2223,3 +2223,22 @@ def test_lsun_ffhq_lmdb_datasets(tmp_path):
     loader = data.DeviceLoader if hasattr(data, 'DeviceLoader') else None
     assert loader is not None
 
+
+
+def test_committed_pmc_traffic_was_measured_on_these_kernel_sources():
+    """`roofline.traffic` on the bench line comes from committed rocprofv3 --pmc passes (they cannot run inside bench.py): the newest
+    file of every config must carry the hash of TODAY's contraction-kernel sources (csrc/gemm.hip + csrc/winograd.hip) and its own
+    config name, or bench.py reports `traffic: null` (bench._pmc_traffic) -- this test makes a stale file a red CPU suite, not a silent null."""
+    import glob
+    import hashlib
+    import json
+    src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
+    blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
+    for sfx, cfg in (('', 'cifar256'), ('_c4_finetune', 'c4_finetune'), ('_ldm', 'ldm')):
+        cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))
+        assert cand, cfg
+        pm = json.load(open(cand[-1]))
+        assert pm.get('_gemm_hip_blob') == blob, (cand[-1], 'measured on other kernel sources: re-run tools/run_evidence.sh pmc')
+        assert pm.get('_config', 'cifar256') == cfg, cand[-1]
+        dom = [k for k, v in pm.items() if isinstance(v, dict) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v]
+        assert dom, cand[-1]
