@@ -181,7 +181,9 @@ class SweepWorkload:
                                          timestep_pipelines=pipelines)
 
     def warmup(self, W):
-        for k in range(W):
+        # every timestep pipeline is created by its first step: a warm-up shorter than the number of pipelines (--warmup 1) would
+        # leave that one-off (~0.3 s of allocations) inside the timed region, so W >= 1 warms each pipeline at least once
+        for k in range(max(W, getattr(self.step, '_tp_want', 1)) if W else 0):
             self.step(k)
         if self.env.args.graph:
             self.step.capture()
