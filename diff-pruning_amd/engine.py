@@ -34,6 +34,10 @@ RES_LDM = dict(norm1='.in_layers.0', conv1='.in_layers.2', temb='.emb_layers.1',
                conv2='.out_layers.3', shortcut='.skip_connection')
 
 
+# most bytes of side-stream operands kept alive between two joins of the weight-gradient stream (UNetEngine._side_stream)
+SIDE_KEEP_MAX_BYTES = int(float(os.environ.get('DP_SIDE_KEEP_GB', '4')) * (1 << 30))
+
+
 def _low_priority_stream(device):
     """Side stream for the weight-gradient work at the LOWEST HIP priority: the backward chain on the main stream gets
     the CUs first, the side stream fills what is left.  torch only exposes priorities <= 0, so the stream is created
@@ -150,6 +154,8 @@ class UNetEngine:
         self.overlap_wgrad = False if os.environ.get('DP_NO_OVERLAP') else (True if os.environ.get('DP_OVERLAP') else None)
         self._overlap_now = True
         self._side, self._side_dev = None, None
+        self._side_keep = []                 # tensors the side stream reads, alive until the next join (_side_stream)
+        self._side_keep_bytes = 0
         # Dropout (training mode only; utils.set_dropout, ddpm_train.py:380-382): {module name: p} of the nn.Dropout
         # holders with p > 0, or None.  Masks are Philox functions of (seed, crc32(module name), step, element index):
         # the backward regenerates them, nothing is stored (csrc/dp_common.h).
@@ -366,15 +372,26 @@ class UNetEngine:
 
     def _side_stream(self, *tensors):
         """Fork: returns the side stream (ordered after everything enqueued so far on the current stream) or None.
-        `tensors` are read by the side-stream work: the allocator must not recycle them before that work is done."""
+        `tensors` are read by the side-stream work: the allocator must not recycle them before that work is done.  They are
+        kept ALIVE (a reference each) until the next join instead of being handed to `Tensor.record_stream`: a recorded block is
+        only reusable once an event on the side stream has been seen complete by a later allocation, so with the host a few
+        timesteps ahead of the device every block of those timesteps is still pending and the allocator reserves new memory
+        instead -- [measured, round 6, CIFAR UNet batch 256, tools/mem_probe.py] 124 GB reserved after 300 timesteps for a 10 GB
+        working set, the whole 288 GB within a 1000-timestep sweep, after which the HIP runtime's own allocations (scratch,
+        kernel arguments, "svm hidden buffer") start to fail: the abort of the round-5 driver run.  A block released AFTER the join
+        is reused by main-stream work that is ordered behind the join, i.e. behind its last side-stream reader."""
         if not self._overlap_now or not hasattr(torch.cuda, 'current_stream') or tensors[0].device.type != 'cuda':
             return None
         if self._side is None or self._side_dev != tensors[0].device:        # the model may have moved to another GPU
+            self._join_side()
             self._side, self._side_dev = _low_priority_stream(tensors[0].device), tensors[0].device
+        if self._side_keep_bytes > SIDE_KEEP_MAX_BYTES:
+            self._join_side()                    # bounds what a backward pass keeps alive beyond its own needs; same kernels and chains
         self._side.wait_stream(torch.cuda.current_stream())
         for t in tensors:
             if t is not None:
-                t.record_stream(self._side)
+                self._side_keep.append(t)
+                self._side_keep_bytes += t.numel() * t.element_size()
         return self._side
 
     def replay_side_stream(self, device):
@@ -387,6 +404,8 @@ class UNetEngine:
     def _join_side(self):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        self._side_keep.clear()                  # (after the join: see _side_stream)
+        self._side_keep_bytes = 0
 
     def _conv_bwd(self, name, dy, x, x2, spec, in_hw, *, need_dx=True, rows=None, dx_out=None, dx_accumulate=False,
                   alpha=1.0, dx_add=None):

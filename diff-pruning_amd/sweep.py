@@ -24,6 +24,13 @@ GRAPH_AUTO_PIXELS = 8192        # taylor_sweep(use_graph=None): shards up to thi
 # (without the weight-gradient side streams: 79.1 with two).  Two is the default for plain Taylor sweeps.
 TIMESTEP_PIPELINES = 2
 GRAPH_AUTO_STEPS = 64           # ... swept for at least this many timesteps replay one captured timestep (native replay list)
+# A plain Taylor sweep never reads anything back, so nothing stops the host from enqueueing hundreds of timesteps ahead of the
+# device: every cross-stream event, kernel-argument block and allocator block of those timesteps is then outstanding at once
+# (round 6: the allocator's reserved memory grew to the whole HBM within a 1000-timestep sweep at batch 256 -- DESIGN.md section 5
+# "Round 6").  HipSweepStep.__call__ lets the host run at most this many timesteps ahead (over all timestep pipelines): it waits
+# for the event recorded behind timestep k - MAX_STEPS_AHEAD before enqueueing timestep k.  The device never runs dry (4 steps =
+# 45 ... 250 ms of queued work) and a GPU-bound sweep loses nothing.  0 = unbounded.
+MAX_STEPS_AHEAD = int(os.environ.get('DP_MAX_STEPS_AHEAD', '4'))
 
 
 def dist_active(group=None):
@@ -34,6 +41,30 @@ def dist_active(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size(group) > 1 or os.environ.get('DP_FORCE_DIST') == '1'
+
+
+class StepThrottle:
+    """`mark(stream)` behind every enqueued step: records 'step enqueued' on the stream the step ran on and first waits (host) for
+    the mark `max_ahead` steps back -- see MAX_STEPS_AHEAD.  Events are reused round-robin; `wait_s` accumulates the host's waits."""
+
+    def __init__(self, max_ahead=None):
+        self.max_ahead = MAX_STEPS_AHEAD if max_ahead is None else max_ahead
+        self.ring, self.i, self.wait_s = [], 0, 0.0
+
+    def mark(self, stream=None):
+        n = self.max_ahead
+        if n <= 0 or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return
+        slot = self.i % n
+        if len(self.ring) < n:
+            self.ring.append(torch.cuda.Event())
+        elif not self.ring[slot].query():                # recorded n steps ago
+            import time
+            t0 = time.perf_counter()
+            self.ring[slot].synchronize()
+            self.wait_s += time.perf_counter() - t0
+        self.ring[slot].record(stream if stream is not None else torch.cuda.current_stream())
+        self.i += 1
 
 
 def flatten_grads(model):
@@ -296,22 +327,39 @@ class HipSweepStep:
             eng.backward(dout)
         return loss
 
+    def _throttle(self, stream=None):
+        if self.clean.device.type != 'cuda':
+            return
+        th = self.__dict__.get('_th')
+        if th is None:
+            th = self._th = StepThrottle()
+        th.mark(stream)
+        self.throttle_wait_s = th.wait_s
+
+    throttle_wait_s = 0.0
+
     def __call__(self, k):
         if self._tp_want >= 2 and self.stop_state is None and self._graph is None and self.micro is None and not self.sequential:
             tps = self._tp if self._tp is not None else self._make_timestep_pipelines()
             i = self._tp_count % (len(tps) + 1)                # round-robin: main pipeline first
             self._tp_count += 1
             if i:
-                return self._second_pipeline_step(k, tps[i - 1])
+                loss = self._second_pipeline_step(k, tps[i - 1])
+                self._throttle(tps[i - 1]['stream'])
+                return loss
         if self._graph is not None:
             self._t.fill_(int(k))
             if self._replay is not None:
                 self._replay.launch(self.eng.replay_side_stream(self.clean.device))
             else:
                 self._graph.replay()
-            return self._loss.clone()
+            loss = self._loss.clone()
+            self._throttle()
+            return loss
         t = torch.full((self.B,), int(k), dtype=torch.long, device=self.clean.device)
-        return self._step(t)          # [1] device tensor: this rank's share of L_t
+        loss = self._step(t)          # [1] device tensor: this rank's share of L_t
+        self._throttle()
+        return loss
 
 
 def _f32_lt_prod(loss, loss_max, thr):
@@ -348,6 +396,7 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     import torch.distributed as dist
     t_start = time.perf_counter()
     poll_wait = 0.0
+    throttle_wait0 = float(getattr(step_fn, 'throttle_wait_s', 0.0))
     use_dist = dist_active(group)
     B_local = clean_images.shape[0]
     per_img = clean_images[0].numel()
@@ -447,8 +496,10 @@ def taylor_sweep(model, scheduler, clean_images, noise, num_steps=1000, thr=None
     if timings is not None:
         # host time spent ENQUEUEING: the waits inside the polls of the on-device early exit (which drain the queue) are not part
         # of it -- with them the figure is just the step time (bedroom-256: 58.07 of a 58.08 ms step in round 3)
-        timings['enqueue_s'] = time.perf_counter() - t_start - poll_wait
+        throttle_wait = float(getattr(step_fn, 'throttle_wait_s', 0.0)) - throttle_wait0     # the host waiting for the device (MAX_STEPS_AHEAD) is not enqueue work
+        timings['enqueue_s'] = time.perf_counter() - t_start - poll_wait - throttle_wait
         timings['poll_wait_s'] = poll_wait
+        timings['throttle_wait_s'] = throttle_wait
     if hasattr(step_fn, 'finish'):
         step_fn.finish()
     if pending:

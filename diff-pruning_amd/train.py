@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import ops
-from .sweep import dist_active
+from .sweep import StepThrottle, dist_active
 
 
 def antithetic_timesteps(bsz, num_train_timesteps, generator=None):
@@ -146,7 +146,9 @@ class FinetuneEngine:
         4-word buffer written by ONE by-value launch per step (ops.set_step_scalars); the weight re-packing is part of the
         captured step.  Same kernels, arguments and order as the eager step -> the same bits."""
         self.replay = replay
-        self._cap = None
+        self._caps = None            # {capture key: captured step} (_step_replayed)
+        self._seen = {}              # {batch shape: eager steps run at it}
+        self._throttle = StepThrottle()
         if dropout is not None:
             set_dropout(model, float(dropout))
         self.model, self.scheduler = model, scheduler
@@ -219,6 +221,12 @@ class FinetuneEngine:
         self._weights_changed()
 
     REPLAY_OVERLAP = None        # weight-gradient side stream inside the captured step: None = the engine's own rule (by step size)
+    MAX_CAPTURES = 2             # captured steps kept alive at once (full batch + the partial last batch of an epoch)
+
+    @property
+    def _cap(self):
+        """The most recently built captured step, or None."""
+        return next(reversed(self._caps.values())) if self._caps else None
 
     def _replay_wanted(self, use_dist, dev):
         import os
@@ -234,10 +242,23 @@ class FinetuneEngine:
         model, dev = self.model, self.flat_p.device
         table = getattr(model, 'dropout_table', dict)()
         # everything the captured launches carry as immediate arguments: a change of any of them builds a new capture
-        key = (tuple(clean.shape), int(image_offset), int(gb), tuple(sorted(table.items())),
+        key = (tuple(clean.shape), int(image_offset), int(gb), tuple(sorted(table.items())), int(self.dropout_seed),
                self.max_grad_norm, self.eps, self.ema_decay, tuple(self.betas))
-        cap = self._cap
-        if cap is None or cap['key'] != key:
+        if self._caps is None:
+            self._caps = {}
+        cap = self._caps.get(key)
+        if cap is None:
+            # One capture per key, at most MAX_CAPTURES alive (the partial last batch of an epoch is a second shape: with
+            # drop_last=False it alternates with the full one, and re-capturing at every epoch boundary would hold the old pool, the
+            # new pool and the eager step's cache at once).  Each capture's private pool pins every activation of a training
+            # step, so the oldest goes -- and its pool is returned to the device -- BEFORE the new one is built.
+            while len(self._caps) >= self.MAX_CAPTURES:
+                old_key = next(iter(self._caps))
+                torch.cuda.synchronize(dev)               # nothing of the old capture may still be in flight when its pool goes
+                del self._caps[old_key]
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
             hyper = torch.zeros(4, dtype=torch.float32, device=dev)
             st = dict(key=key, hyper=hyper, clean=ops.empty_act(tuple(clean.shape), dev), noise=ops.empty_act(tuple(noise.shape), dev),
                       t=torch.zeros(clean.shape[0], dtype=torch.long, device=dev))
@@ -269,7 +290,7 @@ class FinetuneEngine:
             finally:
                 eng.overlap_wgrad = saved_overlap
                 eng.set_dropout(None)
-            self._cap = cap = st
+            self._caps[key] = cap = st
         if clean.data_ptr() != cap['clean'].data_ptr():
             cap['clean'].copy_(clean)
         if noise.data_ptr() != cap['noise'].data_ptr():
@@ -280,13 +301,15 @@ class FinetuneEngine:
         self.last_lr = lr
         ops.set_step_scalars(cap['hyper'], lr, self.betas[0], self.betas[1], self.step_count)
         loss, nc = cap['call'].launch()
-        self.last_grad_norm = nc[0:1]
+        self.last_grad_norm = nc[0:1].clone()              # (the captured tensors are overwritten by the next step)
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()                       # ddpm_train.py:464
         eng = getattr(model, '_engine', None)
         if eng is not None:
             eng.packs.clear()
-        return loss.clone()                                # the captured tensor is overwritten by the next step
+        loss = loss.clone()                                # the captured tensor is overwritten by the next step
+        self._throttle.mark()
+        return loss
 
     def step(self, clean, noise, timesteps, global_batch=None, image_offset=None):
         """Returns the (local share of the) loss as a [1] device tensor; no host synchronisation.
@@ -301,7 +324,11 @@ class FinetuneEngine:
         model = self.model
         model.train()                                     # ddpm_train.py:430
         dev = self.flat_p.device
-        if self.step_count >= 1 and self._replay_wanted(use_dist, dev):     # the first step runs eagerly (lazy operands, streams)
+        # a batch shape runs eagerly the first time it is seen (lazy operands, streams, code objects: CapturedCall's precondition)
+        shape_key = tuple(clean.shape)
+        seen = self._seen.get(shape_key, 0)
+        self._seen[shape_key] = seen + 1
+        if seen >= 1 and self.step_count >= 1 and self._replay_wanted(use_dist, dev):
             return self._step_replayed(clean.to(dev, torch.float32).contiguous(), noise.to(dev, torch.float32).contiguous(),
                                        timesteps.to(device=dev, dtype=torch.long).contiguous(), gb, image_offset)
         clean = clean.to(dev, torch.float32).contiguous()
@@ -346,4 +373,5 @@ class FinetuneEngine:
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()                       # ddpm_train.py:464
         eng.packs.clear()                                  # weights changed: packed operands are stale
+        self._throttle.mark()                              # no host read-back in a step: bound how far the host runs ahead
         return loss

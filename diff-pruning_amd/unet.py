@@ -286,6 +286,7 @@ class UNet2DModel(nn.Module):
             env = os.environ.get('DP_SAMPLE_REPLAY')
             replay = (env != '0' and n_calls >= (1 if env == '1' else REPLAY_MIN_CALLS) and not self.training
                       and self.conv_in.weight.device.type == 'cuda' and self._leaf_hook_owner() is None
+                      and not self._forward_hooks and not self._forward_pre_hooks        # module-level hooks see eager calls only
                       and not self.__dict__.get('_structure_tracing') and hasattr(torch.cuda, 'CUDAGraph'))
         return _CapturedForward(self, shape) if replay else _EagerForward(self)
 
@@ -492,6 +493,9 @@ class _CapturedForward:
             raise
 
     def __call__(self, sample, t):
+        if self._pin is None:
+            # the capture holds the ADDRESSES of the pinned packed operands: after close() they may have been freed or recycled
+            raise RuntimeError('sampling_forward: called after close() (the captured forward\'s packed operands are no longer pinned)')
         self.x.copy_(sample)
         if torch.is_tensor(t) and t.dim() > 0 and t.numel() > 1:
             self.t.copy_(t)
@@ -501,6 +505,9 @@ class _CapturedForward:
 
     def close(self):
         if self._pin is not None:
+            if getattr(self, 'call', None) is not None:
+                torch.cuda.synchronize(self.model.device)    # no replayed launch may still read the operands about to be unpinned
+                self.call = None                             # ... or the capture's pool, which goes with the graph
             self._pin.__exit__(None, None, None)
             self._pin = None
 

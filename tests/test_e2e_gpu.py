@@ -3,11 +3,14 @@
 Bars: prune masks (integer channel indices) bit-exact; fp32 tensors within the tolerance written at each assert
 (fp32 kernels with a different summation order than ATen-CPU: 1e-5 relative per tensor for single passes,
 2e-5 for accumulated gradients)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import golden_common as gc
+from conftest import isolated, run_isolated
 from helpers import load_json, load_npz, make_model, oracle_params, pkg, relerr, oracle_prune_replay
 
 pytestmark = pytest.mark.gpu
@@ -616,6 +619,7 @@ def test_long_sweep_1000_steps_matches_reference(report):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+@isolated()
 def test_c1_size_1000_step_sweep_masks_match_reference(report):
     """Config C2's accumulation length on the C1-size model: CIFAR-10 UNet (35.7 M parameters), B=4, 1000 accumulated
     timesteps, against a 1000-step run of the reference itself (tests/golden/cifar_long_sweep.json): losses, gradient
@@ -646,6 +650,7 @@ def test_c1_size_1000_step_sweep_masks_match_reference(report):
     assert sum(p.numel() for p in model.parameters()) == fx['params_after']
 
 
+@isolated()
 def test_c3_bedroom256_full_size(report):
     """BASELINE.json configs[2] at its real size: google/ddpm-ema-bedroom-256 topology (113.7 M parameters), 256x256 images,
     4 images per GPU (batch 32 over 8 GPUs), Diff-Pruning threshold 0.05:
@@ -919,6 +924,7 @@ def test_dropout_finetune_forward_backward_matches_reference(report):
     assert e_l < 1e-5 and not bad and e_out < 1e-4 and e_bridge < 1e-6, bad[:3]
 
 
+@isolated()
 def test_c4_pruned_cifar_finetune_with_dropout(report):
     """BASELINE.json configs[3] as the reference runs it (scripts/finetune_ddpm_cifar10.sh): the ratio-0.3 PRUNED CIFAR-10 UNet
     (19 851 157 parameters), batch 128 per GPU, dropout 0.1, lr 2e-4, EMA 0.9999, two optimizer steps: loss and raw
@@ -1178,6 +1184,7 @@ def _ldm_masks(model):
     return pr
 
 
+@isolated()
 def test_c5_ldm_cin256_full_size(report):
     """BASELINE.json configs[4] at its real size: the cin256-v2 UNet (400 920 579 parameters), 6 latents of 3 x 64 x 64, one
     512-wide class token, 20 CFG-DDIM steps per importance step (prune_ldm.py:103-131) -- through size-independent properties:
@@ -1294,76 +1301,133 @@ def test_c5_ldm_cin256_full_size(report):
     assert e_x0 < 1e-4 and e_l < 1e-5 and worst < 5e-5                                 # (d)
 
 
-def test_c2_cifar_batch256_1000_steps_as_written(report):
-    """BASELINE.json configs[1] run as written: CIFAR-10 UNet, batch 256, the full 1000-timestep Taylor sweep + prune
-    (ddpm_prune.py:94-109).  One full-batch run and the two 128-image shares of a 2-rank job (scaled for the global batch as
-    the data-parallel path scales them): the masks from the summed shares equal the full-batch masks for all 50 groups, and the
-    smallest decision margin of the 1000 x 256 run is reported next to the observed score difference.  The same 1000 x 256 sweep on
-    the direct kernels only (no Winograd): the same 50 masks, score movement an order of magnitude inside the margin."""
-    from oracle import pruning_ref as R
+C2_LEGS = ('full_wino', 'full_direct', 'shard0', 'shard1')
+
+
+def _c2_store():
+    """Where the legs of config C2 leave their results for the comparison test: a directory named in the environment, so the child
+    interpreters of `isolated` see the one their parent made (the parent makes it when this module is imported)."""
+    import tempfile
+    d = os.environ.get('DP_C2_STORE')
+    if not d or not os.path.isdir(d):
+        d = tempfile.mkdtemp(prefix='dp_c2_')
+        os.environ['DP_C2_STORE'] = d
+    return d
+
+
+if os.environ.get('DP_TEST_CHILD') != '1' and torch.cuda.is_available():
+    _c2_store()
+
+
+@pytest.mark.parametrize('leg', C2_LEGS)
+@isolated(params=('leg',))
+def test_c2_cifar_batch256_1000_steps_leg(leg, report):
+    """One 1000-timestep sweep of BASELINE.json configs[1] (CIFAR-10 UNet, batch 256; ddpm_prune.py:94-109) per leg, each in its own
+    interpreter (<= 75 s): the full batch on the default (Winograd) dispatch, the full batch on the direct kernels only, and the two
+    128-image shares of a 2-rank job scaled for the global batch as the data-parallel path scales them.  Each leg leaves its losses,
+    its flat gradient buffer and (full-batch legs) its prune records for test_c2_cifar_batch256_1000_steps_as_written."""
     sweep, diffusion = pkg('sweep'), pkg('diffusion')
+    from oracle import pruning_ref as R
     cfg, B, steps = gc.CIFAR_CFG, 256, 1000
     clean, noise = _inputs(B, 32, 11, 12)
     clean, noise = clean.to(DEV), noise.to(DEV)
     sched = diffusion.DDPMScheduler()
+    lo, hi = {'full_wino': (0, B), 'full_direct': (0, B), 'shard0': (0, B // 2), 'shard1': (B // 2, B)}[leg]
 
-    def run(lo, hi, n_steps=steps):
+    def run(n_steps, direct):
         model = make_model(cfg, 0)
         flat = sweep.flatten_grads(model)
         step = sweep.HipSweepStep(model, sched, clean[lo:hi], noise[lo:hi], B * clean[0].numel(), 'mse', B)
-        res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, step_fn=step, flat_grads=flat)
-        torch.cuda.synchronize()
+        if direct:
+            with _direct_kernels():
+                res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, step_fn=step, flat_grads=flat)
+                torch.cuda.synchronize()
+        else:
+            res = sweep.taylor_sweep(model, sched, clean[lo:hi], noise[lo:hi], num_steps=n_steps, step_fn=step, flat_grads=flat)
+            torch.cuda.synchronize()
         return model, flat, res
 
-    m_full, g_full, r_full = run(0, B)
-    assert r_full['steps'] == steps and len(r_full['losses']) == steps
-    # Winograd F(2, 3) vs the direct kernels on this configuration (a 24-timestep sweep each: the relative movement of an
-    # accumulated score does not grow with the number of accumulated timesteps): same 50 masks, score movement reported
-    short = {}
-    for key in ('wino', 'direct'):
-        if key == 'direct':
+    def records(model, direct=False):
+        if direct:
             with _direct_kernels():
-                m_s, _, _ = run(0, B, 24)
+                pr = sweep.prune_model(model, 0.3)
         else:
-            m_s, _, _ = run(0, B, 24)
-        short[key] = sweep.prune_model(m_s, 0.3).records
-        del m_s
-    mism_direct = [a[0] for a, b in zip(short['wino'], short['direct']) if a[3] != b[3]]
+            pr = sweep.prune_model(model, 0.3)
+        return [(root, chg, torch.as_tensor(sc).cpu(), [int(i) for i in pruned]) for root, chg, sc, pruned in pr.records]
+
+    out = {}
+    model, flat, res = run(steps, leg == 'full_direct')
+    assert res['steps'] == steps and len(res['losses']) == steps
+    out['losses'] = res['losses']
+    if leg != 'full_direct':
+        out['flat'] = flat.cpu()
+    if leg.startswith('full'):
+        out['records'] = records(model, leg == 'full_direct')
+        out['params_after'] = sum(p.numel() for p in model.parameters())
+    if leg == 'shard0':
+        # Winograd F(2, 3) vs the direct kernels on a 24-timestep sweep each (the relative movement of an accumulated score does not
+        # grow with the number of accumulated timesteps; the full-length comparison is legs full_wino / full_direct)
+        lo, hi = 0, B
+        del model, flat
+        for key in ('wino', 'direct'):
+            m_s, _, _ = run(24, key == 'direct')
+            out['short_' + key] = records(m_s, key == 'direct')
+            del m_s
+    torch.save(out, os.path.join(_c2_store(), leg + '.pt'))
+
+
+def test_c2_cifar_batch256_1000_steps_as_written(report, tmp_path):
+    """BASELINE.json configs[1] run as written: CIFAR-10 UNet, batch 256, the full 1000-timestep Taylor sweep + prune
+    (ddpm_prune.py:94-109).  One full-batch run and the two 128-image shares of a 2-rank job: the masks from the summed shares equal
+    the full-batch masks for all 50 groups, and the smallest decision margin of the 1000 x 256 run is reported next to the observed
+    score difference.  The same 1000 x 256 sweep on the direct kernels only (no Winograd): the same 50 masks, score movement an order
+    of magnitude inside the margin.  The four sweeps are the legs above (one interpreter each); a leg that has not run yet is run."""
+    from oracle import pruning_ref as R
+    sweep = pkg('sweep')
+    store, legs = _c2_store(), {}
+    for leg in C2_LEGS:
+        path = os.path.join(store, leg + '.pt')
+        if not os.path.exists(path):
+            rc, tail, _ = run_isolated('tests/test_e2e_gpu.py::test_c2_cifar_batch256_1000_steps_leg[%s]' % leg, tmp_path)
+            assert rc == 0, (leg, rc, tail)
+        legs[leg] = torch.load(path, weights_only=False)
+    cfg, B, steps = gc.CIFAR_CFG, 256, 1000
+    full, direct, s0, s1 = (legs[k] for k in C2_LEGS)
+    e_loss = max(abs((a + b) - c) / c for a, b, c in zip(s0['losses'], s1['losses'], full['losses']))
+    g_sum = s0['flat'].to(DEV) + s1['flat'].to(DEV)                           # what the all-reduce leaves on every rank
+    e_grad = relerr(g_sum, full['flat'])
+    m_sum = make_model(cfg, 0)
+    sweep.flatten_grads(m_sum).copy_(g_sum)
+    rec_sum = sweep.prune_model(m_sum, 0.3).records
+    rec_full, rec_d = full['records'], direct['records']
+    mism = [a[0] for a, b in zip(rec_full, rec_sum) if list(a[3]) != list(b[3])]
+    margin = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in rec_full)
+    e_score = max(relerr(b[2], a[2]) for a, b in zip(rec_full, rec_sum))
+    mism_direct_full = [a[0] for a, b in zip(rec_full, rec_d) if list(a[3]) != list(b[3])]
+    e_wino_score_full = max(relerr(a[2], b[2]) for a, b in zip(rec_full, rec_d))
+    e_wino_loss_full = max(abs(a - b) / b for a, b in zip(full['losses'], direct['losses']))
+    short = {k: s0['short_' + k] for k in ('wino', 'direct')}
+    mism_direct = [a[0] for a, b in zip(short['wino'], short['direct']) if list(a[3]) != list(b[3])]
     e_wino_score = max(relerr(a[2], b[2]) for a, b in zip(short['wino'], short['direct']))
     margin_short = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in short['direct'])
-    # ... and at full length (round 5, after the host-thread cap freed half of the suite's time): the whole 1000-timestep sweep on
-    # the direct kernels only -- the claim above is measured, not argued
-    with _direct_kernels():
-        m_d, _, r_d = run(0, B)
-    pr_d = sweep.prune_model(m_d, 0.3)
-    del m_d
-    m1, g1, r1 = run(0, B // 2)
-    m2, g2, r2 = run(B // 2, B)
-    e_loss = max(abs((a + b) - c) / c for a, b, c in zip(r1['losses'], r2['losses'], r_full['losses']))
-    e_grad = relerr(g1 + g2, g_full)
-    g1.add_(g2)                                                               # what the all-reduce leaves on every rank
-    pr_full = sweep.prune_model(m_full, 0.3)
-    pr_sum = sweep.prune_model(m1, 0.3)
-    mism = [a[0] for a, b in zip(pr_full.records, pr_sum.records) if a[3] != b[3]]
-    margin = min(R.decision_margin(sc, pruned, len(sc), chg) for _, chg, sc, pruned in pr_full.records)
-    e_score = max(relerr(b[2], a[2]) for a, b in zip(pr_full.records, pr_sum.records))
-    mism_direct_full = [a[0] for a, b in zip(pr_full.records, pr_d.records) if a[3] != b[3]]
-    e_wino_score_full = max(relerr(a[2], b[2]) for a, b in zip(pr_full.records, pr_d.records))
-    e_wino_loss_full = max(abs(a - b) / b for a, b in zip(r_full['losses'], r_d['losses']))
-    report['e2e/c2_as_written'] = dict(steps=steps, batch=B, loss_rel=e_loss, shard_grad_rel=e_grad, groups=len(pr_full.records),
+    params_sum = sum(p.numel() for p in m_sum.parameters())
+    report['e2e/c2_as_written'] = dict(steps=steps, batch=B, loss_rel=e_loss, shard_grad_rel=e_grad, groups=len(rec_full),
                                        wino_vs_direct_score_rel_1000_steps=e_wino_score_full, wino_vs_direct_loss_rel_1000_steps=e_wino_loss_full,
                                        wino_vs_direct_mask_mismatches_1000_steps=mism_direct_full,
                                        mask_mismatches=mism, min_decision_margin=margin, shard_score_rel_worst=e_score,
-                                       params_after=sum(p.numel() for p in m_full.parameters()),
+                                       params_after=full['params_after'],
                                        wino_vs_direct_score_rel_24_steps=e_wino_score, wino_vs_direct_mask_mismatches_24_steps=mism_direct,
                                        min_decision_margin_24_steps=margin_short)
     assert e_loss < 1e-5 and e_grad < 5e-5                                    # fp32 re-association over 1000 accumulations
-    assert len(pr_full.records) == len(pr_sum.records) == 50 and not mism
+    assert len(rec_full) == len(rec_sum) == 50 and not mism
     assert not mism_direct and margin_short > 10 * e_wino_score
     # the decisions are an order of magnitude outside the shard re-association and the Winograd-vs-direct movement of the scores
     assert margin > 10 * max(e_score, e_wino_score, e_wino_score_full)
-    assert len(pr_d.records) == 50 and not mism_direct_full and e_wino_loss_full < 1e-5
-    assert sum(p.numel() for p in m_full.parameters()) == sum(p.numel() for p in m1.parameters())
+    assert len(rec_d) == 50 and not mism_direct_full and e_wino_loss_full < 1e-5
+    assert full['params_after'] == direct['params_after'] == params_sum == 19851157
+    import shutil
+    shutil.rmtree(store, ignore_errors=True)
+    os.environ.pop('DP_C2_STORE', None)
 
 
 def test_batched_prune_tail_equals_member_by_member(report, monkeypatch):
