@@ -35,6 +35,7 @@ RES_LDM = dict(norm1='.in_layers.0', conv1='.in_layers.2', temb='.emb_layers.1',
 
 
 # most bytes of side-stream operands kept alive between two joins of the weight-gradient stream (UNetEngine._side_stream)
+SIDE_RECORD_STREAM = os.environ.get('DP_SIDE_RECORD_STREAM') == '1'
 SIDE_KEEP_MAX_BYTES = int(float(os.environ.get('DP_SIDE_KEEP_GB', '4')) * (1 << 30))
 
 
@@ -389,9 +390,13 @@ class UNetEngine:
             self._join_side()                    # bounds what a backward pass keeps alive beyond its own needs; same kernels and chains
         self._side.wait_stream(torch.cuda.current_stream())
         for t in tensors:
-            if t is not None:
-                self._side_keep.append(t)
-                self._side_keep_bytes += t.numel() * t.element_size()
+            if t is None:
+                continue
+            if SIDE_RECORD_STREAM:               # the round-5 form, kept ONLY so that tools/abort_repro.py can show the failure it caused
+                t.record_stream(self._side)
+                continue
+            self._side_keep.append(t)
+            self._side_keep_bytes += t.numel() * t.element_size()
         return self._side
 
     def replay_side_stream(self, device):

@@ -90,6 +90,15 @@ def report():
         pass
 
 
+_SIGNALLED = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    for node, rc, tail in _SIGNALLED:
+        terminalreporter.write_line('[dp-test] CHILD KILLED BY SIGNAL %d (re-run once): %s' % (-rc, node))
+        terminalreporter.write_line(tail)
+
+
 def run_isolated(nodeid, tmp_dir, timeout=900, extra_env=None):
     """Run ONE test node in a child interpreter (the driver's own pytest flags) and return (returncode, tail of its output,
     its report dict).  A signal in the child (SIGABRT = -6, SIGSEGV = -11) is one red test carrying the child's stderr --
@@ -133,6 +142,13 @@ def isolated(timeout=900, params=()):
             request = kwargs.pop('request')
             tmp = request.getfixturevalue('tmp_path')
             rc, tail, rep = run_isolated(request.node.nodeid, tmp, timeout)
+            if isinstance(rc, int) and rc < 0:
+                # killed by a signal (SIGABRT -6, SIGSEGV -11, SIGKILL -9): keep the evidence -- log line, report entry, terminal
+                # summary -- and run the node ONCE more, so that a crash that depends on the lease's timing is recorded as such
+                # (first attempt died, second passed / died again) instead of ending the suite with the other rows unrun
+                _SIGNALLED.append((request.node.nodeid, rc, tail[-1500:]))
+                _REPORT.setdefault('harness/child_signals', []).append(dict(node=request.node.nodeid, rc=rc, tail=tail[-1500:]))
+                rc, tail, rep = run_isolated(request.node.nodeid, tmp, timeout)
             _REPORT.update(rep)
             assert rc == 0, 'child interpreter for %s ended with %s\n%s' % (request.node.nodeid, rc, tail)
 

@@ -1356,8 +1356,17 @@ def test_c2_cifar_batch256_1000_steps_leg(leg, report):
         return [(root, chg, torch.as_tensor(sc).cpu(), [int(i) for i in pruned]) for root, chg, sc, pruned in pr.records]
 
     out = {}
+    torch.cuda.reset_peak_memory_stats()
     model, flat, res = run(steps, leg == 'full_direct')
     assert res['steps'] == steps and len(res['losses']) == steps
+    # Regression test of the round-5 abort (DESIGN.md section 5 "Round 6"): with Tensor.record_stream on the weight-gradient stream's
+    # operands the allocator RESERVED ~104 GB in this very sweep for a 10 GB working set (+ ~55 GB for every further sweep of the
+    # process, each on fresh streams) until the device had 0 bytes free.  Now: a small multiple of what is allocated, no retries.
+    st = torch.cuda.memory_stats()
+    mem = dict(reserved_peak_gb=st['reserved_bytes.all.peak'] / 2**30, allocated_peak_gb=st['allocated_bytes.all.peak'] / 2**30,
+               alloc_retries=st['num_alloc_retries'], free_gb=torch.cuda.mem_get_info()[0] / 2**30)
+    report['e2e/c2_memory_' + leg] = mem
+    assert mem['reserved_peak_gb'] < 64 and mem['alloc_retries'] == 0 and mem['free_gb'] > 200, mem
     out['losses'] = res['losses']
     if leg != 'full_direct':
         out['flat'] = flat.cpu()
