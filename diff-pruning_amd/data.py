@@ -251,6 +251,32 @@ class FfhqLmdb:
         return np.asarray(img, dtype=np.uint8)
 
 
+def ffhq_split_indices(num_items):
+    """ddpm_exp/datasets/__init__.py:166-177: the 90 / 10 split of FFHQ -- list(range(N)) shuffled by the LEGACY global numpy
+    generator seeded with 2019 (the caller's generator state is saved and restored around it), first int(0.9 N) indices train,
+    the rest test.  Both branches: training never sees the held-out tenth."""
+    indices = list(range(num_items))
+    state = np.random.get_state()
+    np.random.seed(2019)
+    np.random.shuffle(indices)
+    np.random.set_state(state)
+    cut = int(num_items * 0.9)
+    return indices[:cut], indices[cut:]
+
+
+class IndexSubset:
+    """torch.utils.data.Subset for the array-returning datasets of this module."""
+
+    def __init__(self, dataset, indices):
+        self.dataset, self.indices = dataset, list(indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        return self.dataset[self.indices[i]]
+
+
 class ArrayDataset:
     """uint8 images already in memory: [N, H, W, C] (hwc=True) or [N, C, H, W]."""
 
@@ -397,10 +423,9 @@ def dataset_from_config(data, root='data', train=True):
             return _c(_r(img))
         return Lsun(os.path.join(root, 'lsun'), ['%s_%s' % (data['category'], 'train' if train else 'val')], tf), kw
     if name == 'FFHQ':                               # __init__.py:142-157: the stored resolution, no resize
-        if not train:
-            raise NotImplementedError('the reference splits FFHQ 90 / 10 with a seeded numpy permutation (datasets/__init__.py:159-170): '
-                                      'build the Subset over FfhqLmdb with those indices')
-        return FfhqLmdb(os.path.join(root, 'FFHQ'), size), kw
+        ds = FfhqLmdb(os.path.join(root, 'FFHQ'), size)
+        train_idx, test_idx = ffhq_split_indices(len(ds))
+        return IndexSubset(ds, train_idx if train else test_idx), kw
     raise ValueError('unknown dataset %r' % (data['dataset'],))
 
 

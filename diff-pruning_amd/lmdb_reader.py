@@ -54,6 +54,8 @@ class Environment:
         main = self.meta['main']
         if main['flags'] & 0x04:                       # MDB_DUPSORT
             raise LmdbError('duplicate-sorted main database: not a store the reference writes')
+        if main['flags'] & (0x02 | 0x08):              # MDB_REVERSEKEY | MDB_INTEGERKEY: get() descends in memcmp key order only
+            raise LmdbError('main database with MDB_REVERSEKEY / MDB_INTEGERKEY (flags 0x%x): keys are not in memcmp order' % main['flags'])
         self.entries, self.root, self.depth = main['entries'], main['root'], main['depth']
 
     def _meta(self, off):

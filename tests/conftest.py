@@ -108,7 +108,9 @@ def run_isolated(nodeid, tmp_dir, timeout=900, extra_env=None):
     env = dict(os.environ, DP_TEST_CHILD='1', DP_TEST_REPORT=rep_path, PYTHONFAULTHANDLER='1')
     env.setdefault('AMD_LOG_LEVEL', '1')                     # HIP runtime errors only; they land in the child's log
     env.update(extra_env or {})
-    cmd = [sys.executable, '-m', 'pytest', nodeid, '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '--capture=sys', '--durations=0']
+    nodeids = [nodeid] if isinstance(nodeid, str) else list(nodeid)
+    nodeid = nodeids[0] if len(nodeids) == 1 else '%s (+%d)' % (nodeids[0], len(nodeids) - 1)
+    cmd = [sys.executable, '-m', 'pytest'] + nodeids + ['-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '--capture=sys', '--durations=0']
     t0 = time.time()
     with open(log_path, 'wb') as log:
         try:

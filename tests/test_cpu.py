@@ -2218,8 +2218,27 @@ def test_lsun_ffhq_lmdb_datasets(tmp_path):
             fimgs[(r, i)] = rng.integers(0, 256, size=(r, r, 3), dtype=np.uint8)
             ff[('%d-%05d' % (r, i)).encode()] = png(fimgs[(r, i)])
     write_lmdb(str(tmp_path / 'data' / 'FFHQ'), ff)
+    # the 90 / 10 split of datasets/__init__.py:166-177 (seeded legacy numpy shuffle, caller's generator state untouched): index
+    # lists recorded from the reference's own lines (tests/golden/make_golden_ffhq_split.py)
+    import hashlib
+    for case in load_json('ffhq_split.json')['cases']:
+        np.random.seed(777)
+        before = np.random.get_state()[1][:4].tolist()
+        tr, te = data.ffhq_split_indices(case['n'])
+        assert np.random.get_state()[1][:4].tolist() == before
+        assert (len(tr), len(te)) == (case['n_train'], case['n_test'])
+        assert hashlib.sha256(np.asarray(tr, dtype=np.int64).tobytes()).hexdigest() == case['train_sha256']
+        assert hashlib.sha256(np.asarray(te, dtype=np.int64).tobytes()).hexdigest() == case['test_sha256']
+        if 'train' in case:
+            assert tr == case['train'] and te == case['test']
+    split3 = [c for c in load_json('ffhq_split.json')['cases'] if c['n'] == 3][0]
     f16, kw = data.dataset_from_config(dict(cfg, dataset='FFHQ', image_size=16), root=str(tmp_path / 'data'))
-    assert len(f16) == 3 and np.array_equal(f16[2], fimgs[(16, 2)]) and np.array_equal(data.FfhqLmdb(str(tmp_path / 'data' / 'FFHQ'), 8)[1], fimgs[(8, 1)])
+    f16_test, _ = data.dataset_from_config(dict(cfg, dataset='FFHQ', image_size=16), root=str(tmp_path / 'data'), train=False)
+    assert len(f16) == 2 and len(f16_test) == 1                      # training never sees the held-out tenth
+    for j, i in enumerate(split3['train']):
+        assert np.array_equal(f16[j], fimgs[(16, i)])
+    assert np.array_equal(f16_test[0], fimgs[(16, split3['test'][0])])
+    assert np.array_equal(data.FfhqLmdb(str(tmp_path / 'data' / 'FFHQ'), 8)[1], fimgs[(8, 1)])
     loader = data.DeviceLoader if hasattr(data, 'DeviceLoader') else None
     assert loader is not None
 

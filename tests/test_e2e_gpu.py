@@ -1786,3 +1786,20 @@ def test_no_grad_forwards_with_winograd_f43_on_every_supported_layer(which, repo
     report['wino43_forced/' + which] = dict(sub, f43_launches=n[0])
     assert n[0] > 0
 
+
+
+def test_ieee_sigmoid_build_gives_the_same_masks(report, tmp_path):
+    """The default build evaluates sigmoid / SiLU as v_exp_f32 + v_rcp_f32 (csrc/dp_common.h, DP_FAST_SIGMOID) in every kernel of
+    the SCORED forward and backward; `-DDP_IEEE_SIGMOID` builds expf + the IEEE division (__graft_entry__.build() compiles both).
+    The fixtures with the thinnest decision margins -- written by the reference itself -- are run on the exact build too, in a child
+    interpreter with DP_HIP_LIB pointing at it: bit-exact masks on BOTH builds (this suite runs them on the default one)."""
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'diff-pruning_amd', 'libdp_hip_ieee.so')
+    assert os.path.exists(lib), 'libdp_hip_ieee.so is built by __graft_entry__.build()'
+    nodes = ['tests/test_e2e_gpu.py::' + n for n in (
+        'test_tiny_prune_masks_bit_exact_and_post_prune_forward', 'test_cifar_c1_masks_bit_exact', 'test_ldm_prune_masks_bit_exact',
+        'test_long_sweep_1000_steps_matches_reference', 'test_sibling_criteria_masks_bit_exact', 'test_ddim_sampling_matches_reference')]
+    rc, tail, rep = run_isolated(nodes, tmp_path, extra_env={'DP_HIP_LIB': lib})
+    report['e2e/ieee_sigmoid_build'] = dict(rc=rc, nodes=len(nodes), masks={k: v.get('mask_mismatches') for k, v in rep.items()
+                                                                          if isinstance(v, dict) and 'mask_mismatches' in v})
+    assert rc == 0, tail
+    assert report['e2e/ieee_sigmoid_build']['masks'] and not any(report['e2e/ieee_sigmoid_build']['masks'].values())
