@@ -207,7 +207,12 @@ class SweepWorkload:
         return dict(units=self.env.world * self.B * res['steps'], steps_done=res['steps'], t_total=t_total, t_steps=tm['sweep_s'],
                     extra={'sweep_only_images_per_s': self.env.world * self.B * res['steps'] / tm['sweep_s'],
                            'tail_ms': (t_total - tm['sweep_s']) * 1e3,
+                           # the host's own time per timestep (Python + ctypes + hipLaunchKernel); what it spends WAITING for the
+                           # device -- sweep.MAX_STEPS_AHEAD bounds how far it runs ahead -- is reported beside it.  Before round 6
+                           # the figure included the time the HIP runtime blocks a launch once the queue is full (37-50 ms then).
                            'host_enqueue_ms_per_step': tm['enqueue_s'] / res['steps'] * 1e3,
+                           'host_wait_for_device_ms_per_step': tm.get('throttle_wait_s', 0.0) / res['steps'] * 1e3,
+                           'max_steps_ahead': sweep.MAX_STEPS_AHEAD,
                            'kernel_launches_per_step': launches / res['steps'],
                            'grad_allreduce_ms': tm.get('allreduce_s', 0.0) * 1e3,
                            'wgrad_stream_overlap': bool(self.step.eng._overlap_now), 'hipgraph': bool(self.env.args.graph),

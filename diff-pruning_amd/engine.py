@@ -39,6 +39,24 @@ SIDE_RECORD_STREAM = os.environ.get('DP_SIDE_RECORD_STREAM') == '1'
 SIDE_KEEP_MAX_BYTES = int(float(os.environ.get('DP_SIDE_KEEP_GB', '4')) * (1 << 30))
 
 
+_stream_cache = {}
+
+
+def shared_stream(device, role, slot=0, make=None):
+    """ONE stream per (device, role, slot) for the life of the process.  Every engine used to create its own streams: the caching
+    allocator keeps a separate pool of cached blocks per stream, so each new sweep / engine object left ~11 GB (CIFAR UNet,
+    batch 256) of blocks behind that no later stream could reuse (round 6: reserved memory grew by that much per sweep of a
+    process), and the raw HIP streams of the weight-gradient side were never destroyed.  Objects alive at the same time that
+    share a stream are merely ordered on it; each forks and joins with wait_stream on both sides as before.
+    role: 'wgrad' (lowest priority), 'pipeline' (a second timestep / half-batch pipeline), 'replay' (native replay's side)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role, int(slot))
+    st = _stream_cache.get(key)
+    if st is None:
+        st = _stream_cache[key] = (make or (lambda d: torch.cuda.Stream(device=d)))(device)
+    return st
+
+
 def _low_priority_stream(device):
     """Side stream for the weight-gradient work at the LOWEST HIP priority: the backward chain on the main stream gets
     the CUs first, the side stream fills what is left.  torch only exposes priorities <= 0, so the stream is created
@@ -155,6 +173,7 @@ class UNetEngine:
         self.overlap_wgrad = False if os.environ.get('DP_NO_OVERLAP') else (True if os.environ.get('DP_OVERLAP') else None)
         self._overlap_now = True
         self._side, self._side_dev = None, None
+        self.stream_slot = 0                 # engines that run concurrently (timestep pipelines) use different slots (shared_stream)
         self._side_keep = []                 # tensors the side stream reads, alive until the next join (_side_stream)
         self._side_keep_bytes = 0
         # Dropout (training mode only; utils.set_dropout, ddpm_train.py:380-382): {module name: p} of the nn.Dropout
@@ -385,7 +404,8 @@ class UNetEngine:
             return None
         if self._side is None or self._side_dev != tensors[0].device:        # the model may have moved to another GPU
             self._join_side()
-            self._side, self._side_dev = _low_priority_stream(tensors[0].device), tensors[0].device
+            self._side = shared_stream(tensors[0].device, 'wgrad', self.stream_slot, _low_priority_stream)
+            self._side_dev = tensors[0].device
         if self._side_keep_bytes > SIDE_KEEP_MAX_BYTES:
             self._join_side()                    # bounds what a backward pass keeps alive beyond its own needs; same kernels and chains
         self._side.wait_stream(torch.cuda.current_stream())
@@ -403,7 +423,7 @@ class UNetEngine:
         """Second stream for the native replay of a captured step (ops.ReplayList): the forked chains of the capture alternate
         between the two replay streams, so it has the same priority as the main one."""
         if getattr(self, '_replay_side', None) is None or self._replay_side.device != torch.device(device):
-            self._replay_side = torch.cuda.Stream(device=device)
+            self._replay_side = shared_stream(device, 'replay', self.stream_slot)
         return self._replay_side
 
     def _join_side(self):

@@ -292,7 +292,9 @@ class _Pipe:
             G2[n] = flat2[off:off + g.numel()].view_as(g)
             off += g.numel()
         eng.bind(first_step._P, G2)
-        stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        eng.stream_slot = 1                               # its weight-gradient side stream is not the first engine's
+        from .engine import shared_stream
+        stream = shared_stream(dev, 'pipeline', 1) if dev.type == 'cuda' else None
         return cls(dev, LdmSweepStep(model, schedule, first_step.global_numel, engine=eng, grads=G2), stream, flat2)
 
     @contextlib.contextmanager

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import ops
-from .engine import UNetEngine
+from .engine import UNetEngine, shared_stream
 
 
 GRAPH_AUTO_PIXELS = 8192        # taylor_sweep(use_graph=None): shards up to this many pixels (CIFAR: batch <= 8) ...
@@ -168,12 +168,14 @@ class HipSweepStep:
             G2[n] = flat2[off:off + g.numel()].view_as(g)
             off += g.numel()
         eng2 = UNetEngine(self.eng.cfg)
+        slot = 1 + len(self._tp or [])                    # pipeline k of this step: stream slot k (engine.shared_stream)
+        eng2.stream_slot = slot
         eng2.packs = self.eng.packs                       # frozen weights: one set of packed operands for both halves
         eng2.bind(self._P, G2)
         eng2.set_dropout(self.eng.dropout, self.eng.drop_seed, self.eng.drop_step, self.eng.drop_n_off + self.B // 2)
         self.eng.bind(self._P, self._G)
         self.eng.prepare_packs()                          # packed before the second stream's first read
-        self._half = dict(eng=eng2, G=G2, flat=flat2, stream=torch.cuda.Stream(device=dev), h=self.B // 2, serial=False)
+        self._half = dict(eng=eng2, G=G2, flat=flat2, stream=shared_stream(dev, 'pipeline', slot), h=self.B // 2, serial=False)
 
     def finish(self):
         """Fold the second pipeline's gradients into the parameters' .grad buffers (once per sweep)."""
