@@ -343,8 +343,11 @@ static unsigned dp_lds_pad() {
 // ------------------------------------------------------------------------------------------------
 // conv_gemm
 // ------------------------------------------------------------------------------------------------
+// 64 x 128 tiles: under the 128-VGPR cap of four workgroups per CU the compiler spilled 104-107 registers of this variant to
+// scratch (204-220 bytes per lane, `hipcc -S` metadata, round 6) -- memory the HIP runtime has to find at dispatch; with two
+// workgroups per CU asked for it keeps everything in registers.  The other variants fit (0-2 spills).
 template <int BM, int BN, bool A_KC, bool STRADDLE>
-__global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const dp_conv_gemm_params p) {
+__global__ __launch_bounds__(256, (BM == 64 && BN == 128) ? 2 : 4) void conv_gemm_kernel(const dp_conv_gemm_params p) {
     constexpr int BK = 16;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;

@@ -1,11 +1,11 @@
-# Round-5 evidence (one MI355X via gpurun).  usage: bash tools/run_evidence.sh tests|bench|profiles|pmc
+# Round-6 evidence (one MI355X via gpurun).  usage: bash tools/run_evidence.sh tests|bench|profiles|pmc
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
-R=round5
+R=round6
 stats() {  # name, -- command: rocprofv3 per-kernel summary of one bench.py configuration
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r5_prof_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $O/r6_prof_$name.log 2>&1
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1); cp "$f" $O/${R}_${name}_kernel_stats.csv 2>/dev/null
 }
 pmc() {  # config suffix ('' = cifar256), counters..., -- bench arguments: one --pmc pass per counter, aggregated per kernel
@@ -16,15 +16,20 @@ pmc() {  # config suffix ('' = cifar256), counters..., -- bench arguments: one -
   dirs=()
   for ctr in "${ctrs[@]}"; do
     DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 DP_FINETUNE_REPLAY=0 DP_SAMPLE_REPLAY=0 rocprofv3 --kernel-trace --pmc $ctr --output-format csv \
-      -d /tmp/pmc${sfx}_$ctr -- python bench.py "$@" --no-cpu-baseline --no-roofline > $O/r5_pmc${sfx}_$ctr.log 2>&1
+      -d /tmp/pmc${sfx}_$ctr -- python bench.py "$@" --no-cpu-baseline --no-roofline > $O/r6_pmc${sfx}_$ctr.log 2>&1
     dirs+=(/tmp/pmc${sfx}_$ctr)
   done
   echo "${dirs[@]}"
 }
 case "$1" in
 tests)
-  python -m pytest tests -m gpu -q --durations=25 > $O/${R}_gpu_tests.log 2>&1; tail -20 $O/${R}_gpu_tests.log
-  cp $O/test_report.json $O/${R}_test_report.json ;;
+  # the driver's exact command line, twice (two interpreters on one lease), then smoke() as the driver runs it
+  for i in 1 2; do
+    ( time python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider ) > $O/${R}_gpu_tests_run$i.log 2>&1; echo "rc=$?" >> $O/${R}_gpu_tests_run$i.log
+    grep -E "passed|failed|rc=|CHILD KILLED" $O/${R}_gpu_tests_run$i.log | tail -4
+    cp $O/test_report.json $O/${R}_test_report.json; cp $O/last_test.txt $O/${R}_last_test_run$i.txt
+  done
+  python3 -c "import __graft_entry__ as g; g.smoke()" > $O/${R}_smoke.log 2>&1; echo "rc=$?" >> $O/${R}_smoke.log; tail -3 $O/${R}_smoke.log ;;
 bench)
   python bench.py --steps 20 --warmup 5 > $O/${R}_bench_line.json 2> $O/${R}_bench_line.err; tail -c 600 $O/${R}_bench_line.json
   for c in bedroom256 c4_finetune ddim ldm; do
