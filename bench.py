@@ -447,6 +447,7 @@ def kernel_switches(ops):
     return {'wino': bool(ops.WINO), 'wgrad_wino': bool(ops.WINO and ops.WGRAD_WINO), 'wino_min_tiles': ops.WINO_MIN_TILES,
             'splitk_fold': bool(ops.SPLITK_FOLD), 'splitk_fold_max': ops.SPLITK_FOLD_MAX,
             'wino43_no_grad_forwards': getattr(ops, 'WINO43', False),
+            'wino2d': bool(ops.WINO and getattr(ops, 'WINO2D', False)), 'wino2d_min_tiles': getattr(ops, 'WINO2D_MIN_TILES', None),
             'fused_attn': ops.FUSED_ATTN, 'ups_subpixel': bool(eng.UPS_SUBPIXEL), 's2_parity': bool(eng.S2_PARITY),
             'timestep_pipelines_default': sweep.TIMESTEP_PIPELINES,
             'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('DP_')}}
@@ -456,7 +457,7 @@ def _pmc_traffic(config_name, dom):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
     THIS config's bench command, aggregated by tools/pmc_aggregate.py; KB -> bytes; they cannot run inside this process).  Read from
     the newest profiles/round*_pmc_bench_traffic[_<config>].json whose `_config` equals the config being timed and whose recorded
-    hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip) equals today's; anything else = null.
+    hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip) equals today's; anything else = null.
     FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on gfx950 (MI355X_MICROARCH.md, HBM section)."""
     import glob
     import hashlib
@@ -465,7 +466,7 @@ def _pmc_traffic(config_name, dom):
         cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))
         if not cand:
             return None, dict(file=None, reason='no PMC pass of config %r under profiles/' % config_name)
-        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip'))
+        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip'))
         blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()          # the contraction kernels' sources, concatenated
         pm = json.load(open(cand[-1]))
         measured_on, measured_cfg = pm.get('_gemm_hip_blob'), pm.get('_config', 'cifar256')
@@ -501,7 +502,8 @@ def roofline(ops, one_step, step_seconds, flop_reference_per_step, config_name='
     # The Winograd F(2, 3) kernels execute 2/3 of the multiply-adds of the convolution they compute (6 instead of 9 per output,
     # channel pair and pixel): `achieved` / `frac` are EXECUTED FLOPs over time (the number to hold against the matrix pipe);
     # the same launches in the direct form's arithmetic -- the reference's -- are 1.5x that.
-    ref_eq = 1.5 if 'wino' in dom else 1.0
+    # The F(2x2, 3x3) kernel (round 6) executes 4/9: 16 multiplies per 2x2 output tile and channel pair instead of 36 -> x 2.25.
+    ref_eq = 2.25 if 'wino2d' in dom else 1.5 if 'wino' in dom else 1.0
     return dict(bound='mfma', kernel=dom, achieved=fl / sec / 1e12, peak=PEAK_F32_TFLOPS, unit='TFLOP/s',
                 frac=fl / sec / 1e12 / PEAK_F32_TFLOPS, achieved_in_reference_arithmetic=ref_eq * fl / sec / 1e12,
                 traffic=traffic, traffic_source=traffic_src,

@@ -90,6 +90,9 @@ SIGNATURES = {
     'dp_conv_wino_supported': [C.POINTER(ConvGemmParams)],
     'dp_conv_splitk_epilogue': [C.POINTER(ConvGemmParams), _vp],
     'dp_pack_weight_wino': [_vp, _i, _i, _i, _vp, _i, _vp],
+    'dp_conv_wino2d': [C.POINTER(ConvGemmParams), _vp],
+    'dp_conv_wino2d_supported': [C.POINTER(ConvGemmParams)],
+    'dp_pack_weight_wino2d': [_vp, _i, _i, _i, _vp, _i, _vp],
     'dp_conv_wino43': [C.POINTER(ConvGemmParams), _vp],
     'dp_conv_wino43_supported': [C.POINTER(ConvGemmParams)],
     'dp_pack_weight_wino43': [_vp, _i, _i, _vp, _i, _vp],

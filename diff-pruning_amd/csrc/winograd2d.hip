@@ -1,0 +1,366 @@
+// 3x3 stride-1 'same' convolution as a TWO-DIMENSIONAL Winograd F(2x2, 3x3) implicit GEMM on the fp32 matrix cores (round 6).
+//
+// csrc/winograd.hip runs F(2, 3) along W only (12 multiplies per output pair and channel instead of 18: 2/3 of the direct form) and
+// says why the 2-D form did not fit: 16 position accumulators per output tile.  They do fit when the POSITIONS are spread over the
+// wavefronts instead of the rows: F(2x2, 3x3) does 16 multiplies per 2x2 output tile and channel instead of 36 -- 4/9 of the direct
+// form, 2/3 of F(2, 3) --
+//     U = G g G^T (4x4 per (m, c), packed once: dp_pack_weight_wino2d),  V = B^T d B (4x4 per (c, tile), d = the 4x4 input patch),
+//     M[i][j] += U[i][j] V[i][j] over c,   Y = A^T M A (2x2 outputs),
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
+// One 256-thread workgroup = 64 output channels x 32 tiles (128 output pixels: 128 / W whole image rows) x 16 positions.
+// Wavefront i owns ROW i of the position matrix -- positions (i, 0..3) -- for all 64 rows x 32 tiles: 4 positions x 2 row blocks x
+// 16 = 128 accumulator registers, two workgroups per CU.  Why this mapping:
+//   * row i of V needs only TWO of the four patch rows (B^T row i has two non-zeros): a lane reads 2 x 4 raw pixels of its (channel,
+//     tile) from LDS and forms its four B operands with 8 VALU adds and two border selects per 8 MFMAs -- the same VALU / LDS-read
+//     count per MFMA as the one-dimensional kernel;
+//   * the raw input tile in LDS is [channel][tile row][4 patch rows][W]: vertical zero padding and image boundaries are out-of-range
+//     byte offsets of the LDS-DMA loads (the hardware writes zeros), horizontal padding two per-lane selects;
+//   * one K tile (8 channels) carries all 16 positions: there is no kernel-row loop, 32 MFMAs per wavefront between barriers;
+//   * the output transform is 2 x 2 signed sums inside the wavefront (columns) and one exchange through LDS between the four
+//     wavefronts (rows): 64 KB written and read once per workgroup, against ~1.3 MB read during its K loop.
+// Same parameter block, epilogue operands and split-K contract as dp_conv_wino.  fp32 everywhere; the result differs from the direct
+// form by re-association (~1e-6 of the output scale).
+#include <cstdlib>
+#include "dp_common.h"
+
+#define DPW2_RSRC_FLAGS 0x00020000
+#define DPW2_OOB 0x80000000u
+typedef __attribute__((address_space(3))) void dpw2_lds_void;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dpw2_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DPW2_RSRC_FLAGS);
+}
+
+namespace {
+constexpr int W2_BM = 64;                      // output channels per workgroup
+constexpr int W2_BT = 32;                      // 2x2 tiles per workgroup (128 output pixels)
+constexpr int W2_BK = 8;                       // channels per K tile
+constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB)
+constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][tile row][4 patch rows][W] floats, tile rows x W = 64 (8 KB)
+constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];       // 80 KB: two workgroups per CU
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // = row i of the position matrix
+    // row tiles of one pixel block back to back on one XCD (they read the same input block): see conv_wino_kernel
+    int bxx = blockIdx.x, byy = blockIdx.y;
+    if (!(gridDim.x & 7)) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, slot = b >> 3;
+        const int gy = gridDim.y;
+        const int grp = slot / gy;
+        byy = slot - grp * gy;
+        bxx = grp * 8 + xcd;
+    }
+    const int m0 = byy * W2_BM;
+    const dp_conv_geom& g = p.g;
+    const int W = g.Wo, H = g.Ho, HW = H * W;
+    const int lw = 31 - __clz(W);                      // W is a power of two
+    const int TC = W >> 1;                             // tiles per image row
+    const int C = p.C;
+    const int C1 = p.X2 ? g.c_split : C;
+    const int nIterAll = C / W2_BK;
+    const bool ksplit = p.ksplit > 1;
+    const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
+    const int it0 = ksplit ? (int)blockIdx.z * per : 0;
+    const int nIter = ksplit ? max(0, min(per, nIterAll - it0)) : nIterAll;
+    const int row0 = (bxx * 128) >> lw;                // first global image row (over all images) of this block; even
+    const int rows_all = p.NPIX >> lw;                 // N * H
+
+    // ---- A loader: 16-byte chunk e = tid + 256 j of [pos 16][k 8][m 64]
+    unsigned a_voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j;
+        const int pos = e >> 7, k = (e >> 4) & 7, m = m0 + 4 * (e & 15);
+        a_voff[j] = (m < p.lda) ? (unsigned)(((pos * C + k) * p.lda + m) * 4) : DPW2_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rA = dpw2_rsrc(p.A, p.a_bytes);
+    // ---- B loader: 16-byte chunk e = tid + 256 j of [k 8][tile row][patch row 4][W / 4]: 64 chunks per channel
+    unsigned b_voff1[2], b_voff2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + 256 * j;
+        const int k = e >> 6, within = e & 63;
+        const int tr = within >> lw;                   // W chunks per tile row (4 patch rows x W / 4)
+        const int rem = within & (W - 1);
+        const int r = rem >> (lw - 2), cx = rem & ((W >> 2) - 1);
+        const int rg = row0 + 2 * tr;                  // global row of the tile row's first output row
+        const int img = rg / H, y = rg - img * H + r - 1;
+        const bool v = rg < rows_all && (unsigned)y < (unsigned)H;
+        const unsigned lin = (unsigned)(k * HW + y * W + 4 * cx);
+        b_voff1[j] = v ? ((unsigned)((long long)img * g.x1_img_stride) + lin) * 4u : DPW2_OOB;
+        b_voff2[j] = v ? ((unsigned)((long long)img * g.x2_img_stride) + lin) * 4u : DPW2_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t r1 = dpw2_rsrc(p.X1, p.x1_bytes);
+    const __amdgpu_buffer_rsrc_t r2 = dpw2_rsrc(p.X2 ? p.X2 : p.X1, p.X2 ? p.x2_bytes : p.x1_bytes);
+
+    float* const ldsA = smem + 4 * (wave * 64);                       // + buf*STAGE + 1024*j   (chunk e -> float 4 e)
+    float* const ldsB = smem + W2_A_SZ + 4 * (wave * 64);             // + buf*STAGE + 1024*j
+
+    auto dma_tile = [&](int buf, int ch) {
+        const unsigned a_soff = (unsigned)(ch * W2_BK) * (unsigned)p.lda * 4u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned o = a_voff[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw2_lds_void*)(ldsA + buf * W2_STAGE + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
+        }
+        const int c0 = ch * W2_BK;
+        const bool first = c0 < C1;
+        const unsigned b_soff = (unsigned)((first ? c0 : c0 - C1) * HW * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = first ? b_voff1[j] : b_voff2[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(ldsB + buf * W2_STAGE + 1024 * j), 16, (int)o,
+                                                     (int)b_soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+    // ---- fragment addressing: lane = (k parity, li); A row 32 t + li of position (wave, j); B tile li
+    const int li = lane & 31, lk = lane >> 5;
+    const float* fragA = smem + ((wave * 4) * W2_BK + lk) * W2_BM + li;           // + (j*BK + 2 ks)*BM + 32 t
+    const int tr_l = li / TC, tc_l = li - tr_l * TC;
+    // the two patch rows of B^T row `wave`: (0, 2) -, (1, 2) +, (2, 1) -, (1, 3) -
+    const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1;
+    const int rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const float* fragB1 = smem + W2_A_SZ + lk * 256 + ((tr_l * 4 + ra) << lw) + 2 * tc_l;     // + 2 ks * 256; cols -1 .. 2
+    const float* fragB2 = smem + W2_A_SZ + lk * 256 + ((tr_l * 4 + rb) << lw) + 2 * tc_l;
+    const bool pad_l = tc_l == 0, pad_r = tc_l == TC - 1;
+
+    int ch = it0;
+    if (nIter > 0) {
+        dma_tile(0, ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int it = 0; it < nIter; ++it) {
+        const int buf = it & 1;
+        const int ch_next = (it + 1 < nIter) ? ch + 1 : ch;
+        const float* Af = fragA + buf * W2_STAGE;
+        const float* B1 = fragB1 + buf * W2_STAGE;
+        const float* B2 = fragB2 + buf * W2_STAGE;
+        float a[2][8], d[2][8], v[2][4];
+        auto frag = [&](int ks, float (&fa)[8], float (&fd)[8]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[2 * j + t] = Af[(j * W2_BK + 2 * ks) * W2_BM + 32 * t];
+            // plain float reads (see conv_wino_kernel: a float2-typed LDS access drains vmcnt(0) behind the prefetch)
+            fd[1] = B1[2 * ks * 256];
+            fd[2] = B1[2 * ks * 256 + 1];
+            fd[0] = B1[2 * ks * 256 - 1];
+            fd[3] = B1[2 * ks * 256 + 2];
+            fd[5] = B2[2 * ks * 256];
+            fd[6] = B2[2 * ks * 256 + 1];
+            fd[4] = B2[2 * ks * 256 - 1];
+            fd[7] = B2[2 * ks * 256 + 2];
+        };
+        auto xform = [&](const float (&fd)[8], float (&fv)[4]) {
+            float c0 = fmaf(sgn, fd[4], fd[0]), c1 = fmaf(sgn, fd[5], fd[1]), c2 = fmaf(sgn, fd[6], fd[2]), c3 = fmaf(sgn, fd[7], fd[3]);
+            c0 = pad_l ? 0.f : c0;
+            c3 = pad_r ? 0.f : c3;
+            fv[0] = c0 - c2; fv[1] = c1 + c2; fv[2] = c2 - c1; fv[3] = c1 - c3;
+        };
+        frag(0, a[0], d[0]);
+        xform(d[0], v[0]);
+#pragma unroll
+        for (int ks = 0; ks < W2_BK / 2; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < W2_BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2 * j + t], v[cur][j], acc[j][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < W2_BK / 2) { xform(d[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
+            // unconditional (the last K tile fetches itself once more into the idle buffer): a branch here moves the loads out of
+            // the loop body and in front of a compiler-placed wait
+            if (ks == 0) { dma_tile(buf ^ 1, ch_next); __builtin_amdgcn_sched_barrier(0); }
+        }
+        ch = ch_next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- output transform.  Columns inside the wavefront: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3];
+    //      rows across the wavefronts through LDS: Y[0][q] = Z[0][q] + Z[1][q] + Z[2][q], Y[1][q] = Z[1][q] - Z[2][q] - Z[3][q].
+    //      zbuf[((i*2 + q)*2 + t)*16 + r][lane]: 64 KB of the K loop's buffers (every wavefront is past the last barrier).
+    float* zbuf = smem;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            zbuf[(((wave * 2 + 0) * 2 + t) * 16 + r) * 64 + lane] = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
+            zbuf[(((wave * 2 + 1) * 2 + t) * 16 + r) * 64 + lane] = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
+        }
+    __syncthreads();
+    // wavefront w finishes row block t = w >> 1, registers r = 8 (w & 1) .. + 7: element (m, tile li) of every lane
+    const int t_o = wave >> 1, r_o = 8 * (wave & 1);
+    const int rg = row0 + 2 * tr_l;                    // global row of this lane's tile
+    if (rg >= rows_all) return;
+    const int img = rg / H, y = rg - img * H;
+    const int r_in = y * W + 2 * tc_l;
+    if (ksplit) {
+        float* wsb = p.ws + (long long)blockIdx.z * p.M * p.NPIX + (long long)img * HW + r_in;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+            const int r = r_o + q8;
+            const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
+            float z[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * 2 + t_o) * 16 + r) * 64 + lane];
+            if (m >= p.M) continue;
+            float* o = wsb + (long long)m * p.NPIX;
+            *reinterpret_cast<float2*>(o) = make_float2((z[0][0] + z[1][0]) + z[2][0], (z[0][1] + z[1][1]) + z[2][1]);
+            *reinterpret_cast<float2*>(o + W) = make_float2((z[1][0] - z[2][0]) - z[3][0], (z[1][1] - z[2][1]) - z[3][1]);
+        }
+        return;
+    }
+    float* optr = p.out + (long long)img * p.o_img_stride + r_in;
+    const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
+    const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
+    // all eight rows' operand loads in flight before the first use (clamped row index; rows >= M skip the store)
+    int mc[8];
+    float tb[8], tt[8];
+    float2 tr0[8], tr1[8], tp0[8], tp1[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+        const int r = r_o + q8;
+        const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
+        mc[q8] = m < p.M ? m : p.M - 1;
+        tb[q8] = tt[q8] = 0.f;
+        tr0[q8] = tr1[q8] = tp0[q8] = tp1[q8] = make_float2(0.f, 0.f);
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) tb[q8] = p.bias[mc[q8]];
+    }
+    if (tptr) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) tt[q8] = tptr[mc[q8]];
+    }
+    if (rptr) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+            tr0[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW);
+            tr1[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW + W);
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+            tp0[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW);
+            tp1[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW + W);
+        }
+    }
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+        const int r = r_o + q8;
+        const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
+        float z[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * 2 + t_o) * 16 + r) * 64 + lane];
+        float y00 = p.alpha * ((z[0][0] + z[1][0]) + z[2][0]), y01 = p.alpha * ((z[0][1] + z[1][1]) + z[2][1]);
+        float y10 = p.alpha * ((z[1][0] - z[2][0]) - z[3][0]), y11 = p.alpha * ((z[1][1] - z[2][1]) - z[3][1]);
+        if (p.bias) { y00 += tb[q8]; y01 += tb[q8]; y10 += tb[q8]; y11 += tb[q8]; }
+        if (tptr) { y00 += tt[q8]; y01 += tt[q8]; y10 += tt[q8]; y11 += tt[q8]; }
+        if (rptr) { y00 += tr0[q8].x; y01 += tr0[q8].y; y10 += tr1[q8].x; y11 += tr1[q8].y; }
+        y00 *= p.post_scale; y01 *= p.post_scale; y10 *= p.post_scale; y11 *= p.post_scale;
+        if (p.act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+        if (p.accumulate) { y00 += tp0[q8].x; y01 += tp0[q8].y; y10 += tp1[q8].x; y11 += tp1[q8].y; }
+        if (m < p.M) {
+            *reinterpret_cast<float2*>(optr + (long long)m * HW) = make_float2(y00, y01);
+            *reinterpret_cast<float2*>(optr + (long long)m * HW + W) = make_float2(y10, y11);
+        }
+    }
+}
+
+// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 64 (128 output pixels = whole image rows,
+// whole tile rows), H even, channel counts (per concat source) in multiples of 8, 8-byte aligned image planes.
+static bool wino2d_ok(const dp_conv_gemm_params& p) {
+    const dp_conv_geom& g = p.g;
+    if (p.a_kc || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups || g.pad_t != 1 || g.pad_l != 1) return false;
+    if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || (p.ksplit > 1 && !p.ws)) return false;
+    const int W = g.Wo, H = g.Ho;
+    if (W < 4 || W > 64 || (W & (W - 1)) || (H & 1)) return false;
+    if ((p.lda & 3) || p.NPIX % (H * W)) return false;
+    if ((g.x1_img_stride & 1) || (p.X2 && (g.x2_img_stride & 1)) || (p.o_img_stride & 1) || (p.res && (p.r_img_stride & 1))) return false;
+    if ((unsigned long long)p.x1_bytes >= 0x80000000ull || (p.X2 && (unsigned long long)p.x2_bytes >= 0x80000000ull)) return false;
+    const int C1 = p.X2 ? g.c_split : p.C;
+    return p.C % 8 == 0 && C1 % 8 == 0 && p.C >= 8;
+}
+
+extern "C" int dp_conv_wino2d_supported(const dp_conv_gemm_params* p) { return wino2d_ok(*p) ? 1 : 0; }
+extern "C" int dp_conv_splitk_epilogue(const dp_conv_gemm_params* p, void* stream);      // gemm.hip
+
+extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
+    const dp_conv_gemm_params& p = *pp;
+    if (p.M <= 0 || p.NPIX <= 0) return 0;
+    if (!wino2d_ok(p)) return (int)hipErrorInvalidValue;
+    dim3 grid((p.NPIX + 127) / 128, (p.M + W2_BM - 1) / W2_BM, p.ksplit > 1 ? p.ksplit : 1);
+    DP_LAUNCH(conv_wino2d_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const int e = DP_LAUNCH_CHECK();
+    if (e || p.ksplit <= 1) return e;
+    return dp_conv_splitk_epilogue(pp, stream);
+}
+
+// U[(pos*K + k)][ld], pos = 4 i + j, U = G g G^T, from a torch [Co][Ci][3][3] weight.  mode 0 (forward): K = Ci, columns m = co, taps
+// as stored; mode 1 (input gradient): K = Co, columns m = ci, both tap axes flipped.
+__global__ __launch_bounds__(256) void pack_weight_wino2d_kernel(const float* __restrict__ Wt, int Co, int Ci, int mode,
+                                                                 float* __restrict__ dst, int ld) {
+    const int K = mode == 0 ? Ci : Co, Mv = mode == 0 ? Co : Ci;
+    const long long total = 16ll * K * ld;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx % ld);
+        const long long rk = idx / ld;
+        const int k = (int)(rk % K);
+        const int pos = (int)(rk / K);
+        const int i = pos >> 2, j = pos & 3;
+        float v = 0.f;
+        if (m < Mv) {
+            const float* w = mode == 0 ? Wt + ((long long)m * Ci + k) * 9 : Wt + ((long long)k * Ci + m) * 9;
+            float gg[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) gg[a][b] = mode == 0 ? w[a * 3 + b] : w[(2 - a) * 3 + (2 - b)];
+            // t[b] = (G g)[i][b], then v = sum_b t[b] G[j][b]
+            float t[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                t[b] = i == 0 ? gg[0][b] : i == 1 ? ((gg[0][b] + gg[1][b]) + gg[2][b]) * 0.5f : i == 2 ? ((gg[0][b] - gg[1][b]) + gg[2][b]) * 0.5f : gg[2][b];
+            v = j == 0 ? t[0] : j == 1 ? ((t[0] + t[1]) + t[2]) * 0.5f : j == 2 ? ((t[0] - t[1]) + t[2]) * 0.5f : t[2];
+        }
+        dst[idx] = v;
+    }
+}
+
+extern "C" int dp_pack_weight_wino2d(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream) {
+    const long long total = 16ll * (mode == 0 ? Ci : Co) * ld;
+    if (total <= 0) return 0;
+    long long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    DP_LAUNCH(pack_weight_wino2d_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, mode, dst, ld);
+    return DP_LAUNCH_CHECK();
+}

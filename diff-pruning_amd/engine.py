@@ -100,6 +100,8 @@ class _Packs:
             buf, ld = ops.pack_weight_wino43(w)
         elif isinstance(mode, tuple) and mode[0] == 'wino':    # ('wino', 0 | 1): Winograd F(2, 3) operand (ops.pack_weight_wino)
             buf, ld = ops.pack_weight_wino(w, mode[1])
+        elif isinstance(mode, tuple) and mode[0] == 'wino2d':  # ('wino2d', 0 | 1): Winograd F(2x2, 3x3) operand (ops.pack_weight_wino2d)
+            buf, ld = ops.pack_weight_wino2d(w, mode[1])
         elif isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
             weff = self.get_weff(name, w)
             buf, ld = ops.pack_weight(weff[mode[1]], mode[2])
@@ -340,11 +342,14 @@ class UNetEngine:
             del seen[k]
         for name, w in self.P.items():
             if name.endswith('.weight') and w.dim() >= 2:
-                for mode in (0, 1, ('wino', 0), ('wino', 1)):
+                for mode in (0, 1, ('wino', 0), ('wino', 1), ('wino2d', 0), ('wino2d', 1)):
                     if isinstance(mode, tuple) and (name[:-7], mode) not in seen:
                         continue
                     if not self.packs.has(name[:-7], w, mode):
-                        todo.append((name[:-7], w, mode))
+                        if isinstance(mode, tuple) and mode[0] == 'wino2d' and not getattr(ops, 'PACK_BATCH_WINO2D', False):
+                            self.packs.get(name[:-7], w, mode)                     # one launch each (not part of the batched packer)
+                        else:
+                            todo.append((name[:-7], w, mode))
         if hasattr(ops, 'pack_weight_batch') and todo and all(w.is_contiguous() for _, w, _ in todo):
             for (name, w, mode), (buf, ld) in zip(todo, ops.pack_weight_batch([(w, mode) for _, w, mode in todo])):
                 self.packs.put(name, w, mode, buf, ld)
@@ -357,11 +362,23 @@ class UNetEngine:
         return float(hd if hd is not None else channels) ** -0.5
 
     # ---- primitive layers ---------------------------------------------------------------------
-    def _wino_pack(self, name, w, mode):
+    def _wino_pack(self, name, w, mode, kind='wino'):
         if not hasattr(self, '_wino_seen'):
             self._wino_seen = {}
-        self._wino_seen[(name, ('wino', mode))] = getattr(self, '_wino_gen', 0)     # prepare_packs() batches it from the next pass on
-        return self.packs.get(name, w, ('wino', mode))
+        self._wino_seen[(name, (kind, mode))] = getattr(self, '_wino_gen', 0)     # prepare_packs() batches it from the next pass on
+        return self.packs.get(name, w, (kind, mode))
+
+    def _wino_operand(self, name, w, mode, M, C_sources, N, H, W, spec):
+        """The Winograd operand of a 3x3 / stride 1 / pad 1 layer for ops.conv_forward / conv_dgrad (`wino=`), or None: the
+        two-dimensional F(2x2, 3x3) form (csrc/winograd2d.hip: 4/9 of the direct multiplies) where the shape and the grid suit it,
+        else the one-dimensional F(2, 3) form (csrc/winograd.hip: 2/3), else the direct kernel."""
+        if not hasattr(ops, 'wino_wanted'):
+            return None
+        if hasattr(ops, 'wino2d_wanted') and ops.wino2d_wanted(M, C_sources, N, H, W, spec):
+            return ('2d',) + tuple(self._wino_pack(name, w, mode, 'wino2d'))
+        if ops.wino_wanted(M, C_sources, N, H, W, spec):
+            return self._wino_pack(name, w, mode)
+        return None
 
     def _conv(self, name, x, x2, spec, **kw):
         w = self.P[name + '.weight']
@@ -369,8 +386,9 @@ class UNetEngine:
         # 3x3 / stride 1 / pad 1 layers with a grid worth it: Winograd F(2, 3) along W, 2/3 of the multiplies (csrc/winograd.hip)
         if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted'):
             cs = (x.shape[1],) + ((x2.shape[1],) if x2 is not None else ())
-            if ops.wino_wanted(w.shape[0], cs, x.shape[0], x.shape[2], x.shape[3], spec):
-                kw['wino'] = self._wino_pack(name, w, 0)
+            wo = self._wino_operand(name, w, 0, w.shape[0], cs, x.shape[0], x.shape[2], x.shape[3], spec)
+            if wo is not None:
+                kw['wino'] = wo
             # a forward that keeps nothing for a backward (sampling loops, the LDM importance pass's CFG sampler): F(4, 3), half the
             # multiplies at ~1e-6 instead of ~3e-7 fp32 error -- never for a scored forward (csrc/winograd43.hip)
             if self._nograd and hasattr(ops, 'wino43_wanted') and ops.wino43_wanted(w.shape[0], cs, x.shape[0], x.shape[2], x.shape[3], spec):
@@ -464,9 +482,8 @@ class UNetEngine:
             return ops.conv_dgrad_s2(dy, packs, w.shape[1], spec, in_hw, add=dx_add)
         wd, ldd = self.packs.get(name, w, 1)
         wino = None
-        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and tuple(in_hw) == tuple(dy.shape[2:]) and \
-                ops.wino_wanted(w.shape[1], (w.shape[0],), dy.shape[0], dy.shape[2], dy.shape[3], spec):
-            wino = self._wino_pack(name, w, 1)
+        if w.dim() == 4 and w.shape[2] == 3 and hasattr(ops, 'wino_wanted') and tuple(in_hw) == tuple(dy.shape[2:]):
+            wino = self._wino_operand(name, w, 1, w.shape[1], (w.shape[0],), dy.shape[0], dy.shape[2], dy.shape[3], spec)
         dx = ops.conv_dgrad(dy, wd, ldd, w.shape[1], spec, in_hw, alpha=alpha, out=dx_out, accumulate=dx_accumulate,
                             **({'wino': wino} if wino is not None else {}))
         if dx_add is not None:

@@ -368,6 +368,80 @@ def pack_weight_wino(w, mode):
     return dst, ld
 
 
+# ---- two-dimensional Winograd F(2x2, 3x3) (csrc/winograd2d.hip, round 6): 4/9 of the direct multiplies, 2/3 of F(2, 3) ----------
+WINO2D = os.environ.get('DP_WINO2D', '1') not in ('0', '')
+WINO2D_MIN_TILES = int(os.environ.get('DP_WINO2D_MIN_TILES', '512'))   # 64-row x 128-pixel tiles; smaller grids split K or stay 1-D
+
+
+def wino2d_shape_ok(M, C_sources, N, H, W):
+    """Host-side mirror of wino2d_ok (csrc/winograd2d.hip)."""
+    return (WINO2D and 4 <= W <= 64 and not (W & (W - 1)) and not (H & 1) and not any(c % 8 for c in C_sources)
+            and sum(C_sources) >= 8 and M >= 16)
+
+
+WINO2D_MIN_FILL = float(os.environ.get('DP_WINO2D_MIN_FILL', '0.85'))    # M / (64-row tiles x 64): 96 rows fill 75 % -> F(2, 3)'s 32-row tiles
+
+
+def wino2d_wanted(M, C_sources, N, H, W, spec):
+    """Shape rule (wino2d_ok in csrc/winograd2d.hip) + grid rule (_conv_wino2d) + row-tile fill: True when a 3x3 / stride 1 / pad 1
+    convolution should go to dp_conv_wino2d.  [measured, round 6, profiles/round6_wino2d_gate.txt, batch 256, against F(2, 3):
+    128 -> 128 @ 32 x 32 1.43x forward / 1.31x input gradient, 256 -> 256 @ 16 x 16 1.33x / 1.29x, @ 8 x 8 1.21x, @ 4 x 4 1.13x,
+    192 -> 192 @ 16 x 16 1.27x, 384 -> 384 @ 32 x 32 (12 latents) 1.24x; 96 -> 96 @ 32 x 32 0.97x: 64-row tiles fill 75 %.]"""
+    if not WINO or getattr(spec, 'keep', False) or getattr(spec, 'sym', False):
+        return False
+    if not (spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad_h == 1 and spec.pad_w == 1 and not spec.ups):
+        return False
+    if not wino2d_shape_ok(M, C_sources, N, H, W):
+        return False
+    if M / (-(-M // 64) * 64.0) < WINO2D_MIN_FILL:
+        return False
+    tiles = -(-M // 64) * -(-(N * H * W) // 128)
+    if tiles >= WINO2D_MIN_TILES:
+        return True
+    n_iter = sum(C_sources) // 8
+    ks = min(WINO2D_MIN_TILES // max(tiles, 1), n_iter // 8)
+    return ks >= 2 and tiles * ks >= WINO2D_MIN_TILES // 2
+
+
+def pack_weight_wino2d(w, mode):
+    """U[(pos*K + k)][ld], pos = 4 i + j of G g G^T, for dp_conv_wino2d from a [Co, Ci, 3, 3] weight: mode 0 forward (K = Ci),
+    mode 1 input gradient (K = Co, both tap axes flipped)."""
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.is_cuda and w.dtype == _f32 and w.is_contiguous()
+    Co, Ci = w.shape[0], w.shape[1]
+    K = Ci if mode == 0 else Co
+    ld = roundup4(Co if mode == 0 else Ci)
+    dst = torch.empty(16 * K * ld, dtype=_f32, device=w.device)
+    L.check(_lib().dp_pack_weight_wino2d(_p(w), Co, Ci, mode, _p(dst), ld, _stream()), 'dp_pack_weight_wino2d')
+    return dst, ld
+
+
+def _conv_wino2d(p, wino2d, act_bytes):
+    """Run the filled parameter block through dp_conv_wino2d when the kernel takes the shape and the grid is big enough (split-K for
+    small grids, like _conv_wino); False = the caller goes on to F(2, 3) / the direct form."""
+    if not WINO2D:
+        return False
+    U, ld = wino2d
+    tiles = -(-p.M // 64) * -(-p.NPIX // 128)
+    ks = 1
+    if tiles < WINO2D_MIN_TILES:
+        n_iter = p.C // 8
+        ks = min(WINO2D_MIN_TILES // max(tiles, 1), n_iter // 8)
+        if ks < 2 or tiles * ks < WINO2D_MIN_TILES // 2:
+            return False
+    A0, lda0, ab0 = p.A, p.lda, p.a_bytes
+    p.A, p.lda, p.a_bytes = _p(U), ld, U.numel() * 4
+    if ks > 1:
+        ws_t = _workspace(ks * p.M * p.NPIX, U.device)
+        p._keep = (ws_t,)
+        p.ksplit, p.ws, p.tile_counters = ks, _p(ws_t), None
+    if not _lib().dp_conv_wino2d_supported(C.byref(p)):
+        p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
+        return False
+    L.check(_run(lambda: _lib().dp_conv_wino2d(C.byref(p), _stream()), 'conv_wino2d_kernel', 2.0 * p.M * p.NPIX * p.C * 4,
+                 act_bytes + 4.0 * U.numel()), 'dp_conv_wino2d')
+    return True
+
+
 # ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------
 # DEFAULT OFF -- the go / no-go gate of the round-4 verdict (item 5) came out NO-GO [measured, profiles/round5_winograd_gate.txt]:
 # against F(2, 3), forward, batch 256: 128 -> 128 @ 32 x 32 1.23x, 192 -> 192 @ 16 x 16 1.20x, 128 + 128 -> 128 @ 32 x 32 1.20x, but
@@ -443,6 +517,8 @@ def _conv_wino(p, wino, act_bytes):
     the caller launches the direct form."""
     if not WINO:
         return False
+    if wino[0] == '2d':                                # ('2d', U, ld): the F(2x2, 3x3) operand (engine: wino2d_wanted said yes)
+        return _conv_wino2d(p, wino[1:], act_bytes)
     U, ld = wino
     tiles = -(-p.M // 64) * -(-p.NPIX // 128)
     ks = 1

@@ -78,6 +78,18 @@ int dp_conv_splitk_epilogue(const dp_conv_gemm_params* p, void* stream);
  * dst holds 12 * K * ld floats. */
 int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);
 
+/* The same convolution as a TWO-DIMENSIONAL Winograd F(2x2, 3x3) implicit GEMM (csrc/winograd2d.hip, round 6): 16 multiplies per
+ * 2x2 output tile and channel instead of 36 -- 4/9 of dp_conv_gemm, 2/3 of dp_conv_wino.  One workgroup = 64 output channels x 32
+ * tiles (128 output pixels = whole image rows) x 16 positions, the four ROWS of the position matrix on the four wavefronts; input
+ * transform at fragment-read time, output transform in registers (columns) and through LDS (rows).  Replaces the same call sites as
+ * dp_conv_wino (diffusers/models/resnet.py:606,630 and their input gradients; ldm/modules/diffusionmodules/openaimodel.py:214-232).
+ * Same parameter block, epilogue operands and split-K contract; A is dp_pack_weight_wino2d's operand U[(pos*K + k)][lda],
+ * pos = 4 i + j of U = G g G^T (dst holds 16 * K * ld floats; mode 0 forward, mode 1 input gradient with both tap axes flipped).
+ * Takes W a power of two in 4..64, H even, channel counts per concat source in multiples of 8, even image strides. */
+int dp_conv_wino2d(const dp_conv_gemm_params* p, void* stream);
+int dp_conv_wino2d_supported(const dp_conv_gemm_params* p);
+int dp_pack_weight_wino2d(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);
+
 /* The same convolution as Winograd F(4, 3) along W (csrc/winograd43.hip): HALF the multiplies of dp_conv_gemm (6 per 4 outputs x 3
  * taps), for the forwards that keep nothing for a backward -- the sampling loops (diffusers/pipelines/ddim/pipeline_ddim.py:101-116,
  * pipelines/ddpm/pipeline_ddpm.py:87-96) and the CFG sampler of the LDM importance pass (ldm_exp/prune_ldm.py:111-118,

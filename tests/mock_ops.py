@@ -72,10 +72,23 @@ def pack_weight_wino(w, mode):
     return _WinoOperand(w, mode), 0
 
 
+def wino2d_wanted(M, C_sources, N, H, W, spec):
+    import importlib
+    return importlib.import_module('diff-pruning_amd.ops').wino2d_wanted(M, C_sources, N, H, W, spec)
+
+
+def pack_weight_wino2d(w, mode):
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    return _WinoOperand(w, ('2d', mode)), 0
+
+
 def _check_wino(wino, w, mode):
     if wino is None:
         return
-    op = wino[0]
+    if wino[0] == '2d':                                  # ('2d', operand, ld): the F(2x2, 3x3) operand
+        op, mode = wino[1], ('2d', mode)
+    else:
+        op = wino[0]
     # the operand must have been packed from the CURRENT weight (a stale one after an optimizer step or a prune is the bug to catch)
     assert isinstance(op, _WinoOperand) and op.mode == mode and op.w is w and op.version == w._version and op.shape == tuple(w.shape)
     WINO_CALLS.append((mode, tuple(w.shape)))

@@ -1547,8 +1547,11 @@ def test_two_timesteps_in_flight_match_single_pipeline(report):
 
 @pytest.mark.parametrize('which', ['tiny_forward', 'tiny_sweep', 'tiny_prune', 'cifar_c1', 'c1_size_1000', 'ddim', 'pruned_sweep', 'ldm_fwd_bwd',
                                    'finetune', 'ldm_prune', 'ldm_sweep', 'multi_head', 'bedroom_topology', 'ddpm', 'criteria'])
-def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report, monkeypatch):
-    """Round 4: the 3x3 / stride-1 convolutions of big launches run as a Winograd F(2, 3) implicit GEMM (csrc/winograd.hip; the
+@pytest.mark.parametrize('flavour', ['f23', 'f2x2_3x3'])
+def test_reference_fixtures_with_winograd_on_every_supported_layer(which, flavour, report, monkeypatch):
+    """Round 6: flavour f2x2_3x3 = the two-dimensional F(2x2, 3x3) kernel (csrc/winograd2d.hip) on every layer it supports (grid and
+    row-fill rules dropped), the one-dimensional kernel on the rest; flavour f23 = the one-dimensional kernel everywhere (WINO2D off).
+    Round 4: the 3x3 / stride-1 convolutions of big launches run as a Winograd F(2, 3) implicit GEMM (csrc/winograd.hip; the
     default leaves grids of < 512 tiles -- every fixture-sized model -- on the direct kernel).  Here the threshold is dropped, so
     EVERY supported layer of the fixture models takes the Winograd kernel, forward and input gradient, and the reference's recorded
     outputs / gradients / prune masks must still come out: masks bit-exact, tensors within the tolerances of the original tests."""
@@ -1558,12 +1561,18 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
     monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)              # ... and every supported weight gradient its Winograd kernel
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
+    monkeypatch.setattr(ops, 'WINO2D', flavour == 'f2x2_3x3')
+    monkeypatch.setattr(ops, 'WINO2D_MIN_TILES', 0)
+    monkeypatch.setattr(ops, 'WINO2D_MIN_FILL', 0.0)
     nw = [0]
     real_w = ops._conv_wgrad_wino
     monkeypatch.setattr(ops, '_conv_wgrad_wino', lambda *a: (lambda r: (nw.__setitem__(0, nw[0] + (r is not None)), r)[1])(real_w(*a)))
     n = [0]
     real = ops._conv_wino
     monkeypatch.setattr(ops, '_conv_wino', lambda *a: (lambda r: (n.__setitem__(0, n[0] + bool(r)), r)[1])(real(*a)))
+    n2 = [0]
+    real2 = ops._conv_wino2d
+    monkeypatch.setattr(ops, '_conv_wino2d', lambda *a: (lambda r: (n2.__setitem__(0, n2[0] + bool(r)), r)[1])(real2(*a)))
     sub = {}
     {'tiny_forward': test_tiny_forward_matches_reference_and_oracle, 'tiny_sweep': test_tiny_sweep_gradients_match_reference,
      'tiny_prune': test_tiny_prune_masks_bit_exact_and_post_prune_forward, 'cifar_c1': test_cifar_c1_masks_bit_exact,
@@ -1577,8 +1586,9 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, report
      'ddpm': test_ddpm_sampling_matches_reference,
      'criteria': lambda rep: [test_sibling_criteria_masks_bit_exact(rep, c) for c in ('full1', 'full2', 'abs', 'fisher', 'magnitude')],
      }[which](sub)
-    report['wino_forced/' + which] = dict(sub, winograd_launches=n[0], winograd_wgrad_launches=nw[0])
+    report['wino_forced/%s/%s' % (flavour, which)] = dict(sub, winograd_launches=n[0], winograd_2d_launches=n2[0], winograd_wgrad_launches=nw[0])
     assert n[0] > 0 and (nw[0] > 0 or which in ('tiny_forward', 'ddim', 'ddpm'))
+    assert (n2[0] > 0) == (flavour == 'f2x2_3x3'), (flavour, n2[0])
 
 
 @pytest.mark.parametrize('overlap', [False, True], ids=['one_stream', 'wgrad_side_stream'])

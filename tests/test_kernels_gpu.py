@@ -1203,6 +1203,60 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
     assert e['fwd'] < 3e-6 and e['acc'] < 3e-6 and e['dgrad'] < 3e-6, e
 
 
+@pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
+                                             (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (3, 128, 0, 64, 8),
+                                             (1, 8, 0, 16, 4), (2, 256, 0, 128, (6, 16))], ids=str)
+def test_conv_winograd_f2x2_3x3_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
+    """dp_conv_wino2d (3x3 / stride 1 / pad 1 as a TWO-dimensional Winograd F(2x2, 3x3) implicit GEMM, csrc/winograd2d.hip) against the
+    fp64 convolution: forward (two concat sources, bias, per-image addend, residual, scale; accumulate) and input gradient, next to
+    the direct and the F(2, 3) kernels' errors on the same inputs; output-channel tails (40, 70 rows in 64-row tiles); pixel blocks
+    that span several images (8 x 8, 4 x 4), partial last blocks (3 x 64 pixels, 1 x 16), non-square images; split-K; run-to-run bits."""
+    monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
+    monkeypatch.setattr(ops, 'WINO2D_MIN_TILES', 0)
+    Hh, Ww = H if isinstance(H, tuple) else (H, H)
+    xa, xb = rnd(N, C1, Hh, Ww, seed=1), (rnd(N, C2, Hh, Ww, seed=2) if C2 else None)
+    w = rnd(Cout, C1 + C2, 3, 3, seed=3, scale=0.05)
+    b, tadd, res = rnd(Cout, seed=4), rnd(N, Cout, seed=6), rnd(N, Cout, Hh, Ww, seed=7)
+    dy = rnd(N, Cout, Hh, Ww, seed=5)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    wp, ld = ops.pack_weight(w, 0)
+    wd, ldd = ops.pack_weight(w, 1)
+    U0, U1 = ops.pack_weight_wino(w, 0), ops.pack_weight_wino(w, 1)
+    V0, V1 = ('2d',) + tuple(ops.pack_weight_wino2d(w, 0)), ('2d',) + tuple(ops.pack_weight_wino2d(w, 1))
+    x = torch.cat([xa, xb], 1) if C2 else xa
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    ref = (ref + tadd.double().cpu()[:, :, None, None] + res.double().cpu()) * 0.7
+    ref_d = 0.5 * torch.nn.functional.conv_transpose2d(dy.double().cpu(), w.double().cpu(), padding=1)
+    launched = []
+    real = ops._conv_wino2d
+    monkeypatch.setattr(ops, '_conv_wino2d', lambda *a: (launched.append(real(*a)), launched[-1])[1])
+    y_w = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=V0)
+    y_1 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=U0)
+    y_d = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7)
+    acc = res.clone()
+    ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc, accumulate=True, wino=V0)
+    d_w = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (Hh, Ww), alpha=0.5, wino=V1)
+    d_d = ops.conv_dgrad(dy, wd, ldd, C1 + C2, spec, (Hh, Ww), alpha=0.5)
+    assert launched == [True, True, Cout % 8 == 0], launched          # dgrad contracts over Cout: 70 channels keep the direct form
+    ref_acc = res.double().cpu() + torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    e = dict(fwd=relerr(y_w, ref), fwd_f23=relerr(y_1, ref), fwd_direct=relerr(y_d, ref), acc=relerr(acc, ref_acc),
+             dgrad=relerr(d_w, ref_d), dgrad_direct=relerr(d_d, ref_d))
+    y_w2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=V0)
+    # split-K form (small grids): the channel-chunk loop over blockIdx.z + the reduction launch
+    monkeypatch.setattr(ops, 'WINO2D_MIN_TILES', 4 * (-(-Cout // 64)) * (-(-(N * Hh * Ww) // 128)))   # wants 4 slices, gets min(4, K tiles / 8)
+    if (C1 + C2) >= 128:                                 # >= 16 K tiles of 8 channels: at least two slices of 8
+        y_s = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=V0)
+        acc_s = res.clone()
+        ops.conv_forward(xa, xb, wp, ld, Cout, spec, out=acc_s, accumulate=True, wino=V0)
+        y_s2 = ops.conv_forward(xa, xb, wp, ld, Cout, spec, bias=b, tadd=tadd, res=res, post_scale=0.7, wino=V0)
+        e['fwd_splitk'], e['acc_splitk'] = relerr(y_s, ref), relerr(acc_s, ref_acc)
+        assert launched[-3:] == [True, True, True] and torch.equal(y_s, y_s2)
+        assert e['fwd_splitk'] < 3e-6 and e['acc_splitk'] < 3e-6, e
+    report['conv/winograd_f2x2_3x3/%d_%d_%d_%s' % (N, C1 + C2, Cout, H)] = dict(e, run_to_run_equal=bool(torch.equal(y_w, y_w2)))
+    assert torch.equal(y_w, y_w2)
+    assert e['fwd'] < 3e-6 and e['acc'] < 3e-6 and e['dgrad'] < 3e-6, e
+
+
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 192, 8),
                                              (2, 64, 0, 96, 64), (8, 40, 0, 70, 16), (1, 32, 0, 48, 256), (8, 96, 0, 96, 32), (4, 192, 96, 96, 16),
                                              (4, 179, 0, 90, 16)], ids=str)
