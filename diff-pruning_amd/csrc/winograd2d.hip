@@ -10,10 +10,11 @@
 // One 256-thread workgroup = 64 output channels x 32 tiles (128 output pixels: 128 / W whole image rows) x 16 positions.
 // Wavefront i owns ROW i of the position matrix -- positions (i, 0..3) -- for all 64 rows x 32 tiles: 4 positions x 2 row blocks x
 // 16 = 128 accumulator registers, two workgroups per CU.  Why this mapping:
-//   * row i of V needs only TWO of the four patch rows (B^T row i has two non-zeros): a lane reads 2 x 4 raw pixels of its (channel,
-//     tile) from LDS and forms its four B operands with 8 VALU adds and two border selects per 8 MFMAs -- the same VALU / LDS-read
-//     count per MFMA as the one-dimensional kernel;
-//   * the raw input tile in LDS is [channel][tile row][4 patch rows][W]: vertical zero padding and image boundaries are out-of-range
+//   * row i of V needs only TWO of the four patch rows (B^T row i has two non-zeros): a lane reads the 2 x 2 raw pixels of its (channel,
+//     tile) that no other tile owns from LDS (two conflict-free 8-byte reads), takes the two halo columns of the row combination
+//     from its neighbouring lanes (two DPP wave shifts) and forms its four B operands with 6 VALU adds and two border selects per
+//     8 MFMAs;
+//   * the raw input tile in LDS is [channel][4 patch rows][tile row][W]: vertical zero padding and image boundaries are out-of-range
 //     byte offsets of the LDS-DMA loads (the hardware writes zeros), horizontal padding two per-lane selects;
 //   * one K tile (8 channels) carries all 16 positions: there is no kernel-row loop, 32 MFMAs per wavefront between barriers;
 //   * the output transform is 2 x 2 signed sums inside the wavefront (columns) and one exchange through LDS between the four
@@ -31,17 +32,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dpw2_rsrc(const float* base, u
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DPW2_RSRC_FLAGS);
 }
 
+// One 8-byte LDS read as inline asm: the waitcnt pass treats a 64-bit-typed LDS load as aliasing the LDS-DMA writes of the prefetch
+// and drains vmcnt(0) in front of it (on the ISA, round 6: in the middle of every K tile of the 8-channel variant); it does not look
+// into inline asm.  The asm's result is pending on lgkmcnt: dpw2_lds_wait() before its first use.
+template <int OFF>
+__device__ __forceinline__ float2 dpw2_lds_read_b64(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return __builtin_bit_cast(float2, v);
+}
+__device__ __forceinline__ void dpw2_lds_wait(float2& a, float2& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+}
+__device__ __forceinline__ unsigned dpw2_lds_addr(const float* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const float*)p;
+}
+
 namespace {
 constexpr int W2_BM = 64;                      // output channels per workgroup
 constexpr int W2_BT = 32;                      // 2x2 tiles per workgroup (128 output pixels)
-constexpr int W2_BK = 8;                       // channels per K tile
-constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB)
-constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][tile row][4 patch rows][W] floats, tile rows x W = 64 (8 KB)
-constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ;
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];       // 80 KB: two workgroups per CU
+// W2_BK channels per K tile: 8 (32 MFMAs per wavefront between barriers, 80 KB of LDS: two workgroups per CU) or 4 (16 MFMAs, 40 KB:
+// three workgroups per CU when the registers allow it)
+template <int W2_BK, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
+    constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB at BK = 8)
+    constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][tile row][4 patch rows][W] floats, tile rows x W = 64 (8 KB at BK = 8)
+    constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ;
+    // the epilogue's exchange buffer reuses this memory: 64 KB at once when the K loop's buffers hold it, else 32 KB in two passes
+    __shared__ __attribute__((aligned(16))) float smem[(2 * W2_STAGE > 8192) ? 2 * W2_STAGE : 8192];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,23 +92,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
     const int rows_all = p.NPIX >> lw;                 // N * H
 
     // ---- A loader: 16-byte chunk e = tid + 256 j of [pos 16][k 8][m 64]
-    unsigned a_voff[8];
+    unsigned a_voff[W2_BK];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < W2_BK; ++j) {
         const int e = tid + 256 * j;
-        const int pos = e >> 7, k = (e >> 4) & 7, m = m0 + 4 * (e & 15);
+        const int pos = e / (16 * W2_BK), k = (e >> 4) % W2_BK, m = m0 + 4 * (e & 15);
         a_voff[j] = (m < p.lda) ? (unsigned)(((pos * C + k) * p.lda + m) * 4) : DPW2_OOB;
     }
     const __amdgpu_buffer_rsrc_t rA = dpw2_rsrc(p.A, p.a_bytes);
-    // ---- B loader: 16-byte chunk e = tid + 256 j of [k 8][tile row][patch row 4][W / 4]: 64 chunks per channel
-    unsigned b_voff1[2], b_voff2[2];
+    // ---- B loader: 16-byte chunk e = tid + 256 j of [k][patch row 4][tile row][W / 4]: 64 chunks per channel
+    constexpr int NJB = W2_BK / 4;
+    unsigned b_voff1[NJB], b_voff2[NJB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJB; ++j) {
         const int e = tid + 256 * j;
         const int k = e >> 6, within = e & 63;
-        const int tr = within >> lw;                   // W chunks per tile row (4 patch rows x W / 4)
-        const int rem = within & (W - 1);
-        const int r = rem >> (lw - 2), cx = rem & ((W >> 2) - 1);
+        const int r = within >> 4;                     // 16 chunks per patch row: (tile rows) x (W / 4)
+        const int rem = within & 15;
+        const int tr = rem >> (lw - 2), cx = rem & ((W >> 2) - 1);
         const int rg = row0 + 2 * tr;                  // global row of the tile row's first output row
         const int img = rg / H, y = rg - img * H + r - 1;
         const bool v = rg < rows_all && (unsigned)y < (unsigned)H;
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
     auto dma_tile = [&](int buf, int ch) {
         const unsigned a_soff = (unsigned)(ch * W2_BK) * (unsigned)p.lda * 4u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < W2_BK; ++j) {
             unsigned o = a_voff[j];
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw2_lds_void*)(ldsA + buf * W2_STAGE + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
         const bool first = c0 < C1;
         const unsigned b_soff = (unsigned)((first ? c0 : c0 - C1) * HW * 4);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJB; ++j) {
             unsigned o = first ? b_voff1[j] : b_voff2[j];
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(ldsB + buf * W2_STAGE + 1024 * j), 16, (int)o,
@@ -133,13 +154,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
     // ---- fragment addressing: lane = (k parity, li); A row 32 t + li of position (wave, j); B tile li
     const int li = lane & 31, lk = lane >> 5;
     const float* fragA = smem + ((wave * 4) * W2_BK + lk) * W2_BM + li;           // + (j*BK + 2 ks)*BM + 32 t
-    const int tr_l = li / TC, tc_l = li - tr_l * TC;
+    const int tr_l = li >> (lw - 1), tc_l = li & (TC - 1);           // TC = W / 2 is a power of two
     // the two patch rows of B^T row `wave`: (0, 2) -, (1, 2) +, (2, 1) -, (1, 3) -
     const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1;
     const int rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
     const float sgn = wave == 1 ? 1.f : -1.f;
-    const float* fragB1 = smem + W2_A_SZ + lk * 256 + ((tr_l * 4 + ra) << lw) + 2 * tc_l;     // + 2 ks * 256; cols -1 .. 2
-    const float* fragB2 = smem + W2_A_SZ + lk * 256 + ((tr_l * 4 + rb) << lw) + 2 * tc_l;
+    // [k][patch row][tile row][W]: the 32 lanes of a k half read 8 bytes each at 32 different 8-byte bank pairs (tile rows are W
+    // floats apart and (tile rows) x W = 64 = the bank row): conflict-free ds_read_b64
+    const float* fragB1 = smem + W2_A_SZ + lk * 256 + ra * 64 + (tr_l << lw) + 2 * tc_l;      // + 2 ks * 256; cols 0, 1 of the tile
+    const float* fragB2 = smem + W2_A_SZ + lk * 256 + rb * 64 + (tr_l << lw) + 2 * tc_l;
     const bool pad_l = tc_l == 0, pad_r = tc_l == TC - 1;
 
     int ch = it0;
@@ -154,24 +177,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
         const float* Af = fragA + buf * W2_STAGE;
         const float* B1 = fragB1 + buf * W2_STAGE;
         const float* B2 = fragB2 + buf * W2_STAGE;
-        float a[2][8], d[2][8], v[2][4];
-        auto frag = [&](int ks, float (&fa)[8], float (&fd)[8]) {
+        float a[2][8], v[2][4];
+        float2 d[2][2];
+        const unsigned b1a = dpw2_lds_addr(B1), b2a = dpw2_lds_addr(B2);
+        auto frag = [&](int ks, float (&fa)[8], float2 (&fd)[2]) {
+            // the tile's own two columns of the two patch rows (8-byte reads, conflict-free); columns -1 and +2 are the neighbouring
+            // tiles' columns 1 and 0 and come from the neighbouring LANES in xform (the lanes at the ends of an image row take the
+            // zero padding instead)
+            switch (ks) {
+                case 0:  fd[0] = dpw2_lds_read_b64<0>(b1a);    fd[1] = dpw2_lds_read_b64<0>(b2a);    break;
+                case 1:  fd[0] = dpw2_lds_read_b64<2048>(b1a); fd[1] = dpw2_lds_read_b64<2048>(b2a); break;
+                case 2:  fd[0] = dpw2_lds_read_b64<4096>(b1a); fd[1] = dpw2_lds_read_b64<4096>(b2a); break;
+                default: fd[0] = dpw2_lds_read_b64<6144>(b1a); fd[1] = dpw2_lds_read_b64<6144>(b2a); break;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) fa[2 * j + t] = Af[(j * W2_BK + 2 * ks) * W2_BM + 32 * t];
-            // plain float reads (see conv_wino_kernel: a float2-typed LDS access drains vmcnt(0) behind the prefetch)
-            fd[1] = B1[2 * ks * 256];
-            fd[2] = B1[2 * ks * 256 + 1];
-            fd[0] = B1[2 * ks * 256 - 1];
-            fd[3] = B1[2 * ks * 256 + 2];
-            fd[5] = B2[2 * ks * 256];
-            fd[6] = B2[2 * ks * 256 + 1];
-            fd[4] = B2[2 * ks * 256 - 1];
-            fd[7] = B2[2 * ks * 256 + 2];
         };
-        auto xform = [&](const float (&fd)[8], float (&fv)[4]) {
-            float c0 = fmaf(sgn, fd[4], fd[0]), c1 = fmaf(sgn, fd[5], fd[1]), c2 = fmaf(sgn, fd[6], fd[2]), c3 = fmaf(sgn, fd[7], fd[3]);
+        auto xform = [&](float2 (&fd)[2], float (&fv)[4]) {
+            dpw2_lds_wait(fd[0], fd[1]);
+            const float c1 = fmaf(sgn, fd[1].x, fd[0].x), c2 = fmaf(sgn, fd[1].y, fd[0].y);
+            // wave_shr:1 / wave_shl:1: lane l takes lane l - 1's c2 (column 2 tc - 1) / lane l + 1's c1 (column 2 tc + 2)
+            float c0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x138, 0xf, 0xf, false));
+            float c3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x130, 0xf, 0xf, false));
             c0 = pad_l ? 0.f : c0;
             c3 = pad_r ? 0.f : c3;
             fv[0] = c0 - c2; fv[1] = c1 + c2; fv[2] = c2 - c1; fv[3] = c1 - c3;
@@ -201,97 +230,117 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const dp_conv_gemm_
 
     // ---- output transform.  Columns inside the wavefront: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3];
     //      rows across the wavefronts through LDS: Y[0][q] = Z[0][q] + Z[1][q] + Z[2][q], Y[1][q] = Z[1][q] - Z[2][q] - Z[3][q].
-    //      zbuf[((i*2 + q)*2 + t)*16 + r][lane]: 64 KB of the K loop's buffers (every wavefront is past the last barrier).
+    //      The K loop's buffers are free (every wavefront is past its last barrier).  PASSES = 1: both row blocks at once, 64 KB,
+    //      wavefront w finishes row block w >> 1, registers 8 (w & 1) .. + 7.  PASSES = 2 (the 40 KB variant): one row block per pass,
+    //      32 KB, wavefront w finishes registers 4 w .. 4 w + 3 of it.
+    constexpr int PASSES = (2 * W2_STAGE >= 16384) ? 1 : 2;
+    constexpr int NR = 8 / PASSES;                     // accumulator registers (= output rows) a wavefront finishes per pass
     float* zbuf = smem;
+    // the lane's tile coordinates once more, from a laundered lane id: nothing of the epilogue's addressing stays live across the K
+    // loop (the 40 KB variant runs at the 168-register cap of three workgroups per CU and would spill it)
+    int li_e = threadIdx.x & 31;
+    asm volatile("" : "+v"(li_e));
+    const int tr_e = li_e >> (lw - 1), tc_e = li_e & (TC - 1);
+    const int rg = row0 + 2 * tr_e;                    // global row of this lane's tile
+    const bool tile_ok = rg < rows_all;
+    int H_e = H;
+    asm volatile("" : "+s"(H_e));                      // (... including the reciprocal of the division by H)
+    const int img = tile_ok ? rg / H_e : 0, y = tile_ok ? rg - img * H_e : 0;
+    const int r_in = y * W + 2 * tc_e;
+    float* optr = p.out + (long long)img * p.o_img_stride + r_in;
+    const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
+    const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
+    float* wsb = ksplit ? p.ws + (long long)blockIdx.z * p.M * p.NPIX + (long long)img * HW + r_in : nullptr;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass) __syncthreads();                     // the previous pass's reads are done
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            zbuf[(((wave * 2 + 0) * 2 + t) * 16 + r) * 64 + lane] = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
-            zbuf[(((wave * 2 + 1) * 2 + t) * 16 + r) * 64 + lane] = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
+        for (int t = 0; t < 2; ++t) {
+            if (PASSES == 2 && t != pass) continue;
+            const int tz = PASSES == 2 ? 0 : t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                zbuf[(((wave * 2 + 0) * (2 / PASSES) + tz) * 16 + r) * 64 + lane] = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
+                zbuf[(((wave * 2 + 1) * (2 / PASSES) + tz) * 16 + r) * 64 + lane] = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
+            }
         }
-    __syncthreads();
-    // wavefront w finishes row block t = w >> 1, registers r = 8 (w & 1) .. + 7: element (m, tile li) of every lane
-    const int t_o = wave >> 1, r_o = 8 * (wave & 1);
-    const int rg = row0 + 2 * tr_l;                    // global row of this lane's tile
-    if (rg >= rows_all) return;
-    const int img = rg / H, y = rg - img * H;
-    const int r_in = y * W + 2 * tc_l;
-    if (ksplit) {
-        float* wsb = p.ws + (long long)blockIdx.z * p.M * p.NPIX + (long long)img * HW + r_in;
+        __syncthreads();
+        if (!tile_ok) continue;
+        const int t_o = PASSES == 2 ? pass : (wave >> 1);
+        const int tz_o = PASSES == 2 ? 0 : t_o;
+        const int r_o = PASSES == 2 ? 4 * wave : 8 * (wave & 1);
+        if (ksplit) {
 #pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
+            for (int q8 = 0; q8 < NR; ++q8) {
+                const int r = r_o + q8;
+                const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
+                float z[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * (2 / PASSES) + tz_o) * 16 + r) * 64 + lane];
+                if (m >= p.M) continue;
+                float* o = wsb + (long long)m * p.NPIX;
+                *reinterpret_cast<float2*>(o) = make_float2((z[0][0] + z[1][0]) + z[2][0], (z[0][1] + z[1][1]) + z[2][1]);
+                *reinterpret_cast<float2*>(o + W) = make_float2((z[1][0] - z[2][0]) - z[3][0], (z[1][1] - z[2][1]) - z[3][1]);
+            }
+            continue;
+        }
+        // all NR rows' operand loads in flight before the first use (clamped row index; rows >= M skip the store)
+        int mc[NR];
+        float tb[NR], tt[NR];
+        float2 tr0[NR], tr1[NR], tp0[NR], tp1[NR];
+#pragma unroll
+        for (int q8 = 0; q8 < NR; ++q8) {
+            const int r = r_o + q8;
+            const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
+            mc[q8] = m < p.M ? m : p.M - 1;
+            tb[q8] = tt[q8] = 0.f;
+            tr0[q8] = tr1[q8] = tp0[q8] = tp1[q8] = make_float2(0.f, 0.f);
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int q8 = 0; q8 < NR; ++q8) tb[q8] = p.bias[mc[q8]];
+        }
+        if (tptr) {
+#pragma unroll
+            for (int q8 = 0; q8 < NR; ++q8) tt[q8] = tptr[mc[q8]];
+        }
+        if (rptr) {
+#pragma unroll
+            for (int q8 = 0; q8 < NR; ++q8) {
+                tr0[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW);
+                tr1[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW + W);
+            }
+        }
+        if (p.accumulate) {
+#pragma unroll
+            for (int q8 = 0; q8 < NR; ++q8) {
+                tp0[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW);
+                tp1[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW + W);
+            }
+        }
+#pragma unroll
+        for (int q8 = 0; q8 < NR; ++q8) {
             const int r = r_o + q8;
             const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
             float z[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * 2 + t_o) * 16 + r) * 64 + lane];
-            if (m >= p.M) continue;
-            float* o = wsb + (long long)m * p.NPIX;
-            *reinterpret_cast<float2*>(o) = make_float2((z[0][0] + z[1][0]) + z[2][0], (z[0][1] + z[1][1]) + z[2][1]);
-            *reinterpret_cast<float2*>(o + W) = make_float2((z[1][0] - z[2][0]) - z[3][0], (z[1][1] - z[2][1]) - z[3][1]);
-        }
-        return;
-    }
-    float* optr = p.out + (long long)img * p.o_img_stride + r_in;
-    const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
-    const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
-    // all eight rows' operand loads in flight before the first use (clamped row index; rows >= M skip the store)
-    int mc[8];
-    float tb[8], tt[8];
-    float2 tr0[8], tr1[8], tp0[8], tp1[8];
-#pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) {
-        const int r = r_o + q8;
-        const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
-        mc[q8] = m < p.M ? m : p.M - 1;
-        tb[q8] = tt[q8] = 0.f;
-        tr0[q8] = tr1[q8] = tp0[q8] = tp1[q8] = make_float2(0.f, 0.f);
-    }
-    if (p.bias) {
-#pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) tb[q8] = p.bias[mc[q8]];
-    }
-    if (tptr) {
-#pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) tt[q8] = tptr[mc[q8]];
-    }
-    if (rptr) {
-#pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-            tr0[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW);
-            tr1[q8] = *reinterpret_cast<const float2*>(rptr + (long long)mc[q8] * HW + W);
-        }
-    }
-    if (p.accumulate) {
-#pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-            tp0[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW);
-            tp1[q8] = *reinterpret_cast<const float2*>(optr + (long long)mc[q8] * HW + W);
-        }
-    }
-#pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) {
-        const int r = r_o + q8;
-        const int m = m0 + 32 * t_o + 4 * lk + (r & 3) + 8 * (r >> 2);
-        float z[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * 2 + t_o) * 16 + r) * 64 + lane];
-        float y00 = p.alpha * ((z[0][0] + z[1][0]) + z[2][0]), y01 = p.alpha * ((z[0][1] + z[1][1]) + z[2][1]);
-        float y10 = p.alpha * ((z[1][0] - z[2][0]) - z[3][0]), y11 = p.alpha * ((z[1][1] - z[2][1]) - z[3][1]);
-        if (p.bias) { y00 += tb[q8]; y01 += tb[q8]; y10 += tb[q8]; y11 += tb[q8]; }
-        if (tptr) { y00 += tt[q8]; y01 += tt[q8]; y10 += tt[q8]; y11 += tt[q8]; }
-        if (rptr) { y00 += tr0[q8].x; y01 += tr0[q8].y; y10 += tr1[q8].x; y11 += tr1[q8].y; }
-        y00 *= p.post_scale; y01 *= p.post_scale; y10 *= p.post_scale; y11 *= p.post_scale;
-        if (p.act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
-        if (p.accumulate) { y00 += tp0[q8].x; y01 += tp0[q8].y; y10 += tp1[q8].x; y11 += tp1[q8].y; }
-        if (m < p.M) {
-            *reinterpret_cast<float2*>(optr + (long long)m * HW) = make_float2(y00, y01);
-            *reinterpret_cast<float2*>(optr + (long long)m * HW + W) = make_float2(y10, y11);
+                for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * (2 / PASSES) + tz_o) * 16 + r) * 64 + lane];
+            float y00 = p.alpha * ((z[0][0] + z[1][0]) + z[2][0]), y01 = p.alpha * ((z[0][1] + z[1][1]) + z[2][1]);
+            float y10 = p.alpha * ((z[1][0] - z[2][0]) - z[3][0]), y11 = p.alpha * ((z[1][1] - z[2][1]) - z[3][1]);
+            if (p.bias) { y00 += tb[q8]; y01 += tb[q8]; y10 += tb[q8]; y11 += tb[q8]; }
+            if (tptr) { y00 += tt[q8]; y01 += tt[q8]; y10 += tt[q8]; y11 += tt[q8]; }
+            if (rptr) { y00 += tr0[q8].x; y01 += tr0[q8].y; y10 += tr1[q8].x; y11 += tr1[q8].y; }
+            y00 *= p.post_scale; y01 *= p.post_scale; y10 *= p.post_scale; y11 *= p.post_scale;
+            if (p.act == 1) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+            if (p.accumulate) { y00 += tp0[q8].x; y01 += tp0[q8].y; y10 += tp1[q8].x; y11 += tp1[q8].y; }
+            if (m < p.M) {
+                *reinterpret_cast<float2*>(optr + (long long)m * HW) = make_float2(y00, y01);
+                *reinterpret_cast<float2*>(optr + (long long)m * HW + W) = make_float2(y10, y11);
+            }
         }
     }
 }
@@ -319,7 +368,15 @@ extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
     if (p.M <= 0 || p.NPIX <= 0) return 0;
     if (!wino2d_ok(p)) return (int)hipErrorInvalidValue;
     dim3 grid((p.NPIX + 127) / 128, (p.M + W2_BM - 1) / W2_BM, p.ksplit > 1 ? p.ksplit : 1);
-    DP_LAUNCH(conv_wino2d_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // K tiles of 4 channels (40 KB of LDS, 164 VGPRs: three workgroups per CU) for grids of at least one full round of them, K tiles
+    // of 8 (80 KB, two per CU, half the barriers) for the small and the split-K grids.  [measured, round 6,
+    // profiles/round6_wino2d_variants.txt, batch 256: 256 -> 256 @ 16 x 16 0.329 -> 0.307 ms, 128 -> 128 @ 32 x 32 0.367 -> 0.350,
+    // 384 -> 384 @ 32 x 32 (12 latents) 0.187 -> 0.167; 256 -> 256 @ 8 x 8 0.097 -> 0.100, @ 4 x 4 (split-K) 0.063 -> 0.069]
+    static const int forced = [] { const char* e = getenv("DP_WINO2D_VARIANT"); return e ? atoi(e) : -1; }();
+    const long long wgs = (long long)grid.x * grid.y * grid.z;
+    const int variant = forced >= 0 ? forced : ((p.ksplit <= 1 && wgs >= 768) ? 1 : 0);
+    if (variant == 1) DP_LAUNCH((conv_wino2d_kernel<4, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else              DP_LAUNCH((conv_wino2d_kernel<8, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     const int e = DP_LAUNCH_CHECK();
     if (e || p.ksplit <= 1) return e;
     return dp_conv_splitk_epilogue(pp, stream);
