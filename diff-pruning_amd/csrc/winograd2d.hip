@@ -368,13 +368,13 @@ extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
     if (p.M <= 0 || p.NPIX <= 0) return 0;
     if (!wino2d_ok(p)) return (int)hipErrorInvalidValue;
     dim3 grid((p.NPIX + 127) / 128, (p.M + W2_BM - 1) / W2_BM, p.ksplit > 1 ? p.ksplit : 1);
-    // K tiles of 4 channels (40 KB of LDS, 164 VGPRs: three workgroups per CU) for grids of at least one full round of them, K tiles
+    // K tiles of 4 channels (40 KB of LDS, 164 VGPRs: three workgroups per CU) for grids beyond one round of two per CU, K tiles
     // of 8 (80 KB, two per CU, half the barriers) for the small and the split-K grids.  [measured, round 6,
     // profiles/round6_wino2d_variants.txt, batch 256: 256 -> 256 @ 16 x 16 0.329 -> 0.307 ms, 128 -> 128 @ 32 x 32 0.367 -> 0.350,
     // 384 -> 384 @ 32 x 32 (12 latents) 0.187 -> 0.167; 256 -> 256 @ 8 x 8 0.097 -> 0.100, @ 4 x 4 (split-K) 0.063 -> 0.069]
     static const int forced = [] { const char* e = getenv("DP_WINO2D_VARIANT"); return e ? atoi(e) : -1; }();
     const long long wgs = (long long)grid.x * grid.y * grid.z;
-    const int variant = forced >= 0 ? forced : ((p.ksplit <= 1 && wgs >= 768) ? 1 : 0);
+    const int variant = forced >= 0 ? forced : ((p.ksplit <= 1 && wgs > 512) ? 1 : 0);     // 512 = one round of two per CU
     if (variant == 1) DP_LAUNCH((conv_wino2d_kernel<4, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else              DP_LAUNCH((conv_wino2d_kernel<8, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     const int e = DP_LAUNCH_CHECK();

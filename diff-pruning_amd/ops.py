@@ -379,14 +379,15 @@ def wino2d_shape_ok(M, C_sources, N, H, W):
             and sum(C_sources) >= 8 and M >= 16)
 
 
-WINO2D_MIN_FILL = float(os.environ.get('DP_WINO2D_MIN_FILL', '0.85'))    # M / (64-row tiles x 64): 96 rows fill 75 % -> F(2, 3)'s 32-row tiles
+WINO2D_MIN_FILL = float(os.environ.get('DP_WINO2D_MIN_FILL', '0.7'))     # M / (64-row tiles x 64): 96 rows fill 75 % (1.04-1.09x F(2, 3)'s 32-row tiles); 40 of 64 do not
 
 
 def wino2d_wanted(M, C_sources, N, H, W, spec):
     """Shape rule (wino2d_ok in csrc/winograd2d.hip) + grid rule (_conv_wino2d) + row-tile fill: True when a 3x3 / stride 1 / pad 1
     convolution should go to dp_conv_wino2d.  [measured, round 6, profiles/round6_wino2d_gate.txt, batch 256, against F(2, 3):
     128 -> 128 @ 32 x 32 1.43x forward / 1.31x input gradient, 256 -> 256 @ 16 x 16 1.33x / 1.29x, @ 8 x 8 1.21x, @ 4 x 4 1.13x,
-    192 -> 192 @ 16 x 16 1.27x, 384 -> 384 @ 32 x 32 (12 latents) 1.24x; 96 -> 96 @ 32 x 32 0.97x: 64-row tiles fill 75 %.]"""
+    192 -> 192 @ 16 x 16 1.27x, 384 -> 384 @ 32 x 32 (12 latents) 1.24x; 96 -> 96 @ 32 x 32 0.97x: 64-row tiles fill 75 %.  With the
+    tuned kernel (profiles/round6_wino2d_tuned.txt): 1.50x / 1.40x, 1.46x / 1.39x, 1.42x, 1.38x, 1.34x, 1.28x, 1.09x / 1.04x.]"""
     if not WINO or getattr(spec, 'keep', False) or getattr(spec, 'sym', False):
         return False
     if not (spec.kh == 3 and spec.kw == 3 and spec.stride == 1 and spec.pad_h == 1 and spec.pad_w == 1 and not spec.ups):
