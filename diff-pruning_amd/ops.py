@@ -438,9 +438,18 @@ def _conv_wino2d(p, wino2d, act_bytes):
     if not _lib().dp_conv_wino2d_supported(C.byref(p)):
         p.A, p.lda, p.a_bytes, p.ksplit, p.ws = A0, lda0, ab0, 1, None
         return False
-    L.check(_run(lambda: _lib().dp_conv_wino2d(C.byref(p), _stream()), 'conv_wino2d_kernel', 2.0 * p.M * p.NPIX * p.C * 4,
+    L.check(_run(lambda: _lib().dp_conv_wino2d(C.byref(p), _stream()), _wino2d_name(p), 2.0 * p.M * p.NPIX * p.C * 4,
                  act_bytes + 4.0 * U.numel()), 'dp_conv_wino2d')
     return True
+
+
+def _wino2d_name(p):
+    """The instantiation dp_conv_wino2d launches (the launcher's rule, csrc/winograd2d.hip): 4-channel K tiles at three workgroups
+    per CU for grids beyond one round of two per CU, 8-channel K tiles for the small and the split-K grids."""
+    wgs = -(-p.NPIX // 128) * -(-p.M // 64) * max(int(p.ksplit), 1)
+    forced = os.environ.get('DP_WINO2D_VARIANT')
+    v = int(forced) if forced not in (None, '') else (1 if (p.ksplit <= 1 and wgs > 512) else 0)
+    return 'conv_wino2d_kernel<4, 3>' if v == 1 else 'conv_wino2d_kernel<8, 2>'
 
 
 # ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------
