@@ -42,9 +42,10 @@ print('$c', round(d['value'],2), d['unit'], round(d['ms_per_step'],2), 'ms/step;
   DP_SAMPLE_REPLAY=0 python bench.py --config ddim --no-roofline 2>/dev/null | tail -1 > $O/${R}_ddim_eager.json
   ( python tools/bench_c1.py; python tools/exp_replay.py cifar 4 eager native ) 2>&1 | grep -v amdgpu.ids > $O/${R}_c1_latency.log; cat $O/${R}_c1_latency.log
   DP_WINO=0 DP_WGRAD_WINO=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/${R}_bench_line_direct_kernels.json
+  DP_WINO2D=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/${R}_bench_line_winograd_1d_only.json
   python -c "
-import json; a=json.load(open('$O/${R}_bench_line.json')); b=json.load(open('$O/${R}_bench_line_direct_kernels.json'))
-print('headline ms/step: winograd', round(a['ms_per_step'],2), 'direct kernels only', round(b['ms_per_step'],2))" ;;
+import json; a=json.load(open('$O/${R}_bench_line.json')); b=json.load(open('$O/${R}_bench_line_direct_kernels.json')); c=json.load(open('$O/${R}_bench_line_winograd_1d_only.json'))
+print('headline ms/step: F(2x2,3x3) + F(2,3)', round(a['ms_per_step'],2), '; F(2,3) only (DP_WINO2D=0)', round(c['ms_per_step'],2), '; direct kernels only', round(b['ms_per_step'],2))" ;;
 profiles)
   stats bench python bench.py --steps 10 --warmup 2 --no-cpu-baseline
   DP_NO_OVERLAP=1 DP_TIMESTEP_PIPELINES=1 stats bench_serial python bench.py --steps 10 --warmup 2 --no-cpu-baseline
