@@ -55,11 +55,14 @@ constexpr int W2_BT = 32;                      // 2x2 tiles per workgroup (128 o
 
 // W2_BK channels per K tile: 8 (32 MFMAs per wavefront between barriers, 80 KB of LDS: two workgroups per CU) or 4 (16 MFMAs, 40 KB:
 // three workgroups per CU when the registers allow it)
-template <int W2_BK, int OCC>
+// SEG (images wider than 64 pixels): a block is ONE tile row of 32 tiles = a 2-row x 64-column segment; the two halo columns of its
+// 4-row patch belong to the neighbouring segments (or are the image border) and come through a small extra tile [k][patch row][side][4].
+template <int W2_BK, int OCC, bool SEG>
 __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
     constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB at BK = 8)
-    constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][tile row][4 patch rows][W] floats, tile rows x W = 64 (8 KB at BK = 8)
-    constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ;
+    constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][4 patch rows][tile row][W] floats, tile rows x W = 64 (8 KB at BK = 8)
+    constexpr int W2_H_SZ = SEG ? W2_BK * 32 : 0;  // halo columns of a segment: [k][patch row][left | right][4 floats]
+    constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ + W2_H_SZ;
     // the epilogue's exchange buffer reuses this memory: 64 KB at once when the K loop's buffers hold it, else 32 KB in two passes
     __shared__ __attribute__((aligned(16))) float smem[(2 * W2_STAGE > 8192) ? 2 * W2_STAGE : 8192];
 
@@ -88,7 +91,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     const int per = ksplit ? (nIterAll + p.ksplit - 1) / p.ksplit : nIterAll;
     const int it0 = ksplit ? (int)blockIdx.z * per : 0;
     const int nIter = ksplit ? max(0, min(per, nIterAll - it0)) : nIterAll;
-    const int row0 = (bxx * 128) >> lw;                // first global image row (over all images) of this block; even
+    // first global image row (over all images) of this block (even) and, for segments, its first column
+    const int row0 = SEG ? 2 * (bxx >> (lw - 6)) : (bxx * 128) >> lw;
+    const int x0 = SEG ? (bxx & ((1 << (lw - 6)) - 1)) << 6 : 0;
     const int rows_all = p.NPIX >> lw;                 // N * H
 
     // ---- A loader: 16-byte chunk e = tid + 256 j of [pos 16][k 8][m 64]
@@ -109,13 +114,24 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
         const int k = e >> 6, within = e & 63;
         const int r = within >> 4;                     // 16 chunks per patch row: (tile rows) x (W / 4)
         const int rem = within & 15;
-        const int tr = rem >> (lw - 2), cx = rem & ((W >> 2) - 1);
+        const int tr = SEG ? 0 : rem >> (lw - 2), cx = SEG ? rem : rem & ((W >> 2) - 1);
         const int rg = row0 + 2 * tr;                  // global row of the tile row's first output row
         const int img = rg / H, y = rg - img * H + r - 1;
         const bool v = rg < rows_all && (unsigned)y < (unsigned)H;
-        const unsigned lin = (unsigned)(k * HW + y * W + 4 * cx);
+        const unsigned lin = (unsigned)(k * HW + y * W + x0 + 4 * cx);
         b_voff1[j] = v ? ((unsigned)((long long)img * g.x1_img_stride) + lin) * 4u : DPW2_OOB;
         b_voff2[j] = v ? ((unsigned)((long long)img * g.x2_img_stride) + lin) * 4u : DPW2_OOB;
+    }
+    // ---- halo loader (segments): chunk e = tid < 8 BK of [k][patch row][side]: the 4 pixels left of / right of the segment
+    unsigned h_voff1 = DPW2_OOB, h_voff2 = DPW2_OOB;
+    if (SEG && tid < 8 * W2_BK) {
+        const int k = tid >> 3, r = (tid >> 1) & 3, side = tid & 1;
+        const int img = row0 / H, y = row0 - img * H + r - 1;
+        const int col = side ? x0 + 64 : x0 - 4;
+        const bool v = row0 < rows_all && (unsigned)y < (unsigned)H && (unsigned)col < (unsigned)W;      // outside the image: zeros
+        const unsigned lin = (unsigned)(k * HW + y * W + col);
+        h_voff1 = v ? ((unsigned)((long long)img * g.x1_img_stride) + lin) * 4u : DPW2_OOB;
+        h_voff2 = v ? ((unsigned)((long long)img * g.x2_img_stride) + lin) * 4u : DPW2_OOB;
     }
     const __amdgpu_buffer_rsrc_t r1 = dpw2_rsrc(p.X1, p.x1_bytes);
     const __amdgpu_buffer_rsrc_t r2 = dpw2_rsrc(p.X2 ? p.X2 : p.X1, p.X2 ? p.x2_bytes : p.x1_bytes);
@@ -141,6 +157,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
             __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(ldsB + buf * W2_STAGE + 1024 * j), 16, (int)o,
                                                      (int)b_soff, 0, 0);
         }
+        if (SEG && wave == 0) {
+            if (lane < 8 * W2_BK) {
+                unsigned o = first ? h_voff1 : h_voff2;
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(smem + W2_A_SZ + W2_B_SZ + buf * W2_STAGE), 16,
+                                                         (int)o, (int)b_soff, 0, 0);
+            }
+        }
     };
 
     f32x16 acc[4][2];
@@ -154,7 +178,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     // ---- fragment addressing: lane = (k parity, li); A row 32 t + li of position (wave, j); B tile li
     const int li = lane & 31, lk = lane >> 5;
     const float* fragA = smem + ((wave * 4) * W2_BK + lk) * W2_BM + li;           // + (j*BK + 2 ks)*BM + 32 t
-    const int tr_l = li >> (lw - 1), tc_l = li & (TC - 1);           // TC = W / 2 is a power of two
+    const int tr_l = SEG ? 0 : li >> (lw - 1), tc_l = SEG ? li : li & (TC - 1);      // TC = W / 2 is a power of two
     // the two patch rows of B^T row `wave`: (0, 2) -, (1, 2) +, (2, 1) -, (1, 3) -
     const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1;
     const int rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
@@ -163,7 +187,9 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     // floats apart and (tile rows) x W = 64 = the bank row): conflict-free ds_read_b64
     const float* fragB1 = smem + W2_A_SZ + lk * 256 + ra * 64 + (tr_l << lw) + 2 * tc_l;      // + 2 ks * 256; cols 0, 1 of the tile
     const float* fragB2 = smem + W2_A_SZ + lk * 256 + rb * 64 + (tr_l << lw) + 2 * tc_l;
-    const bool pad_l = tc_l == 0, pad_r = tc_l == TC - 1;
+    const bool pad_l = tc_l == 0, pad_r = tc_l == (SEG ? 31 : TC - 1);
+    // segments: the halo tile's column x0 - 1 (fourth float of the left chunk) and x0 + 64 (first of the right one), rows ra / rb
+    const float* fragH = smem + W2_A_SZ + W2_B_SZ + lk * 32;            // + 2 ks * 32 + (row*2 + side)*4 + {3 | 0}
 
     int ch = it0;
     if (nIter > 0) {
@@ -177,10 +203,11 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
         const float* Af = fragA + buf * W2_STAGE;
         const float* B1 = fragB1 + buf * W2_STAGE;
         const float* B2 = fragB2 + buf * W2_STAGE;
-        float a[2][8], v[2][4];
+        float a[2][8], v[2][4], hh[2][4];
         float2 d[2][2];
+        const float* Hf = fragH + buf * W2_STAGE;
         const unsigned b1a = dpw2_lds_addr(B1), b2a = dpw2_lds_addr(B2);
-        auto frag = [&](int ks, float (&fa)[8], float2 (&fd)[2]) {
+        auto frag = [&](int ks, float (&fa)[8], float2 (&fd)[2], float (&fh)[4]) {
             // the tile's own two columns of the two patch rows (8-byte reads, conflict-free); columns -1 and +2 are the neighbouring
             // tiles' columns 1 and 0 and come from the neighbouring LANES in xform (the lanes at the ends of an image row take the
             // zero padding instead)
@@ -194,23 +221,30 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) fa[2 * j + t] = Af[(j * W2_BK + 2 * ks) * W2_BM + 32 * t];
+            if (SEG) {                                   // (wave-uniform addresses per k half: broadcast reads)
+                fh[0] = Hf[2 * ks * 32 + (ra * 2 + 0) * 4 + 3];
+                fh[1] = Hf[2 * ks * 32 + (rb * 2 + 0) * 4 + 3];
+                fh[2] = Hf[2 * ks * 32 + (ra * 2 + 1) * 4];
+                fh[3] = Hf[2 * ks * 32 + (rb * 2 + 1) * 4];
+            }
         };
-        auto xform = [&](float2 (&fd)[2], float (&fv)[4]) {
+        auto xform = [&](float2 (&fd)[2], const float (&fh)[4], float (&fv)[4]) {
             dpw2_lds_wait(fd[0], fd[1]);
             const float c1 = fmaf(sgn, fd[1].x, fd[0].x), c2 = fmaf(sgn, fd[1].y, fd[0].y);
             // wave_shr:1 / wave_shl:1: lane l takes lane l - 1's c2 (column 2 tc - 1) / lane l + 1's c1 (column 2 tc + 2)
             float c0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x138, 0xf, 0xf, false));
             float c3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x130, 0xf, 0xf, false));
-            c0 = pad_l ? 0.f : c0;
-            c3 = pad_r ? 0.f : c3;
+            // the block's first / last tile: the image border (zeros) or, in a segment, the neighbouring segment's column
+            c0 = pad_l ? (SEG ? fmaf(sgn, fh[1], fh[0]) : 0.f) : c0;
+            c3 = pad_r ? (SEG ? fmaf(sgn, fh[3], fh[2]) : 0.f) : c3;
             fv[0] = c0 - c2; fv[1] = c1 + c2; fv[2] = c2 - c1; fv[3] = c1 - c3;
         };
-        frag(0, a[0], d[0]);
-        xform(d[0], v[0]);
+        frag(0, a[0], d[0], hh[0]);
+        xform(d[0], hh[0], v[0]);
 #pragma unroll
         for (int ks = 0; ks < W2_BK / 2; ++ks) {
             const int cur = ks & 1;
-            if (ks + 1 < W2_BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1]);
+            if (ks + 1 < W2_BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1], hh[cur ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -218,7 +252,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
                 for (int t = 0; t < 2; ++t)
                     acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2 * j + t], v[cur][j], acc[j][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < W2_BK / 2) { xform(d[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
+            if (ks + 1 < W2_BK / 2) { xform(d[cur ^ 1], hh[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
             // unconditional (the last K tile fetches itself once more into the idle buffer): a branch here moves the loads out of
             // the loop body and in front of a compiler-placed wait
             if (ks == 0) { dma_tile(buf ^ 1, ch_next); __builtin_amdgcn_sched_barrier(0); }
@@ -240,13 +274,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     // loop (the 40 KB variant runs at the 168-register cap of three workgroups per CU and would spill it)
     int li_e = threadIdx.x & 31;
     asm volatile("" : "+v"(li_e));
-    const int tr_e = li_e >> (lw - 1), tc_e = li_e & (TC - 1);
+    const int tr_e = SEG ? 0 : li_e >> (lw - 1), tc_e = SEG ? li_e : li_e & (TC - 1);
     const int rg = row0 + 2 * tr_e;                    // global row of this lane's tile
     const bool tile_ok = rg < rows_all;
     int H_e = H;
     asm volatile("" : "+s"(H_e));                      // (... including the reciprocal of the division by H)
     const int img = tile_ok ? rg / H_e : 0, y = tile_ok ? rg - img * H_e : 0;
-    const int r_in = y * W + 2 * tc_e;
+    const int r_in = y * W + x0 + 2 * tc_e;
     float* optr = p.out + (long long)img * p.o_img_stride + r_in;
     const float* rptr = p.res ? p.res + (long long)img * p.r_img_stride + r_in : nullptr;
     const float* tptr = p.tadd ? p.tadd + (long long)img * p.tadd_stride : nullptr;
@@ -345,14 +379,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     }
 }
 
-// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 64 (128 output pixels = whole image rows,
-// whole tile rows), H even, channel counts (per concat source) in multiples of 8, 8-byte aligned image planes.
+// Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 256 (128 output pixels = whole image rows of
+// whole tile rows up to 64 pixels; one 2 x 64 segment of a tile row beyond), H even, channel counts (per concat source) in multiples of 8, 8-byte aligned image planes.
 static bool wino2d_ok(const dp_conv_gemm_params& p) {
     const dp_conv_geom& g = p.g;
     if (p.a_kc || p.ntaps != 9 || g.kw != 3 || g.stride != 1 || g.sden != 1 || g.ups || g.pad_t != 1 || g.pad_l != 1) return false;
     if (g.Ho != g.Hs || g.Wo != g.Ws || g.Hs != g.Hv || g.Ws != g.Wv || p.batches > 1 || (p.ksplit > 1 && !p.ws)) return false;
     const int W = g.Wo, H = g.Ho;
-    if (W < 4 || W > 64 || (W & (W - 1)) || (H & 1)) return false;
+    if (W < 4 || W > 256 || (W & (W - 1)) || (H & 1)) return false;
     if ((p.lda & 3) || p.NPIX % (H * W)) return false;
     if ((g.x1_img_stride & 1) || (p.X2 && (g.x2_img_stride & 1)) || (p.o_img_stride & 1) || (p.res && (p.r_img_stride & 1))) return false;
     if ((unsigned long long)p.x1_bytes >= 0x80000000ull || (p.X2 && (unsigned long long)p.x2_bytes >= 0x80000000ull)) return false;
@@ -375,8 +409,13 @@ extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
     static const int forced = [] { const char* e = getenv("DP_WINO2D_VARIANT"); return e ? atoi(e) : -1; }();
     const long long wgs = (long long)grid.x * grid.y * grid.z;
     const int variant = forced >= 0 ? forced : ((p.ksplit <= 1 && wgs > 512) ? 1 : 0);     // 512 = one round of two per CU
-    if (variant == 1) DP_LAUNCH((conv_wino2d_kernel<4, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else              DP_LAUNCH((conv_wino2d_kernel<8, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (p.g.Wo > 64) {                       // 2 x 64-pixel segments of two image rows: 4-channel K tiles (42 KB of LDS) at whatever
+        (void)variant;                       // occupancy ~180 registers allow (the halo operands do not fit under the 168 of three per CU)
+        DP_LAUNCH((conv_wino2d_kernel<4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (variant == 1) DP_LAUNCH((conv_wino2d_kernel<4, 3, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else              DP_LAUNCH((conv_wino2d_kernel<8, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     const int e = DP_LAUNCH_CHECK();
     if (e || p.ksplit <= 1) return e;
     return dp_conv_splitk_epilogue(pp, stream);

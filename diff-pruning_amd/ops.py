@@ -375,7 +375,7 @@ WINO2D_MIN_TILES = int(os.environ.get('DP_WINO2D_MIN_TILES', '512'))   # 64-row 
 
 def wino2d_shape_ok(M, C_sources, N, H, W):
     """Host-side mirror of wino2d_ok (csrc/winograd2d.hip)."""
-    return (WINO2D and 4 <= W <= 64 and not (W & (W - 1)) and not (H & 1) and not any(c % 8 for c in C_sources)
+    return (WINO2D and 4 <= W <= 256 and not (W & (W - 1)) and not (H & 1) and not any(c % 8 for c in C_sources)
             and sum(C_sources) >= 8 and M >= 16)
 
 
@@ -449,7 +449,9 @@ def _wino2d_name(p):
     wgs = -(-p.NPIX // 128) * -(-p.M // 64) * max(int(p.ksplit), 1)
     forced = os.environ.get('DP_WINO2D_VARIANT')
     v = int(forced) if forced not in (None, '') else (1 if (p.ksplit <= 1 and wgs > 512) else 0)
-    return 'conv_wino2d_kernel<4, 3>' if v == 1 else 'conv_wino2d_kernel<8, 2>'
+    if p.g.Wo > 64:
+        return 'conv_wino2d_kernel<4, 2, true>'          # 2 x 64-pixel segments (images wider than 64 pixels)
+    return 'conv_wino2d_kernel<4, 3, false>' if v == 1 else 'conv_wino2d_kernel<8, 2, false>'
 
 
 # ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------

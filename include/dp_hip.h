@@ -85,7 +85,8 @@ int dp_pack_weight_wino(const float* W, int Co, int Ci, int mode, float* dst, in
  * dp_conv_wino (diffusers/models/resnet.py:606,630 and their input gradients; ldm/modules/diffusionmodules/openaimodel.py:214-232).
  * Same parameter block, epilogue operands and split-K contract; A is dp_pack_weight_wino2d's operand U[(pos*K + k)][lda],
  * pos = 4 i + j of U = G g G^T (dst holds 16 * K * ld floats; mode 0 forward, mode 1 input gradient with both tap axes flipped).
- * Takes W a power of two in 4..64, H even, channel counts per concat source in multiples of 8, even image strides. */
+ * Takes W a power of two in 4..256 (beyond 64 pixels a block is a 2-row x 64-column segment with a halo tile), H even, channel counts
+ * per concat source in multiples of 8, even image strides. */
 int dp_conv_wino2d(const dp_conv_gemm_params* p, void* stream);
 int dp_conv_wino2d_supported(const dp_conv_gemm_params* p);
 int dp_pack_weight_wino2d(const float* W, int Co, int Ci, int mode, float* dst, int ld, void* stream);

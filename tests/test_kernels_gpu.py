@@ -1205,12 +1205,14 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
                                              (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (3, 128, 0, 64, 8),
-                                             (1, 8, 0, 16, 4), (2, 256, 0, 128, (6, 16))], ids=str)
+                                             (1, 8, 0, 16, 4), (2, 256, 0, 128, (6, 16)), (1, 32, 0, 48, 256), (2, 16, 8, 64, 128), (3, 8, 0, 16, (4, 128)),
+                                             (1, 128, 0, 128, 128)], ids=str)
 def test_conv_winograd_f2x2_3x3_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_conv_wino2d (3x3 / stride 1 / pad 1 as a TWO-dimensional Winograd F(2x2, 3x3) implicit GEMM, csrc/winograd2d.hip) against the
     fp64 convolution: forward (two concat sources, bias, per-image addend, residual, scale; accumulate) and input gradient, next to
     the direct and the F(2, 3) kernels' errors on the same inputs; output-channel tails (40, 70 rows in 64-row tiles); pixel blocks
-    that span several images (8 x 8, 4 x 4), partial last blocks (3 x 64 pixels, 1 x 16), non-square images; split-K; run-to-run bits."""
+    that span several images (8 x 8, 4 x 4), partial last blocks (3 x 64 pixels, 1 x 16), non-square images; images wider than 64 pixels (2 x 64-pixel segments with a halo tile: 128 and
+    256 columns, segment borders inside the image and on it); split-K; run-to-run bits."""
     monkeypatch.setattr(ops, 'WINO_MIN_TILES', 0)
     monkeypatch.setattr(ops, 'WINO2D_MIN_TILES', 0)
     Hh, Ww = H if isinstance(H, tuple) else (H, H)

@@ -28,11 +28,13 @@ def err(y, ref):
 
 
 shapes = [(128, 0, 128, 32), (256, 0, 256, 16), (256, 0, 256, 8), (128, 128, 128, 32), (256, 256, 256, 16), (256, 0, 256, 4), (96, 0, 96, 32),
-          (192, 0, 192, 16), (128, 0, 256, 16), (384, 0, 384, 32), (64, 0, 64, 64)]
+          (192, 0, 192, 16), (128, 0, 256, 16), (384, 0, 384, 32), (64, 0, 64, 64), (128, 0, 128, 256), (128, 0, 128, 128), (256, 0, 256, 64),
+          (128, 128, 128, 256)]
 print('shape                      direct ms   F(2,3) ms (ref-eq TF/s)   F(2x2,3x3) ms (ref-eq TF/s, executed TF/s)   2-D vs 1-D   err direct / 1-D / 2-D vs fp64')
 for (ci, c2, co, h) in shapes:
     bb = B if ci < 384 else 12
     if h == 64: bb = min(bb, 64)
+    if h >= 128: bb = 4                            # bedroom-256 at 4 images per GPU
     dev = torch.device('cuda')
     x = ops.empty_act((bb, ci, h, h), dev).normal_()
     x2 = ops.empty_act((bb, c2, h, h), dev).normal_() if c2 else None
