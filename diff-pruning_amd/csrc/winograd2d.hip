@@ -61,7 +61,7 @@ template <int W2_BK, int OCC, bool SEG>
 __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
     constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB at BK = 8)
     constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][4 patch rows][tile row][W] floats, tile rows x W = 64 (8 KB at BK = 8)
-    constexpr int W2_H_SZ = SEG ? W2_BK * 32 : 0;  // halo columns of a segment: [k][patch row][left | right][4 floats]
+    constexpr int W2_H_SZ = SEG ? 256 : 0;         // halo columns of a segment: [k][patch row][left | right][4 floats], one wave instruction
     constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ + W2_H_SZ;
     // the epilogue's exchange buffer reuses this memory: 64 KB at once when the K loop's buffers hold it, else 32 KB in two passes
     __shared__ __attribute__((aligned(16))) float smem[(2 * W2_STAGE > 8192) ? 2 * W2_STAGE : 8192];
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     }
     // ---- halo loader (segments): chunk e = tid < 8 BK of [k][patch row][side]: the 4 pixels left of / right of the segment
     unsigned h_voff1 = DPW2_OOB, h_voff2 = DPW2_OOB;
-    if (SEG && tid < 8 * W2_BK) {
-        const int k = tid >> 3, r = (tid >> 1) & 3, side = tid & 1;
+    if (SEG && lane < 8 * W2_BK) {
+        const int k = lane >> 3, r = (lane >> 1) & 3, side = lane & 1;
         const int img = row0 / H, y = row0 - img * H + r - 1;
         const int col = side ? x0 + 64 : x0 - 4;
         const bool v = row0 < rows_all && (unsigned)y < (unsigned)H && (unsigned)col < (unsigned)W;      // outside the image: zeros
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
             __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(ldsB + buf * W2_STAGE + 1024 * j), 16, (int)o,
                                                      (int)b_soff, 0, 0);
         }
-        if (SEG && wave == 0) {
-            if (lane < 8 * W2_BK) {
-                unsigned o = first ? h_voff1 : h_voff2;
-                asm volatile("" : "+v"(o));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(smem + W2_A_SZ + W2_B_SZ + buf * W2_STAGE), 16,
-                                                         (int)o, (int)b_soff, 0, 0);
-            }
+        if (SEG) {
+            // branch-free: every wavefront issues the same 64-lane load (lanes >= 8 BK are out of range and zero the padding of the
+            // halo tile; the four copies write the same bytes) -- an exec-masked or one-wavefront load would split the K loop's block
+            unsigned o = first ? h_voff1 : h_voff2;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? r1 : r2, (dpw2_lds_void*)(smem + W2_A_SZ + W2_B_SZ + buf * W2_STAGE), 16,
+                                                     (int)o, (int)b_soff, 0, 0);
         }
     };
 
