@@ -97,6 +97,8 @@ SIGNATURES = {
     'dp_conv_wino43_supported': [C.POINTER(ConvGemmParams)],
     'dp_pack_weight_wino43': [_vp, _i, _i, _vp, _i, _vp],
     'dp_wgrad_wino': [C.POINTER(NtGemmParams), _vp],
+    'dp_wgrad_wino2d': [C.POINTER(NtGemmParams), _vp],
+    'dp_wgrad_wino2d_supported': [C.POINTER(NtGemmParams)],
     'dp_wgrad_wino_supported': [C.POINTER(NtGemmParams)],
     'dp_nt_gemm': [C.POINTER(NtGemmParams), _vp],
     'dp_splitk_reduce': [_vp, _ll, _i, _vp, _ll, _i, _vp],

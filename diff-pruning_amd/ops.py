@@ -759,6 +759,52 @@ WGRAD_WINO_MIN_FILL = float(os.environ.get('DP_WGRAD_WINO_MIN_FILL', '0.7'))
 WGRAD_WINO_MIN_WORK = int(os.environ.get('DP_WGRAD_WINO_MIN_WORK', '512'))      # (64x64 tiles x 3 kernel rows) x (pixels / 1024)
 
 
+WGRAD_WINO2D = os.environ.get('DP_WGRAD_WINO2D', '1') not in ('0', '')
+WGRAD_WINO2D_MIN_FILL = float(os.environ.get('DP_WGRAD_WINO2D_MIN_FILL', '0.7'))     # Cout x Cin against its 64 x 32 tiles
+
+
+def _conv_wgrad_wino2d(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
+    """3x3 / stride 1 / pad 1 weight gradient on the two-dimensional transposed Winograd F(3x3, 2x2) kernel (csrc/wgrad2d.hip): 4/9 of the
+    direct multiplies, 2/3 of _conv_wgrad_wino's.  Same tap-major split-K partials and reduction launch.  None = the kernel does not
+    take the shape (W in {8, 16, 32}, H even, H*W a power of two >= 64, concat boundary on a multiple of 32 channels)."""
+    N, Cout, Ho, Wo = dy.shape
+    C1 = x.shape[1]
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    P = N * Ho * Wo
+    if Wo not in (8, 16, 32) or (Ho & 1) or ((Ho * Wo) & (Ho * Wo - 1)) or Ho * Wo < 64 or (x2 is not None and C1 % 32):
+        return None
+    p = L.NtGemmParams()
+    p.A, p.a_bs, p.a_img_stride = _p(dy), 0, sd
+    p.X1, p.X2, p.x_bs = _p(x), _p(x2), 0
+    p.a_bytes, p.x1_bytes, p.x2_bytes = _extent_bytes(dy), _extent_bytes(x), _extent_bytes(x2)
+    p.g = _geom(Ho, Wo, Ho, Wo, Ho, Wo, 3, 1, 1, 1, 1, 0, C1 if x2 is not None else Cin, s1, s2)
+    p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, 9, P
+    tiles = -(-Cout // 64) * (-(-C1 // 32) + (-(-(Cin - C1) // 32) if x2 is not None else 0))
+    nt = P // 64                                       # K tiles of 16 tiles = 64 pixels
+    splits = max(1, min(WGRAD_BLOCKS // tiles, nt // 4))
+    tps = -(-nt // splits)
+    splits = -(-nt // tps)
+    p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 64, 0, 0
+    p.alpha = alpha
+    p.ldo = Cin * 9
+    if not _lib().dp_wgrad_wino2d_supported(C.byref(p)):
+        return None
+    flops = 2.0 * Cout * Cin * 4 * P
+    name = 'wgrad_wino2d_kernel<%d>' % {8: 3, 16: 4, 32: 5}[Wo]
+    if splits == 1:
+        p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
+        L.check(_run(lambda: _lib().dp_wgrad_wino2d(C.byref(p), _stream()), name, flops), 'dp_wgrad_wino2d')
+    else:
+        n = Cout * Cin * 9
+        ws = _workspace(splits * n, dy.device)
+        p.out, p.o_bs, p.accumulate = _p(ws), n, 0
+        p.ldo, p.o_col_stride, p.o_tap_stride = Cin, 1, Cout * Cin          # tap-major partials [split][tap][Cout][Cin]
+        L.check(_run(lambda: _lib().dp_wgrad_wino2d(C.byref(p), _stream()), name, flops), 'dp_wgrad_wino2d')
+        L.check(_lib().dp_splitk_reduce_taps(_p(ws), n, splits, _p(gw), Cout * Cin, 9, 1 if accumulate else 0, _stream()),
+                'dp_splitk_reduce_taps')
+    return gw
+
+
 def _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     """3x3 / stride 1 / pad 1 weight gradient on the transposed Winograd F(2, 3) kernel (csrc/winograd.hip): 2/3 of the multiplies.
     Same split-K partials and reduction launch as the direct form.  None = the kernel does not take the shape."""
@@ -829,7 +875,11 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
             # is then slower than the direct kernel's 96 x 96 tile [measured 0.90x]
             and Cout * Cin >= WGRAD_WINO_MIN_FILL * min((-(-Cout // 64) * 64) * (-(-Cin // 64) * 64),
                                                         (-(-Cout // 96) * 96) * (-(-Cin // 96) * 96))):
-        r = _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
+        r = None
+        if WINO2D and WGRAD_WINO2D and P % 64 == 0 and Cout * Cin >= WGRAD_WINO2D_MIN_FILL * (-(-Cout // 64) * 64) * (-(-Cin // 32) * 32):
+            r = _conv_wgrad_wino2d(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
+        if r is None:
+            r = _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
         if r is not None:
             return r
     # big tiles + split-K over the pixels: the 128x128 tile has the best MFMA efficiency and the pixel dimension

@@ -139,6 +139,15 @@ int dp_nt_gemm(const dp_nt_gemm_params* p, void* stream);
 int dp_wgrad_wino(const dp_nt_gemm_params* p, void* stream);
 int dp_wgrad_wino_supported(const dp_nt_gemm_params* p);
 
+/* The same weight gradient by the TWO-dimensional transposed algorithm F(3x3, 2x2) (csrc/wgrad2d.hip, round 6): 16 multiplies per
+ * (2x2 block of output gradients, m, c) instead of 36 -- 2/3 of dp_wgrad_wino's.  One workgroup = a 64 x 32 (m, c) tile of all 16
+ * position matrices over a range of 64-pixel K tiles; the nine taps are folded out of the positions in the epilogue and written as
+ * the same tap-major split-K partials (dp_splitk_reduce_taps).  Parameter block as for dp_wgrad_wino; splits * p_per_split must cover
+ * P, counted in 64-pixel tiles.  Shapes: W in {8, 16, 32}, H even, H*W a power of two >= 64, P % 64 == 0, c_split % 32 == 0 with two
+ * sources.  Replaces the same ConvolutionBackward weight gradients (diffusers/models/resnet.py:606,630). */
+int dp_wgrad_wino2d(const dp_nt_gemm_params* p, void* stream);
+int dp_wgrad_wino2d_supported(const dp_nt_gemm_params* p);
+
 /* out[i] (+)= sum_s ws[s*stride + i], fixed summation order (deterministic split-K epilogue). */
 int dp_splitk_reduce(const float* ws, long long stride, int splits, float* out, long long n, int accumulate, void* stream);
 /* same for tap-major partials ws[s][tap][mc] -> out[mc][ntaps] (the torch weight layout) */

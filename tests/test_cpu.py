@@ -2064,7 +2064,7 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
         pytest.skip('hipcc not available')
     csrc = os.path.join(ROOT, 'diff-pruning_amd', 'csrc')
     want = {'gemm.hip': ('conv_gemm_fast_kernel', 'nt_gemm_fast_kernel'), 'winograd.hip': ('conv_wino_kernel', 'wgrad_wino_kernel'),
-            'winograd43.hip': ('conv_wino43_kernel',), 'winograd2d.hip': ('conv_wino2d_kernel',)}
+            'winograd43.hip': ('conv_wino43_kernel',), 'winograd2d.hip': ('conv_wino2d_kernel',), 'wgrad2d.hip': ('wgrad_wino2d_kernel',)}
     checked = 0
     for src, kernels in want.items():
         out = str(tmp_path / (src + '.s'))
@@ -2106,7 +2106,7 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
                 assert not bad, (fname, 'compiler-inserted s_waitcnt vmcnt(0) between the barrier and the hand-placed wait of a K tile', bad)
                 assert not any('scratch_' in t for t in seg), (fname, 'scratch access inside the K loop')
                 checked += 1
-    assert checked >= 11, checked            # 6 fast-conv + 4 fast-wgrad + 5 Winograd-conv + 2 Winograd-wgrad + 1 F(2x2, 3x3) instantiations
+    assert checked >= 14, checked            # 6 fast-conv + 4 fast-wgrad + 5 Winograd-conv + 2 Winograd-wgrad + 1 F(2x2, 3x3) instantiations
 
 
 def test_winograd_refuses_activations_within_a_row_of_2gib():
@@ -2246,12 +2246,12 @@ def test_lsun_ffhq_lmdb_datasets(tmp_path):
 
 def test_committed_pmc_traffic_was_measured_on_these_kernel_sources():
     """`roofline.traffic` on the bench line comes from committed rocprofv3 --pmc passes (they cannot run inside bench.py): the newest
-    file of every config must carry the hash of TODAY's contraction-kernel sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip) and its own
+    file of every config must carry the hash of TODAY's contraction-kernel sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip + csrc/wgrad2d.hip) and its own
     config name, or bench.py reports `traffic: null` (bench._pmc_traffic) -- this test makes a stale file a red CPU suite, not a silent null."""
     import glob
     import hashlib
     import json
-    src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip'))
+    src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'wgrad2d.hip'))
     blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
     for sfx, cfg in (('', 'cifar256'), ('_c4_finetune', 'c4_finetune'), ('_ldm', 'ldm')):
         cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))

@@ -1564,9 +1564,14 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, flavou
     monkeypatch.setattr(ops, 'WINO2D', flavour == 'f2x2_3x3')
     monkeypatch.setattr(ops, 'WINO2D_MIN_TILES', 0)
     monkeypatch.setattr(ops, 'WINO2D_MIN_FILL', 0.0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO2D', flavour == 'f2x2_3x3')   # ... and the two-dimensional weight-gradient kernel (csrc/wgrad2d.hip)
+    monkeypatch.setattr(ops, 'WGRAD_WINO2D_MIN_FILL', 0.0)
     nw = [0]
     real_w = ops._conv_wgrad_wino
     monkeypatch.setattr(ops, '_conv_wgrad_wino', lambda *a: (lambda r: (nw.__setitem__(0, nw[0] + (r is not None)), r)[1])(real_w(*a)))
+    nw2 = [0]
+    real_w2 = ops._conv_wgrad_wino2d
+    monkeypatch.setattr(ops, '_conv_wgrad_wino2d', lambda *a: (lambda r: (nw2.__setitem__(0, nw2[0] + (r is not None)), r)[1])(real_w2(*a)))
     n = [0]
     real = ops._conv_wino
     monkeypatch.setattr(ops, '_conv_wino', lambda *a: (lambda r: (n.__setitem__(0, n[0] + bool(r)), r)[1])(real(*a)))
@@ -1586,9 +1591,12 @@ def test_reference_fixtures_with_winograd_on_every_supported_layer(which, flavou
      'ddpm': test_ddpm_sampling_matches_reference,
      'criteria': lambda rep: [test_sibling_criteria_masks_bit_exact(rep, c) for c in ('full1', 'full2', 'abs', 'fisher', 'magnitude')],
      }[which](sub)
-    report['wino_forced/%s/%s' % (flavour, which)] = dict(sub, winograd_launches=n[0], winograd_2d_launches=n2[0], winograd_wgrad_launches=nw[0])
-    assert n[0] > 0 and (nw[0] > 0 or which in ('tiny_forward', 'ddim', 'ddpm'))
+    report['wino_forced/%s/%s' % (flavour, which)] = dict(sub, winograd_launches=n[0], winograd_2d_launches=n2[0], winograd_wgrad_launches=nw[0],
+                                                          winograd_2d_wgrad_launches=nw2[0])
+    no_backward = which in ('tiny_forward', 'ddim', 'ddpm')
+    assert n[0] > 0 and (nw[0] + nw2[0] > 0 or no_backward)
     assert (n2[0] > 0) == (flavour == 'f2x2_3x3'), (flavour, n2[0])
+    assert (nw2[0] > 0) == (flavour == 'f2x2_3x3' and not no_backward), (flavour, nw2[0])
 
 
 @pytest.mark.parametrize('overlap', [False, True], ids=['one_stream', 'wgrad_side_stream'])

@@ -1268,6 +1268,7 @@ def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, C
     pixels width, accumulation into an existing gradient, several split counts; run-to-run bit-identical."""
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)
     monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO2D', False)                    # (the two-dimensional kernel has its own test below)
     xa, xb = rnd(N, C1, H, H, seed=1), (rnd(N, C2, H, H, seed=2) if C2 else None)
     dy = rnd(N, Cout, H, H, seed=5)
     spec = ops.ConvSpec(3, 1, 1, 0)
@@ -1292,3 +1293,52 @@ def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, C
     report['wgrad/winograd_f23/%d_%d_%d_%d' % (N, C1 + C2, Cout, H)] = dict(wino=e_w, direct=e_d, run_to_run_equal=bool(torch.equal(gw, gw2)))
     assert torch.equal(gw, gw2)
     assert e_w < 5e-6, (e_w, e_d)
+
+
+@pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 192, 8),
+                                             (8, 40, 0, 70, 16), (8, 96, 0, 96, 32), (4, 192, 96, 96, 16), (4, 179, 0, 90, 16), (1, 8, 0, 16, 8),
+                                             (3, 32, 32, 24, (16, 32)), (2, 64, 0, 64, (32, 8))], ids=str)
+def test_conv_wgrad_winograd_f3x3_2x2_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
+    """dp_wgrad_wino2d (3x3 / stride 1 / pad 1 weight gradient by the TWO-dimensional transposed Winograd algorithm F(3x3, 2x2),
+    csrc/wgrad2d.hip) against the fp64 weight gradient, next to the F(3, 2) and the direct kernels' errors: two concat sources (boundary
+    on a multiple of 32), row / column tails (96, 70, 90, 40, 179 channels in 64 x 32 tiles), images of 8, 16 and 32 pixels width incl.
+    non-square ones, a single 64-pixel K tile, accumulation into an existing gradient, several split counts; run-to-run bits."""
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_WORK', 0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO_MIN_FILL', 0.0)
+    monkeypatch.setattr(ops, 'WGRAD_WINO2D_MIN_FILL', 0.0)
+    Hh, Ww = H if isinstance(H, tuple) else (H, H)
+    xa, xb = rnd(N, C1, Hh, Ww, seed=1), (rnd(N, C2, Hh, Ww, seed=2) if C2 else None)
+    dy = rnd(N, Cout, Hh, Ww, seed=5)
+    spec = ops.ConvSpec(3, 1, 1, 0)
+    x = torch.cat([xa, xb], 1) if C2 else xa
+    wz = torch.zeros(Cout, C1 + C2, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double().cpu(), wz, None, padding=1).backward(dy.double().cpu())
+    ref = 0.5 * wz.grad
+    used = []
+    real = ops._conv_wgrad_wino2d
+    monkeypatch.setattr(ops, '_conv_wgrad_wino2d', lambda *a: (lambda r: (used.append(r is not None), r)[1])(real(*a)))
+    g0 = rnd(Cout, C1 + C2, 3, 3, seed=9)
+    gw = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gw, spec, alpha=0.5, accumulate=True)
+    gw2 = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gw2, spec, alpha=0.5, accumulate=True)
+    assert used == [True, True], used
+    # other split counts (the default aims at ~1024 workgroups): one slice, and as many as there are K tiles
+    e_split = {}
+    for blocks in (1, 1 << 20):
+        monkeypatch.setattr(ops, 'WGRAD_BLOCKS', blocks)
+        gs = g0.clone()
+        ops.conv_wgrad(dy, xa, xb, gs, spec, alpha=0.5, accumulate=True)
+        e_split[blocks] = relerr(gs - g0, ref)
+    monkeypatch.setattr(ops, 'WGRAD_BLOCKS', 1024)
+    monkeypatch.setattr(ops, 'WGRAD_WINO2D', False)
+    g1 = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, g1, spec, alpha=0.5, accumulate=True)
+    monkeypatch.setattr(ops, 'WGRAD_WINO', False)
+    gd = g0.clone()
+    ops.conv_wgrad(dy, xa, xb, gd, spec, alpha=0.5, accumulate=True)
+    e_w, e_1, e_d = relerr(gw - g0, ref), relerr(g1 - g0, ref), relerr(gd - g0, ref)
+    report['wgrad/winograd_f3x3_2x2/%d_%d_%d_%s' % (N, C1 + C2, Cout, H)] = dict(wino2d=e_w, wino1d=e_1, direct=e_d, splits=e_split,
+                                                                             run_to_run_equal=bool(torch.equal(gw, gw2)))
+    assert torch.equal(gw, gw2)
+    assert e_w < 5e-6 and max(e_split.values()) < 5e-6, (e_w, e_split, e_1, e_d)
