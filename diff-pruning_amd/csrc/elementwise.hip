@@ -957,6 +957,34 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch 
     while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
     const dp_pack_item& it = b.it[i];
     const long long step = (long long)it.nblk * 256;
+    if (it.mode >= 4) {      // Winograd F(2x2, 3x3) operand of a 3x3 weight (same element map and arithmetic as pack_weight_wino2d_kernel, winograd2d.hip)
+        const int wm = it.mode - 4;
+        const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
+        const long long total = 16ll * K * it.ld;
+        for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
+            const int m = (int)(e % it.ld);
+            const long long rk = e / it.ld;
+            const int k = (int)(rk % K);
+            const int pos = (int)(rk / K);
+            const int i = pos >> 2, j = pos & 3;
+            float v = 0.f;
+            if (m < Mv) {
+                const float* w = wm == 0 ? it.W + ((long long)m * it.Ci + k) * 9 : it.W + ((long long)k * it.Ci + m) * 9;
+                float gg[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gg[a][c] = wm == 0 ? w[a * 3 + c] : w[(2 - a) * 3 + (2 - c)];
+                float t[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    t[c] = i == 0 ? gg[0][c] : i == 1 ? ((gg[0][c] + gg[1][c]) + gg[2][c]) * 0.5f : i == 2 ? ((gg[0][c] - gg[1][c]) + gg[2][c]) * 0.5f : gg[2][c];
+                v = j == 0 ? t[0] : j == 1 ? ((t[0] + t[1]) + t[2]) * 0.5f : j == 2 ? ((t[0] - t[1]) + t[2]) * 0.5f : t[2];
+            }
+            it.dst[e] = v;
+        }
+        return;
+    }
     if (it.mode >= 2) {      // Winograd F(2, 3) operand of a 3x3 weight (same element map as pack_weight_wino_kernel, winograd.hip)
         const int wm = it.mode - 2;
         const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
@@ -1001,9 +1029,9 @@ extern "C" int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stre
         for (int i = 0; i < b.n; ++i) {
             b.it[i] = items[lo + i];
             dp_pack_item& it = b.it[i];
-            if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || it.mode < 0 || it.mode > 3) return (int)hipErrorInvalidValue;
+            if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || it.mode < 0 || it.mode > 5) return (int)hipErrorInvalidValue;
             if (it.mode >= 2 && it.taps != 9) return (int)hipErrorInvalidValue;
-            const long long total = (long long)(it.mode >= 2 ? 12 : it.taps) * ((it.mode & 1) == 0 ? it.Ci : it.Co) * it.ld;
+            const long long total = (long long)(it.mode >= 4 ? 16 : it.mode >= 2 ? 12 : it.taps) * ((it.mode & 1) == 0 ? it.Ci : it.Co) * it.ld;
             long long nb = (total + 1023) / 1024;
             if (nb > 512) nb = 512;
             it.blk0 = blocks;

@@ -25,8 +25,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dpg2_rsrc(const float* base, u
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, DPG2_RSRC_FLAGS);
 }
 
-template <int LW>
-__global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const dp_nt_gemm_params p) {
+// TAIL (M % 64 in 1 .. 32, e.g. the pruned models' 96-wide layers): the workgroups of the last row tile have no second row block of
+// output channels -- they run the K loop without its dy fragments, transforms and MFMAs.
+template <int LW, bool TAIL>
+__device__ __forceinline__ void wgrad_wino2d_body(const dp_nt_gemm_params& p) {
     constexpr int W = 1 << LW, TC = W / 2, LTC = LW - 1;
     constexpr int PA = 68;                             // floats per dy row in LDS: 64 pixels + 4
     constexpr int NXC = 16 + W / 2;                    // 16-byte chunks of an input row: 64 + 2 W pixels
@@ -121,61 +123,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const dp_nt_gemm_p
         dma_tile(t0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int it = 0; it < nIter; ++it) {
-            const int buf = it & 1;
-            const float* Af = fragA + buf * STAGE;
-            const float* Bf = fragB + buf * STAGE + ra * W;
-            const float* Bg = fragB + buf * STAGE + rb * W;
-            float fa[2][8], fb[2][8];
-            auto frag = [&](int ks, float (&xa)[8], float (&xb)[8]) {
-                const int tr = (2 * ks) >> LTC, tc0 = (2 * ks) & (TC - 1);           // (lk adds 1 to the tile column: 2 lk floats)
-                const int oa = 2 * tr * W + 2 * tc0;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    xa[4 * t + 0] = Af[32 * t * PA + oa];
-                    xa[4 * t + 1] = Af[32 * t * PA + oa + 1];
-                    xa[4 * t + 2] = Af[32 * t * PA + oa + W];
-                    xa[4 * t + 3] = Af[32 * t * PA + oa + W + 1];
-                }
-                const int ob = 2 * tr * W + 2 * tc0 - 1;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    xb[x] = Bf[ob + x];
-                    xb[4 + x] = Bg[ob + x];
-                }
-            };
-            float ua[2][8], ub[2][4];
-            auto xform = [&](int ks, const float (&xa)[8], const float (&xb)[8], float (&oa)[8], float (&ob)[4]) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float r0 = fmaf(s1, xa[4 * t + 2], s0 * xa[4 * t + 0]);
-                    const float r1 = fmaf(s1, xa[4 * t + 3], s0 * xa[4 * t + 1]);
-                    oa[4 * t + 0] = r0; oa[4 * t + 1] = r0 + r1; oa[4 * t + 2] = r0 - r1; oa[4 * t + 3] = -r1;
-                }
-                float c0 = fmaf(sgn, xb[4], xb[0]), c1 = fmaf(sgn, xb[5], xb[1]), c2 = fmaf(sgn, xb[6], xb[2]), c3 = fmaf(sgn, xb[7], xb[3]);
-                // horizontal zero padding: tile column 0 (its column -1) / TC - 1 (its column W) of an image row
-                if (((2 * ks) & (TC - 1)) == 0) c0 = lk0 ? 0.f : c0;
-                if (((2 * ks + 1) & (TC - 1)) == TC - 1) c3 = lk1 ? 0.f : c3;
-                ob[0] = c0 - c2; ob[1] = c1 + c2; ob[2] = c2 - c1; ob[3] = c1 - c3;
-            };
-            frag(0, fa[0], fb[0]);
-            xform(0, fa[0], fb[0], ua[0], ub[0]);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const int cur = ks & 1;
-                if (ks + 1 < 8) frag(ks + 1, fa[cur ^ 1], fb[cur ^ 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[cur][4 * t + j], ub[cur][j], acc[j][t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < 8) { xform(ks + 1, fa[cur ^ 1], fb[cur ^ 1], ua[cur ^ 1], ub[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
-                if (ks == 1) { dma_tile(t0 + (it + 1 < nIter ? it + 1 : it), buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        if (TAIL && m0 + 32 >= p.M) {
+#define G2_NT 1
+#include "wgrad2d_kloop.inc"
+#undef G2_NT
+        } else {
+#define G2_NT 2
+#include "wgrad2d_kloop.inc"
+#undef G2_NT
         }
     }
 
@@ -226,6 +181,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const dp_nt_gemm_p
     }
 }
 
+template <int LW>
+__global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const dp_nt_gemm_params p) {
+    wgrad_wino2d_body<LW, false>(p);
+}
+template <int LW>
+__global__ __launch_bounds__(256, 2) void wgrad_wino2d_tail_kernel(const dp_nt_gemm_params p) {
+    wgrad_wino2d_body<LW, true>(p);
+}
+
 // Shapes: 3x3 / stride 1 / pad 1, W in {8, 16, 32}, H even, H*W a power of two >= 64 (a K tile of 64 pixels never leaves its image and
 // starts on an even image row), P and p_per_split multiples of 64, a concat boundary on a multiple of 32 channels.
 static bool wgrad_wino2d_ok(const dp_nt_gemm_params& p) {
@@ -251,6 +215,14 @@ extern "C" int dp_wgrad_wino2d(const dp_nt_gemm_params* pp, void* stream) {
     const int C1 = p.X2 ? p.g.c_split : p.NCOLS;
     dim3 grid((C1 + 31) / 32 + (p.X2 ? (p.NCOLS - C1 + 31) / 32 : 0), (p.M + 63) / 64, p.splits);
     hipStream_t st = (hipStream_t)stream;
+    static const bool tail_off = [] { const char* e = getenv("DP_WINO2D_TAIL"); return e && atoi(e) == 0; }();
+    const bool tail = !tail_off && (p.M & 63) >= 1 && (p.M & 63) <= 32;       // the last row tile holds one row block only
+    if (tail) {
+        if (p.g.Wo == 32)      DP_LAUNCH((wgrad_wino2d_tail_kernel<5>), grid, dim3(256), 0, st, p);
+        else if (p.g.Wo == 16) DP_LAUNCH((wgrad_wino2d_tail_kernel<4>), grid, dim3(256), 0, st, p);
+        else                   DP_LAUNCH((wgrad_wino2d_tail_kernel<3>), grid, dim3(256), 0, st, p);
+        return DP_LAUNCH_CHECK();
+    }
     if (p.g.Wo == 32)      DP_LAUNCH((wgrad_wino2d_kernel<5>), grid, dim3(256), 0, st, p);
     else if (p.g.Wo == 16) DP_LAUNCH((wgrad_wino2d_kernel<4>), grid, dim3(256), 0, st, p);
     else                   DP_LAUNCH((wgrad_wino2d_kernel<3>), grid, dim3(256), 0, st, p);

@@ -57,8 +57,10 @@ constexpr int W2_BT = 32;                      // 2x2 tiles per workgroup (128 o
 // three workgroups per CU when the registers allow it)
 // SEG (images wider than 64 pixels): a block is ONE tile row of 32 tiles = a 2-row x 64-column segment; the two halo columns of its
 // 4-row patch belong to the neighbouring segments (or are the image border) and come through a small extra tile [k][patch row][side][4].
-template <int W2_BK, int OCC, bool SEG>
-__global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
+// TAIL (M % 64 in 1 .. 32, e.g. the pruned models' 96-wide layers): the workgroups of the last row tile have no second row block --
+// they run the K loop without its MFMAs and A fragments (half the matrix work of that tile instead of multiplying zeros).
+template <int W2_BK, int OCC, bool SEG, bool TAIL>
+__device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
     constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB at BK = 8)
     constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][4 patch rows][tile row][W] floats, tile rows x W = 64 (8 KB at BK = 8)
     constexpr int W2_H_SZ = SEG ? 256 : 0;         // halo columns of a segment: [k][patch row][left | right][4 floats], one wave instruction
@@ -197,69 +199,14 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    for (int it = 0; it < nIter; ++it) {
-        const int buf = it & 1;
-        const int ch_next = (it + 1 < nIter) ? ch + 1 : ch;
-        const float* Af = fragA + buf * W2_STAGE;
-        const float* B1 = fragB1 + buf * W2_STAGE;
-        const float* B2 = fragB2 + buf * W2_STAGE;
-        float a[2][8], v[2][4], hh[2][4];
-        float2 d[2][2];
-        const float* Hf = fragH + buf * W2_STAGE;
-        const unsigned b1a = dpw2_lds_addr(B1), b2a = dpw2_lds_addr(B2);
-        auto frag = [&](int ks, float (&fa)[8], float2 (&fd)[2], float (&fh)[4]) {
-            // the tile's own two columns of the two patch rows (8-byte reads, conflict-free); columns -1 and +2 are the neighbouring
-            // tiles' columns 1 and 0 and come from the neighbouring LANES in xform (the lanes at the ends of an image row take the
-            // zero padding instead)
-            switch (ks) {
-                case 0:  fd[0] = dpw2_lds_read_b64<0>(b1a);    fd[1] = dpw2_lds_read_b64<0>(b2a);    break;
-                case 1:  fd[0] = dpw2_lds_read_b64<2048>(b1a); fd[1] = dpw2_lds_read_b64<2048>(b2a); break;
-                case 2:  fd[0] = dpw2_lds_read_b64<4096>(b1a); fd[1] = dpw2_lds_read_b64<4096>(b2a); break;
-                default: fd[0] = dpw2_lds_read_b64<6144>(b1a); fd[1] = dpw2_lds_read_b64<6144>(b2a); break;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) fa[2 * j + t] = Af[(j * W2_BK + 2 * ks) * W2_BM + 32 * t];
-            if (SEG) {                                   // (wave-uniform addresses per k half: broadcast reads)
-                fh[0] = Hf[2 * ks * 32 + (ra * 2 + 0) * 4 + 3];
-                fh[1] = Hf[2 * ks * 32 + (rb * 2 + 0) * 4 + 3];
-                fh[2] = Hf[2 * ks * 32 + (ra * 2 + 1) * 4];
-                fh[3] = Hf[2 * ks * 32 + (rb * 2 + 1) * 4];
-            }
-        };
-        auto xform = [&](float2 (&fd)[2], const float (&fh)[4], float (&fv)[4]) {
-            dpw2_lds_wait(fd[0], fd[1]);
-            const float c1 = fmaf(sgn, fd[1].x, fd[0].x), c2 = fmaf(sgn, fd[1].y, fd[0].y);
-            // wave_shr:1 / wave_shl:1: lane l takes lane l - 1's c2 (column 2 tc - 1) / lane l + 1's c1 (column 2 tc + 2)
-            float c0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x138, 0xf, 0xf, false));
-            float c3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x130, 0xf, 0xf, false));
-            // the block's first / last tile: the image border (zeros) or, in a segment, the neighbouring segment's column
-            c0 = pad_l ? (SEG ? fmaf(sgn, fh[1], fh[0]) : 0.f) : c0;
-            c3 = pad_r ? (SEG ? fmaf(sgn, fh[3], fh[2]) : 0.f) : c3;
-            fv[0] = c0 - c2; fv[1] = c1 + c2; fv[2] = c2 - c1; fv[3] = c1 - c3;
-        };
-        frag(0, a[0], d[0], hh[0]);
-        xform(d[0], hh[0], v[0]);
-#pragma unroll
-        for (int ks = 0; ks < W2_BK / 2; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < W2_BK / 2) frag(ks + 1, a[cur ^ 1], d[cur ^ 1], hh[cur ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2 * j + t], v[cur][j], acc[j][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < W2_BK / 2) { xform(d[cur ^ 1], hh[cur ^ 1], v[cur ^ 1]); __builtin_amdgcn_sched_barrier(0); }
-            // unconditional (the last K tile fetches itself once more into the idle buffer): a branch here moves the loads out of
-            // the loop body and in front of a compiler-placed wait
-            if (ks == 0) { dma_tile(buf ^ 1, ch_next); __builtin_amdgcn_sched_barrier(0); }
-        }
-        ch = ch_next;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    if (TAIL && m0 + 32 >= p.M) {
+#define W2_NT 1
+#include "winograd2d_kloop.inc"
+#undef W2_NT
+    } else {
+#define W2_NT 2
+#include "winograd2d_kloop.inc"
+#undef W2_NT
     }
 
     // ---- output transform.  Columns inside the wavefront: Z[i][0] = M[i][0] + M[i][1] + M[i][2], Z[i][1] = M[i][1] - M[i][2] - M[i][3];
@@ -379,6 +326,15 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
     }
 }
 
+template <int W2_BK, int OCC, bool SEG>
+__global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gemm_params p) {
+    conv_wino2d_body<W2_BK, OCC, SEG, false>(p);
+}
+template <int W2_BK, int OCC, bool SEG>
+__global__ __launch_bounds__(256, OCC) void conv_wino2d_tail_kernel(const dp_conv_gemm_params p) {
+    conv_wino2d_body<W2_BK, OCC, SEG, true>(p);
+}
+
 // Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 256 (128 output pixels = whole image rows of
 // whole tile rows up to 64 pixels; one 2 x 64 segment of a tile row beyond), H even, channel counts (per concat source) in multiples of 8, 8-byte aligned image planes.
 static bool wino2d_ok(const dp_conv_gemm_params& p) {
@@ -409,12 +365,18 @@ extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
     static const int forced = [] { const char* e = getenv("DP_WINO2D_VARIANT"); return e ? atoi(e) : -1; }();
     const long long wgs = (long long)grid.x * grid.y * grid.z;
     const int variant = forced >= 0 ? forced : ((p.ksplit <= 1 && wgs > 512) ? 1 : 0);     // 512 = one round of two per CU
+    static const bool tail_off = [] { const char* e = getenv("DP_WINO2D_TAIL"); return e && atoi(e) == 0; }();
+    const bool tail = !tail_off && (p.M & 63) >= 1 && (p.M & 63) <= 32;       // the last row tile holds one row block only
     if (p.g.Wo > 64) {                       // 2 x 64-pixel segments of two image rows: 4-channel K tiles (42 KB of LDS) at whatever
         (void)variant;                       // occupancy ~180 registers allow (the halo operands do not fit under the 168 of three per CU)
-        DP_LAUNCH((conv_wino2d_kernel<4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (tail) DP_LAUNCH((conv_wino2d_tail_kernel<4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else      DP_LAUNCH((conv_wino2d_kernel<4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else if (variant == 1) {
+        if (tail) DP_LAUNCH((conv_wino2d_tail_kernel<4, 3, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else      DP_LAUNCH((conv_wino2d_kernel<4, 3, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        if (variant == 1) DP_LAUNCH((conv_wino2d_kernel<4, 3, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else              DP_LAUNCH((conv_wino2d_kernel<8, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (tail) DP_LAUNCH((conv_wino2d_tail_kernel<8, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else      DP_LAUNCH((conv_wino2d_kernel<8, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     const int e = DP_LAUNCH_CHECK();
     if (e || p.ksplit <= 1) return e;

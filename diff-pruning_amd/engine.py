@@ -347,7 +347,7 @@ class UNetEngine:
                         continue
                     if not self.packs.has(name[:-7], w, mode):
                         if isinstance(mode, tuple) and mode[0] == 'wino2d' and not getattr(ops, 'PACK_BATCH_WINO2D', False):
-                            self.packs.get(name[:-7], w, mode)                     # one launch each (not part of the batched packer)
+                            self.packs.get(name[:-7], w, mode)                     # (a packer without modes 4 / 5: one launch each)
                         else:
                             todo.append((name[:-7], w, mode))
         if hasattr(ops, 'pack_weight_batch') and todo and all(w.is_contiguous() for _, w, _ in todo):

@@ -260,8 +260,8 @@ def pack_weight(w, mode):
 
 
 def pack_weight_batch(ws_modes):
-    """pack_weight (mode 0 / 1) or pack_weight_wino (mode ('wino', 0 | 1)) for a list of (weight, mode) in ceil(n / 64) launches;
-    returns [(packed, ld), ...] in order."""
+    """pack_weight (mode 0 / 1), pack_weight_wino (mode ('wino', 0 | 1)) or pack_weight_wino2d (mode ('wino2d', 0 | 1)) for a list of
+    (weight, mode) in ceil(n / 64) launches; returns [(packed, ld), ...] in order."""
     n = len(ws_modes)
     arr = (L.PackItem * n)()
     out = []
@@ -269,12 +269,14 @@ def pack_weight_batch(ws_modes):
         assert w.is_cuda and w.dtype == _f32 and w.is_contiguous(), 'pack_weight_batch takes contiguous fp32 device weights'
         Co, Ci = w.shape[0], w.shape[1]
         taps = w[0, 0].numel() if w.dim() == 4 else 1
-        wino = isinstance(mode, tuple)                     # ('wino', 0 | 1): the pack_weight_wino operand
+        wino = isinstance(mode, tuple)                     # ('wino' | 'wino2d', 0 | 1): the Winograd operands
+        assert not wino or mode[0] in ('wino', 'wino2d')
         m01 = mode[1] if wino else mode
         K = Ci if m01 == 0 else Co
         ld = roundup4(Co if m01 == 0 else Ci)
-        dst = torch.empty((12 if wino else taps) * K * ld, dtype=_f32, device=w.device)
-        a.W, a.dst, a.Co, a.Ci, a.taps, a.mode, a.ld = w.data_ptr(), dst.data_ptr(), Co, Ci, taps, (2 + m01 if wino else m01), ld
+        npos, base = (taps, 0) if not wino else (12, 2) if mode[0] == 'wino' else (16, 4)
+        dst = torch.empty(npos * K * ld, dtype=_f32, device=w.device)
+        a.W, a.dst, a.Co, a.Ci, a.taps, a.mode, a.ld = w.data_ptr(), dst.data_ptr(), Co, Ci, taps, base + m01, ld
         out.append((dst, ld))
     if n:
         L.check(_lib().dp_pack_weight_batch(arr, n, _stream()), 'dp_pack_weight_batch')
@@ -394,7 +396,7 @@ def wino2d_wanted(M, C_sources, N, H, W, spec):
         return False
     if not wino2d_shape_ok(M, C_sources, N, H, W):
         return False
-    if M / (-(-M // 64) * 64.0) < WINO2D_MIN_FILL:
+    if M / float(_wino2d_rows(M)) < WINO2D_MIN_FILL:
         return False
     tiles = -(-M // 64) * -(-(N * H * W) // 128)
     if tiles >= WINO2D_MIN_TILES:
@@ -402,6 +404,9 @@ def wino2d_wanted(M, C_sources, N, H, W, spec):
     n_iter = sum(C_sources) // 8
     ks = min(WINO2D_MIN_TILES // max(tiles, 1), n_iter // 8)
     return ks >= 2 and tiles * ks >= WINO2D_MIN_TILES // 2
+
+
+PACK_BATCH_WINO2D = os.environ.get('DP_PACK_BATCH_WINO2D', '1') != '0'     # dp_pack_weight_batch takes the F(2x2, 3x3) operands (modes 4 / 5)
 
 
 def pack_weight_wino2d(w, mode):
@@ -449,9 +454,22 @@ def _wino2d_name(p):
     wgs = -(-p.NPIX // 128) * -(-p.M // 64) * max(int(p.ksplit), 1)
     forced = os.environ.get('DP_WINO2D_VARIANT')
     v = int(forced) if forced not in (None, '') else (1 if (p.ksplit <= 1 and wgs > 512) else 0)
+    k = 'conv_wino2d_tail_kernel' if _wino2d_tail(p.M) else 'conv_wino2d_kernel'
     if p.g.Wo > 64:
-        return 'conv_wino2d_kernel<4, 2, true>'          # 2 x 64-pixel segments (images wider than 64 pixels)
-    return 'conv_wino2d_kernel<4, 3, false>' if v == 1 else 'conv_wino2d_kernel<8, 2, false>'
+        return k + '<4, 2, true>'                        # 2 x 64-pixel segments (images wider than 64 pixels)
+    return k + ('<4, 3, false>' if v == 1 else '<8, 2, false>')
+
+
+def _wino2d_tail(M):
+    """The launchers' rule (csrc/winograd2d.hip, csrc/wgrad2d.hip): the last 64-row tile holds one 32-row block only -> the `_tail`
+    instantiation, whose last-row-tile workgroups skip the empty block's MFMAs."""
+    return 1 <= (M & 63) <= 32 and os.environ.get('DP_WINO2D_TAIL', '1') not in ('0',)
+
+
+def _wino2d_rows(M):
+    """Row blocks of 32 output channels the F(2x2, 3x3) / F(3x3, 2x2) kernels multiply for M rows, in rows: whole 64-row tiles, the
+    last one counted as 32 when the tail instantiation skips its empty half."""
+    return -(-M // 64) * 64 - (32 if _wino2d_tail(M) else 0)
 
 
 # ---- Winograd F(4, 3) along W for the NO-GRAD forwards (csrc/winograd43.hip): half the multiplies; see include/dp_hip.h ----------
@@ -790,7 +808,7 @@ def _conv_wgrad_wino2d(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     if not _lib().dp_wgrad_wino2d_supported(C.byref(p)):
         return None
     flops = 2.0 * Cout * Cin * 4 * P
-    name = 'wgrad_wino2d_kernel<%d>' % {8: 3, 16: 4, 32: 5}[Wo]
+    name = ('wgrad_wino2d_tail_kernel<%d>' if _wino2d_tail(Cout) else 'wgrad_wino2d_kernel<%d>') % {8: 3, 16: 4, 32: 5}[Wo]
     if splits == 1:
         p.out, p.o_bs, p.accumulate = _p(gw), 0, 1 if accumulate else 0
         L.check(_run(lambda: _lib().dp_wgrad_wino2d(C.byref(p), _stream()), name, flops), 'dp_wgrad_wino2d')
@@ -876,7 +894,7 @@ def conv_wgrad(dy, x, x2, gw, spec, *, alpha=1.0, accumulate=True, max_splits=No
             and Cout * Cin >= WGRAD_WINO_MIN_FILL * min((-(-Cout // 64) * 64) * (-(-Cin // 64) * 64),
                                                         (-(-Cout // 96) * 96) * (-(-Cin // 96) * 96))):
         r = None
-        if WINO2D and WGRAD_WINO2D and P % 64 == 0 and Cout * Cin >= WGRAD_WINO2D_MIN_FILL * (-(-Cout // 64) * 64) * (-(-Cin // 32) * 32):
+        if WINO2D and WGRAD_WINO2D and P % 64 == 0 and Cout * Cin >= WGRAD_WINO2D_MIN_FILL * _wino2d_rows(Cout) * (-(-Cin // 32) * 32):
             r = _conv_wgrad_wino2d(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)
         if r is None:
             r = _conv_wgrad_wino(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2)

@@ -437,7 +437,8 @@ int dp_replay_info(void* handle, int* info8);
 int dp_replay_free(void* handle);
 
 /* dp_pack_weight for many layers in one launch (blk0 / nblk are filled by the launcher).  mode 0 / 1 as dp_pack_weight;
- * mode 2 / 3: the dp_pack_weight_wino operand (mode - 2) of a 3x3 weight (taps = 9, dst holds 12 * K * ld floats). */
+ * mode 2 / 3: the dp_pack_weight_wino operand (mode - 2) of a 3x3 weight (taps = 9, dst holds 12 * K * ld floats);
+ * mode 4 / 5: the dp_pack_weight_wino2d operand (mode - 4) of a 3x3 weight (taps = 9, dst holds 16 * K * ld floats). */
 typedef struct dp_pack_item {
     const float* W; float* dst;
     int Co, Ci, taps, mode, ld, blk0, nblk, _pad;

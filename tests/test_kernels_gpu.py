@@ -1107,10 +1107,14 @@ def test_pack_weight_batch_equals_per_layer_pack(ops):
     ws = [rnd(90, 45, 3, 3, seed=1), rnd(128, 256, 1, 1, seed=2), rnd(33, 70, seed=3), rnd(192, 192, 3, 3, seed=4), rnd(3, 96, 3, 3, seed=5)]
     items = [(w, m) for w in ws for m in (0, 1)] * 9                       # > 64 items: more than one launch
     items += [(w, ('wino', m)) for w in ws if w.dim() == 4 and w.shape[2] == 3 for m in (0, 1)]     # Winograd F(2, 3) operands
+    items += [(w, ('wino2d', m)) for w in ws if w.dim() == 4 and w.shape[2] == 3 for m in (0, 1)]   # F(2x2, 3x3) operands
     got = ops.pack_weight_batch(items)
     for (w, m), (buf, ld) in zip(items, got):
-        ref, ld0 = ops.pack_weight_wino(w, m[1]) if isinstance(m, tuple) else ops.pack_weight(w, m)
-        assert ld == ld0 and torch.equal(buf, ref)
+        if isinstance(m, tuple):
+            ref, ld0 = (ops.pack_weight_wino if m[0] == 'wino' else ops.pack_weight_wino2d)(w, m[1])
+        else:
+            ref, ld0 = ops.pack_weight(w, m)
+        assert ld == ld0 and torch.equal(buf, ref), (tuple(w.shape), m)
 
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
@@ -1206,7 +1210,8 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
                                              (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (3, 128, 0, 64, 8),
                                              (1, 8, 0, 16, 4), (2, 256, 0, 128, (6, 16)), (1, 32, 0, 48, 256), (2, 16, 8, 64, 128), (3, 8, 0, 16, (4, 128)),
-                                             (1, 128, 0, 128, 128)], ids=str)
+                                             (1, 128, 0, 128, 128), (64, 96, 0, 96, 32), (8, 96, 0, 96, 32), (4, 64, 0, 160, 16), (1, 32, 0, 96, 128)],
+                         ids=str)
 def test_conv_winograd_f2x2_3x3_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_conv_wino2d (3x3 / stride 1 / pad 1 as a TWO-dimensional Winograd F(2x2, 3x3) implicit GEMM, csrc/winograd2d.hip) against the
     fp64 convolution: forward (two concat sources, bias, per-image addend, residual, scale; accumulate) and input gradient, next to
@@ -1297,7 +1302,7 @@ def test_conv_wgrad_winograd_matches_fp64(ops, report, monkeypatch, N, C1, C2, C
 
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 192, 8),
                                              (8, 40, 0, 70, 16), (8, 96, 0, 96, 32), (4, 192, 96, 96, 16), (4, 179, 0, 90, 16), (1, 8, 0, 16, 8),
-                                             (3, 32, 32, 24, (16, 32)), (2, 64, 0, 64, (32, 8))], ids=str)
+                                             (3, 32, 32, 24, (16, 32)), (2, 64, 0, 64, (32, 8)), (8, 64, 0, 160, 8)], ids=str)
 def test_conv_wgrad_winograd_f3x3_2x2_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_wgrad_wino2d (3x3 / stride 1 / pad 1 weight gradient by the TWO-dimensional transposed Winograd algorithm F(3x3, 2x2),
     csrc/wgrad2d.hip) against the fp64 weight gradient, next to the F(3, 2) and the direct kernels' errors: two concat sources (boundary
