@@ -189,15 +189,16 @@ class LdmGraph(_GraphBase):
         return self.linear(pre + '.to_out.0', out)                # Dropout is the identity
 
     def transformer(self, pre, x):
-        tb = pre + '.transformer_blocks.0'
         h = self.gn(pre + '.norm', x)
         h = self.conv(pre + '.proj_in', h)
         h = self.ew(self.ew(h))                                   # rearrange 'b c h w -> b (h w) c'
-        h = self.ew(self.cross_attn(tb + '.attn1', self.ln(tb + '.norm1', h), True), h)
-        h = self.ew(self.cross_attn(tb + '.attn2', self.ln(tb + '.norm2', h), False), h)
-        p = self.linear(tb + '.ff.net.0.proj', self.ln(tb + '.norm3', h))
-        gl = self.ew(self.slice(p, 0, 2), self.ew(self.slice(p, 1, 2)))      # x * gelu(gate)
-        h = self.ew(self.linear(tb + '.ff.net.2', gl), h)
+        for d in range(self.cfg.get('transformer_depth', 1)):     # attention.py:253-254
+            tb = pre + '.transformer_blocks.%d' % d
+            h = self.ew(self.cross_attn(tb + '.attn1', self.ln(tb + '.norm1', h), True), h)
+            h = self.ew(self.cross_attn(tb + '.attn2', self.ln(tb + '.norm2', h), False), h)
+            p = self.linear(tb + '.ff.net.0.proj', self.ln(tb + '.norm3', h))
+            gl = self.ew(self.slice(p, 0, 2), self.ew(self.slice(p, 1, 2)))      # x * gelu(gate)
+            h = self.ew(self.linear(tb + '.ff.net.2', gl), h)
         h = self.ew(self.ew(h))                                   # rearrange back
         return self.ew(self.conv(pre + '.proj_out', h), x)        # x + x_in
 

@@ -2,7 +2,7 @@
 (ldm_exp/prune_ldm.py:86-132, config ldm_exp/configs/latent-diffusion/cin256-v2.yaml).
 
 `UNetModel` mirrors ldm_exp/ldm/modules/diffusionmodules/openaimodel.py:413-742 for the configuration family the
-reference prunes (use_spatial_transformer=True, num_heads=1, transformer_depth=1, no class labels): same constructor
+reference prunes (use_spatial_transformer=True, no class labels; any num_heads / num_head_channels / transformer_depth): same constructor
 arguments, same `forward(x, timesteps, context)` and the same state-dict keys, with every weight held by a real
 nn.Conv2d / nn.Linear / nn.GroupNorm / nn.LayerNorm (parameter holders; all arithmetic is in the HIP kernels).
 
@@ -59,6 +59,14 @@ def ldm_blocks(cfg):
     return inp, out, mid
 
 
+def st_heads(cfg, ch):
+    """(heads, dim_head) of the SpatialTransformer of a `ch`-channel level (openaimodel.py:542-549, legacy=True with
+    use_spatial_transformer: `num_heads` heads, or ch // num_head_channels of them; dim_head = ch // heads)."""
+    nhc = cfg.get('num_head_channels', -1)
+    heads = cfg.get('num_heads', 1) if nhc in (-1, None) else ch // nhc
+    return heads, ch // heads
+
+
 # ---- parameter-holder modules (names as in the CompVis code base) -----------------------------------------------
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
@@ -93,13 +101,13 @@ class BasicTransformerBlock(nn.Module):
 
 
 class SpatialTransformer(nn.Module):
-    def __init__(self, in_channels, n_heads, d_head, context_dim):
+    def __init__(self, in_channels, n_heads, d_head, context_dim, depth=1):
         super().__init__()
         inner = n_heads * d_head
         self.in_channels = in_channels
         self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
         self.proj_in = nn.Conv2d(in_channels, inner, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim) for _ in range(depth)])
         self.proj_out = nn.Conv2d(inner, in_channels, 1)
 
 
@@ -131,17 +139,31 @@ class Upsample(nn.Module):
 class UNetModel(nn.Module):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), num_heads=1, use_spatial_transformer=True, transformer_depth=1,
-                 context_dim=None):
+                 context_dim=None, num_head_channels=-1):
         super().__init__()
-        if not use_spatial_transformer or num_heads != 1 or transformer_depth != 1 or context_dim is None or dropout:
-            raise NotImplementedError('only the cin256-v2 configuration family of the LDM importance pass is implemented')
+        if not use_spatial_transformer or context_dim is None or dropout:
+            raise NotImplementedError('only the spatial-transformer (cross-attention conditioned, dropout-free) family of the LDM '
+                                      'importance pass is implemented')
+        if num_head_channels in (-1, None):
+            num_head_channels = -1
+            if num_heads is None or num_heads < 1:                                  # openaimodel.py:483-487
+                raise ValueError('Either num_heads or num_head_channels has to be set')
+        if transformer_depth < 1:
+            raise ValueError('transformer_depth >= 1')
         self.config = dict(image_size=image_size, in_channels=in_channels, model_channels=model_channels,
                            out_channels=out_channels, num_res_blocks=num_res_blocks,
                            attention_resolutions=list(attention_resolutions), channel_mult=list(channel_mult),
-                           num_heads=num_heads, use_spatial_transformer=True, transformer_depth=1, context_dim=context_dim)
+                           num_heads=num_heads, num_head_channels=num_head_channels, use_spatial_transformer=True,
+                           transformer_depth=int(transformer_depth), context_dim=context_dim)
         tdim = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, tdim), nn.SiLU(), nn.Linear(tdim, tdim))
         inp, out, mid = ldm_blocks(self.config)
+
+        def st_module(ch):
+            heads, d_head = st_heads(self.config, ch)
+            if heads < 1 or heads * d_head != ch:
+                raise ValueError('q,k,v channels %d is not divisible by the head width / count' % ch)      # openaimodel.py:299-300
+            return SpatialTransformer(ch, heads, d_head, context_dim, depth=int(transformer_depth))
 
         def make(it):
             if it[0] == 'conv_in':
@@ -149,13 +171,13 @@ class UNetModel(nn.Module):
             if it[0] == 'res':
                 return ResBlock(it[1], tdim, it[2])
             if it[0] == 'st':
-                return SpatialTransformer(it[1], 1, it[1], context_dim)
+                return st_module(it[1])
             if it[0] == 'down':
                 return Downsample(it[1])
             return Upsample(it[1])
 
         self.input_blocks = nn.ModuleList([nn.Sequential(*[make(it) for it in items]) for items in inp])
-        self.middle_block = nn.Sequential(ResBlock(mid, tdim, mid), SpatialTransformer(mid, 1, mid, context_dim),
+        self.middle_block = nn.Sequential(ResBlock(mid, tdim, mid), st_module(mid),
                                           ResBlock(mid, tdim, mid))
         self.output_blocks = nn.ModuleList([nn.Sequential(*[make(it) for it in items]) for items in out])
         self.out = nn.Sequential(nn.GroupNorm(32, model_channels), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
@@ -212,18 +234,33 @@ class LdmEngine(UNetEngine):
         return self.resnet_fwd(pre, xa, xb, semb, 1.0, save, names=RES_LDM, G=32, eps=1e-5)
 
     # ---- SpatialTransformer (attention.py:215-258) ------------------------------------------------------------
-    def st_fwd(self, pre, x, ctx2d, dim_head, save):
+    def st_fwd(self, pre, x, ctx2d, ch, save):
+        """`ch`: the UN-pruned channel count of the level -- heads and the softmax scale dim_head ** -0.5 are fixed at construction
+        (openaimodel.py:542-549, attention.py:158) and survive pruning.  `transformer_depth` BasicTransformerBlocks."""
         P = self.P
-        N, C, H, W = x.shape
-        T = H * W
-        tb = pre + '.transformer_blocks.0'
+        heads, dim_head = st_heads(self.cfg, ch)
         scale = float(dim_head) ** -0.5
         n0, st0 = ops.groupnorm_fwd(x, None, P[pre + '.norm.weight'], P[pre + '.norm.bias'], 32, 1e-6, False)
         h = self._conv(pre + '.proj_in', n0, None, _SPEC1)
-        inner = h.shape[1]
+        blocks = []
+        for d in range(self.cfg.get('transformer_depth', 1)):
+            h, kept = self._tb_fwd('%s.transformer_blocks.%d' % (pre, d), h, ctx2d, scale, heads, save is not None)
+            blocks.append(kept)
+        out = self._conv(pre + '.proj_out', h, None, _SPEC1, res=x)
+        if save is not None:
+            save[pre] = (x, st0, n0, blocks, h, scale, heads)
+        return out
+
+    def _tb_fwd(self, tb, h, ctx2d, scale, heads, keep):
+        """BasicTransformerBlock (attention.py:196-212) on channel-major tokens [N, inner, H, W]: self-attention, cross-attention,
+        GEGLU feed-forward, each with its residual.  Heads: 'b n (h d) -> (b h) n d' (attention.py:177) is a VIEW here -- head j owns
+        the contiguous channel rows [j d, (j + 1) d) of every image, batch index n * heads + j."""
+        P = self.P
+        N, inner, H, W = h.shape
+        T = H * W
         # attn1: self-attention
         l1, ls1 = ops.layernorm_fwd(h, P[tb + '.norm1.weight'], P[tb + '.norm1.bias'])
-        fused = self.fuse_qkv and hasattr(ops, 'empty_act')
+        fused = self.fuse_qkv and heads == 1 and hasattr(ops, 'empty_act')
         if fused:                                     # one M = 3 * inner contraction instead of three (see UNetEngine.attn_fwd)
             wp, ld, _, _, _, (cq, ck, cv) = self._qkv_pack(tb + '.attn1')
             qkv = ops.conv_forward(l1, None, wp, ld, cq + ck + cv, _SPEC1)
@@ -232,26 +269,28 @@ class LdmEngine(UNetEngine):
             q = self._conv(tb + '.attn1.to_q', l1, None, _SPEC1)
             k = self._conv(tb + '.attn1.to_k', l1, None, _SPEC1)
             v = self._conv(tb + '.attn1.to_v', l1, None, _SPEC1)
-        ai = q.shape[1]
-        if save is None and getattr(ops, 'FUSED_ATTN', False) and ops.attention_fused_ok(T, ai, ai):
+        ai, av = q.shape[1], v.shape[1]               # the value width may differ from the query / key width after pruning
+        Z = N * heads
+        if not keep and getattr(ops, 'FUSED_ATTN', False) and ops.attention_fused_ok(T, ai // heads, av // heads):
             p = None                                  # sampling forward: one kernel, no [T, T] scores (csrc/attention.hip)
-            o = ops.attention_fwd(q, k, v, 1, scale)
+            o = ops.attention_fwd(q, k, v, heads, scale)
         else:
-            s = ops.bmm_tn(q.view(N, ai, T), k.view(N, ai, T), alpha=scale)
+            s = ops.bmm_tn(q.view(Z, ai // heads, T), k.view(Z, ai // heads, T), alpha=scale)
             p = ops.softmax_fwd(s, out=s)
-            o = ops.bmm_nt(v.view(N, ai, T), p)
-        h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, ai, H, W), None, _SPEC1, res=h)
-        hit = self._ctx_cache.get(pre) if self._ctx_cache is not None else None
+            o = ops.bmm_nt(v.view(Z, av // heads, T), p)
+        h1 = self._conv(tb + '.attn1.to_out.0', o.view(N, av, H, W), None, _SPEC1, res=h)
+        hit = self._ctx_cache.get(tb) if self._ctx_cache is not None else None
         x2 = None
         if ctx2d is not None:
-            # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context))
+            # attn2: cross-attention over a single context token == broadcast of to_out(to_v(context)) (the softmax over one key
+            # is 1 for every head)
             if hit is not None:
                 v2, o2 = hit                          # sampling loop: same context and weights at every DDIM step
             else:
                 v2 = self._linear(tb + '.attn2.to_v', ctx2d)
                 o2 = self._linear(tb + '.attn2.to_out.0', v2).contiguous()
                 if self._ctx_cache is not None:
-                    self._ctx_cache[pre] = (v2, o2)
+                    self._ctx_cache[tb] = (v2, o2)
             h2 = ops.add_rowvec(h1, o2)
         else:
             # attn2 over L > 1 context tokens (ldm/modules/attention.py:152-193, general form): the context as channel-major
@@ -267,22 +306,20 @@ class LdmEngine(UNetEngine):
                 k2 = self._conv(tb + '.attn2.to_k', cx, None, _SPEC1)
                 v2 = self._conv(tb + '.attn2.to_v', cx, None, _SPEC1)
                 if self._ctx_cache is not None:
-                    self._ctx_cache[pre] = (k2, v2)
-            a2 = q2.shape[1]
-            s2 = ops.bmm_tn(q2.view(N, a2, T), k2.view(N, a2, L_), alpha=scale)
+                    self._ctx_cache[tb] = (k2, v2)
+            a2, b2 = q2.shape[1], v2.shape[1]
+            s2 = ops.bmm_tn(q2.view(Z, a2 // heads, T), k2.view(Z, a2 // heads, L_), alpha=scale)
             p2 = ops.softmax_fwd(s2, out=s2)
-            o2 = ops.bmm_nt(v2.view(N, a2, L_), p2)
-            h2 = self._conv(tb + '.attn2.to_out.0', o2.view(N, a2, H, W), None, _SPEC1, res=h1)
+            o2 = ops.bmm_nt(v2.view(Z, b2 // heads, L_), p2)
+            h2 = self._conv(tb + '.attn2.to_out.0', o2.view(N, b2, H, W), None, _SPEC1, res=h1)
             x2 = (l2, ls2, q2, k2, p2, o2, cx)
         # feed-forward (GEGLU)
         l3, ls3 = ops.layernorm_fwd(h2, P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
         pr = self._conv(tb + '.ff.net.0.proj', l3, None, _SPEC1)
         gg = ops.geglu_fwd(pr)
         h3 = self._conv(tb + '.ff.net.2', gg, None, _SPEC1, res=h2)
-        out = self._conv(pre + '.proj_out', h3, None, _SPEC1, res=x)
-        if save is not None:
-            save[pre] = (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused, x2)
-        return out
+        kept = (h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, fused, x2) if keep else None
+        return h3, kept
 
     # The cross-attention branch of every transformer block depends on the context token and the weights only
     # (module docstring): inside a sampling loop -- frozen weights, one context for all DDIM steps -- it is computed once.
@@ -309,14 +346,28 @@ class LdmEngine(UNetEngine):
         self._colsum(pws, N, C, 2, 0, self.G[name + '.bias'])
 
     def st_bwd(self, pre, dout, extra=None):
-        (x, st0, n0, h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, h3, scale, fused, x2) = self.ctx.pop(pre)
+        x, st0, n0, blocks, h_last, scale, heads = self.ctx.pop(pre)
         P = self.P
-        N, C, H, W = x.shape
+        hw = (x.shape[2], x.shape[3])
+        dh = self._conv_bwd(pre + '.proj_out', dout, h_last, None, _SPEC1, hw)
+        for d in range(len(blocks) - 1, -1, -1):
+            dh = self._tb_bwd('%s.transformer_blocks.%d' % (pre, d), blocks[d], dh, scale, heads)
+            blocks[d] = None
+        dn0 = self._conv_bwd(pre + '.proj_in', dh, n0, None, _SPEC1, hw)
+        dx, pws = ops.groupnorm_bwd(x, None, P[pre + '.norm.weight'], P[pre + '.norm.bias'], st0, dn0, 32, False,
+                                    add1=dout, add2=extra)
+        self._gn_param_grads(pre + '.norm', pws)
+        return dx
+
+    def _tb_bwd(self, tb, kept, dh3, scale, heads):
+        """Backward of _tb_fwd: dh3 = gradient of the block's output; returns the gradient of its input."""
+        (h, l1, ls1, q, k, v, p, o, h1, v2, ctx2d, h2, l3, ls3, pr, gg, fused, x2) = kept
+        P = self.P
+        N, inner, H, W = h.shape
         T = H * W
         hw = (H, W)
-        tb = pre + '.transformer_blocks.0'
-        inner, ai = h.shape[1], q.shape[1]
-        dh3 = self._conv_bwd(pre + '.proj_out', dout, h3, None, _SPEC1, hw)
+        ai, av = q.shape[1], v.shape[1]
+        Z = N * heads
         # feed-forward
         dgg = self._conv_bwd(tb + '.ff.net.2', dh3, gg, None, _SPEC1, hw)
         dpr = ops.geglu_bwd(pr, dgg)
@@ -334,27 +385,27 @@ class LdmEngine(UNetEngine):
             # gradients now (over a single key the softmax is constant and they are exactly zero), the context itself gets none
             # (the importance pass differentiates the UNet's parameters only)
             l2, ls2, q2, k2, p2, o2, cx = x2
-            a2, L_ = q2.shape[1], cx.shape[3]
-            do2 = self._conv_bwd(tb + '.attn2.to_out.0', dh2, o2.view(N, a2, H, W), None, _SPEC1, hw)
-            do23 = do2.view(N, a2, T)
-            dv2 = ops.bmm_nn(do23, p2)                                         # [N, a2, L]
-            dp2 = ops.bmm_tn(do23, v2.view(N, a2, L_))                         # [N, T, L]
+            a2, b2, L_ = q2.shape[1], v2.shape[1], cx.shape[3]
+            do2 = self._conv_bwd(tb + '.attn2.to_out.0', dh2, o2.view(N, b2, H, W), None, _SPEC1, hw)
+            do23 = do2.view(Z, b2 // heads, T)
+            dv2 = ops.bmm_nn(do23, p2)                                         # [Z, dv, L]
+            dp2 = ops.bmm_tn(do23, v2.view(Z, b2 // heads, L_))                # [Z, T, L]
             ds2 = ops.softmax_bwd(p2, dp2, scale, out=dp2)
-            dq2 = ops.bmm_nt(k2.view(N, a2, L_), ds2)                          # [N, a2, T]
-            dk2 = ops.bmm_nn(q2.view(N, a2, T), ds2)                           # [N, a2, L]
+            dq2 = ops.bmm_nt(k2.view(Z, a2 // heads, L_), ds2)                 # [Z, d, T]
+            dk2 = ops.bmm_nn(q2.view(Z, a2 // heads, T), ds2)                  # [Z, d, L]
             self._conv_bwd(tb + '.attn2.to_k', dk2.view(N, a2, 1, L_), cx, None, _SPEC1, (1, L_), need_dx=False)
-            self._conv_bwd(tb + '.attn2.to_v', dv2.view(N, a2, 1, L_), cx, None, _SPEC1, (1, L_), need_dx=False)
+            self._conv_bwd(tb + '.attn2.to_v', dv2.view(N, b2, 1, L_), cx, None, _SPEC1, (1, L_), need_dx=False)
             dl2 = self._conv_bwd(tb + '.attn2.to_q', dq2.view(N, a2, H, W), l2, None, _SPEC1, hw)
             dh1, pws2 = ops.layernorm_bwd(h1, P[tb + '.norm2.weight'], ls2, dl2, add=dh2)
             self._ln_param_grads(tb + '.norm2', pws2)
         dh2 = dh1
         # attn1
-        do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, ai, H, W), None, _SPEC1, hw)
-        do3 = do.view(N, ai, T)
+        do = self._conv_bwd(tb + '.attn1.to_out.0', dh2, o.view(N, av, H, W), None, _SPEC1, hw)
+        do3 = do.view(Z, av // heads, T)
         if fused:
             # dq | dk | dv written straight into channel slices of one buffer; one K = 3 * inner input-gradient contraction
             _, _, _, wd, ldd, (cq, ck, cv) = self._qkv_pack(tb + '.attn1')
-            d_qkv = ops.empty_act((N, cq + ck + cv, H, W), x.device)
+            d_qkv = ops.empty_act((N, cq + ck + cv, H, W), h.device)
             sl = (d_qkv[:, :cq], d_qkv[:, cq:cq + ck], d_qkv[:, cq + ck:])
             ops.bmm_nn(do3, p, out=sl[2].view(N, cv, T))
             dp = ops.bmm_tn(do3, v.view(N, cv, T))
@@ -370,22 +421,18 @@ class LdmEngine(UNetEngine):
             dl1 = ops.conv_dgrad(d_qkv, wd, ldd, l1.shape[1], _SPEC1, hw)
         else:
             dv = ops.bmm_nn(do3, p)
-            dp = ops.bmm_tn(do3, v.view(N, ai, T))
+            dp = ops.bmm_tn(do3, v.view(Z, av // heads, T))
             ds = ops.softmax_bwd(p, dp, scale, out=dp)
-            dq = ops.bmm_nt(k.view(N, ai, T), ds)
-            dk = ops.bmm_nn(q.view(N, ai, T), ds)
+            dq = ops.bmm_nt(k.view(Z, ai // heads, T), ds)
+            dk = ops.bmm_nn(q.view(Z, ai // heads, T), ds)
             dl1 = torch.empty_like(l1)
             first = True
-            for dproj, name in ((dq, '.attn1.to_q'), (dk, '.attn1.to_k'), (dv, '.attn1.to_v')):
-                self._conv_bwd(tb + name, dproj.view(N, ai, H, W), l1, None, _SPEC1, hw, dx_out=dl1, dx_accumulate=not first)
+            for dproj, name, c in ((dq, '.attn1.to_q', ai), (dk, '.attn1.to_k', ai), (dv, '.attn1.to_v', av)):
+                self._conv_bwd(tb + name, dproj.view(N, c, H, W), l1, None, _SPEC1, hw, dx_out=dl1, dx_accumulate=not first)
                 first = False
         dh, pws = ops.layernorm_bwd(h, P[tb + '.norm1.weight'], ls1, dl1, add=dh2)
         self._ln_param_grads(tb + '.norm1', pws)
-        dn0 = self._conv_bwd(pre + '.proj_in', dh, n0, None, _SPEC1, hw)
-        dx, pws = ops.groupnorm_bwd(x, None, P[pre + '.norm.weight'], P[pre + '.norm.bias'], st0, dn0, 32, False,
-                                    add1=dout, add2=extra)
-        self._gn_param_grads(pre + '.norm', pws)
-        return dx
+        return dh
 
     # ---- whole network ----------------------------------------------------------------------------------------
     def forward(self, x, timesteps, context, save=False, cfg_pair=False):

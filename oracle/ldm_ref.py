@@ -60,34 +60,50 @@ def res_block(P, pre, x, emb):
     return x + h
 
 
-def cross_attention(P, pre, x, context, scale):
-    """attention.py:168-193, heads == 1."""
+def cross_attention(P, pre, x, context, scale, heads=1):
+    """attention.py:168-193: 'b n (h d) -> (b h) n d', scaled dot-product per head, heads concatenated again."""
     q = _lin(P, pre + '.to_q', x)
     ctx = x if context is None else context
     k = _lin(P, pre + '.to_k', ctx)
     v = _lin(P, pre + '.to_v', ctx)
+
+    def split(t):                                    # rearrange(t, 'b n (h d) -> (b h) n d', h=heads)
+        b, n, hd = t.shape
+        return t.reshape(b, n, heads, hd // heads).permute(0, 2, 1, 3).reshape(b * heads, n, hd // heads)
+    q, k, v = split(q), split(k), split(v)
     sim = torch.einsum('bid,bjd->bij', q, k) * scale
     attn = sim.softmax(dim=-1)
     out = torch.einsum('bij,bjd->bid', attn, v)
+    bh, n, d = out.shape                             # rearrange(out, '(b h) n d -> b n (h d)', h=heads)
+    out = out.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, heads * d)
     return _lin(P, pre + '.to_out.0', out)
 
 
-def spatial_transformer(P, pre, x, context, dim_head):
-    """attention.py:218-258.  `dim_head` = the UN-pruned channel count of the block (CrossAttention.scale is fixed at
-    construction: attention.py:158), heads == 1."""
+def st_heads(cfg, ch):
+    """(heads, dim_head) of the SpatialTransformer of a `ch`-channel level (openaimodel.py:542-549, legacy=True with
+    use_spatial_transformer: num_heads fixed, or ch // num_head_channels heads; dim_head = ch // heads)."""
+    nhc = cfg.get('num_head_channels', -1)
+    heads = cfg.get('num_heads', 1) if nhc in (-1, None) else ch // nhc
+    return heads, ch // heads
+
+
+def spatial_transformer(P, pre, x, context, dim_head, heads=1, depth=1):
+    """attention.py:218-258.  `dim_head` = the UN-pruned head width of the block (CrossAttention.scale is fixed at
+    construction: attention.py:158); `depth` BasicTransformerBlocks (attention.py:196-212) between proj_in and proj_out."""
     b, c, h, w = x.shape
     x_in = x
     x = F.group_norm(x, 32, P[pre + '.norm.weight'], P[pre + '.norm.bias'], 1e-6)
     x = _conv(P, pre + '.proj_in', x, padding=0)
     inner = x.shape[1]
     x = x.reshape(b, inner, h * w).transpose(1, 2)
-    tb = pre + '.transformer_blocks.0'
     scale = float(dim_head) ** -0.5
-    x = cross_attention(P, tb + '.attn1', F.layer_norm(x, (inner,), P[tb + '.norm1.weight'], P[tb + '.norm1.bias']), None, scale) + x
-    x = cross_attention(P, tb + '.attn2', F.layer_norm(x, (inner,), P[tb + '.norm2.weight'], P[tb + '.norm2.bias']), context, scale) + x
-    y = F.layer_norm(x, (inner,), P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
-    a, gate = _lin(P, tb + '.ff.net.0.proj', y).chunk(2, dim=-1)
-    x = _lin(P, tb + '.ff.net.2', a * F.gelu(gate)) + x
+    for d in range(depth):
+        tb = pre + '.transformer_blocks.%d' % d
+        x = cross_attention(P, tb + '.attn1', F.layer_norm(x, (inner,), P[tb + '.norm1.weight'], P[tb + '.norm1.bias']), None, scale, heads) + x
+        x = cross_attention(P, tb + '.attn2', F.layer_norm(x, (inner,), P[tb + '.norm2.weight'], P[tb + '.norm2.bias']), context, scale, heads) + x
+        y = F.layer_norm(x, (inner,), P[tb + '.norm3.weight'], P[tb + '.norm3.bias'])
+        a, gate = _lin(P, tb + '.ff.net.0.proj', y).chunk(2, dim=-1)
+        x = _lin(P, tb + '.ff.net.2', a * F.gelu(gate)) + x
     x = x.transpose(1, 2).reshape(b, inner, h, w)
     return _conv(P, pre + '.proj_out', x, padding=0) + x_in
 
@@ -125,6 +141,7 @@ def ldm_blocks(cfg):
 def ldm_unet_forward(P, cfg, x, timesteps, context):
     """openaimodel.py:710-742 (num_classes None, use_spatial_transformer True)."""
     inp, out, mid_ch = ldm_blocks(cfg)
+    depth = cfg.get('transformer_depth', 1)
     emb = _lin(P, 'time_embed.2', F.silu(_lin(P, 'time_embed.0', timestep_embedding(timesteps, cfg['model_channels']))))
     hs = []
     h = x
@@ -136,12 +153,12 @@ def ldm_unet_forward(P, cfg, x, timesteps, context):
             elif it[0] == 'res':
                 h = res_block(P, pre, h, emb)
             elif it[0] == 'st':
-                h = spatial_transformer(P, pre, h, context, it[1])
+                h = spatial_transformer(P, pre, h, context, st_heads(cfg, it[1])[1], st_heads(cfg, it[1])[0], depth)
             elif it[0] == 'down':
                 h = _conv(P, pre + '.op', h, stride=2, padding=1)
         hs.append(h)
     h = res_block(P, 'middle_block.0', h, emb)
-    h = spatial_transformer(P, 'middle_block.1', h, context, mid_ch)
+    h = spatial_transformer(P, 'middle_block.1', h, context, st_heads(cfg, mid_ch)[1], st_heads(cfg, mid_ch)[0], depth)
     h = res_block(P, 'middle_block.2', h, emb)
     for bi, items in enumerate(out):
         h = torch.cat([h, hs.pop()], dim=1)
@@ -150,7 +167,7 @@ def ldm_unet_forward(P, cfg, x, timesteps, context):
             if it[0] == 'res':
                 h = res_block(P, pre, h, emb)
             elif it[0] == 'st':
-                h = spatial_transformer(P, pre, h, context, it[1])
+                h = spatial_transformer(P, pre, h, context, st_heads(cfg, it[1])[1], st_heads(cfg, it[1])[0], depth)
             elif it[0] == 'up':
                 h = _conv(P, pre + '.conv', F.interpolate(h, scale_factor=2, mode='nearest'))
     h = F.silu(F.group_norm(h, 32, P['out.0.weight'], P['out.0.bias'], 1e-5))
@@ -188,16 +205,17 @@ def ldm_param_shapes(cfg):
     def st(n, c):
         norm(n + '.norm', c)
         conv(n + '.proj_in', c, c, 1)
-        tb = n + '.transformer_blocks.0'
-        for a, kd in (('attn1', c), ('attn2', cdim)):
-            lin(tb + '.%s.to_q' % a, c, c, False)
-            lin(tb + '.%s.to_k' % a, kd, c, False)
-            lin(tb + '.%s.to_v' % a, kd, c, False)
-            lin(tb + '.%s.to_out.0' % a, c, c)
-        lin(tb + '.ff.net.0.proj', c, 8 * c)
-        lin(tb + '.ff.net.2', 4 * c, c)
-        for k in ('norm1', 'norm2', 'norm3'):
-            norm(tb + '.' + k, c)
+        for d in range(cfg.get('transformer_depth', 1)):
+            tb = n + '.transformer_blocks.%d' % d
+            for a, kd in (('attn1', c), ('attn2', cdim)):
+                lin(tb + '.%s.to_q' % a, c, c, False)
+                lin(tb + '.%s.to_k' % a, kd, c, False)
+                lin(tb + '.%s.to_v' % a, kd, c, False)
+                lin(tb + '.%s.to_out.0' % a, c, c)
+            lin(tb + '.ff.net.0.proj', c, 8 * c)
+            lin(tb + '.ff.net.2', 4 * c, c)
+            for k in ('norm1', 'norm2', 'norm3'):
+                norm(tb + '.' + k, c)
         conv(n + '.proj_out', c, c, 1)
 
     lin('time_embed.0', mc, tdim)

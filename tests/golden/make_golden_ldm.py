@@ -400,6 +400,118 @@ def ldm_driver(K=4):
     print('ldm driver ok: lines', i0 + 1, i1 + 1, 'iterations', len(losses), 'losses', losses[:3], 'min ratio', min(losses) / rec['max_loss'])
 
 
+
+LDM_HEAD_VARIANTS = {   # multi-head / deeper SpatialTransformers (openaimodel.py:542-559, attention.py:196-258): (config, context tokens)
+    'h2d2': (dict(gc.LDM_TINY_CFG, num_heads=2, transformer_depth=2), 1),                       # 2 heads, 2 blocks, the class token
+    'hc16_L3': (dict(gc.LDM_TINY_CFG, num_heads=-1, num_head_channels=16, attention_resolutions=[4, 2]), 3),   # 6 / 10 heads of 16, 3 tokens
+}
+
+
+def ldm_heads():
+    """Multi-head (`num_heads` > 1 / `num_head_channels`) and `transformer_depth` > 1 members of the LDM UNet family under the
+    reference's own UNetModel + vendored torch_pruning: forward, loss, gradients, the group table, and the interactive Taylor prune
+    with the head channel groups of prune_ldm.py:78-82 (scores, masks, shapes and forward after)."""
+    sys.path.insert(0, '/root/reference/ddpm_exp')
+    os.makedirs('/tmp/golden_scratch', exist_ok=True)
+    os.chdir('/tmp/golden_scratch')
+    import torch_pruning as tp
+    from ldm.modules.attention import CrossAttention
+    f = tp.function
+    rec_all, arrays = {}, {}
+    for tag, (cfg, L_ctx) in LDM_HEAD_VARIANTS.items():
+        m = UNetModel(**cfg).eval()
+        gc.det_init_(m, 9)
+        H = cfg['image_size']
+        x = torch.from_numpy(gc.det_noise((2, 3, H, H), 31))
+        ctx = torch.from_numpy(gc.det_noise((2, L_ctx, cfg['context_dim']), 32))
+        noise = torch.from_numpy(gc.det_noise((2, 3, H, H), 33))
+        t = torch.tensor([7, 640])
+        ex = {'x': torch.randn(2, 3, H, H), 'timesteps': torch.full((2,), 1, dtype=torch.long), 'context': torch.randn(2, L_ctx, cfg['context_dim'])}
+        channel_groups = {}
+        for mod in m.modules():
+            if isinstance(mod, CrossAttention):
+                channel_groups[mod.to_q] = channel_groups[mod.to_k] = channel_groups[mod.to_v] = mod.heads
+        pr = tp.pruner.MagnitudePruner(m, ex, importance=tp.importance.TaylorImportance(), iterative_steps=1,
+                                       channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[m.out], round_to=2)
+        names = {mod: n for n, mod in m.named_modules()}
+        table = []
+        for g in pr.DG.get_all_groups(ignored_layers=pr.ignored_layers, root_module_types=pr.root_module_types):
+            mem = []
+            for dep, idxs in g:
+                mod = dep.target.module
+                if mod not in names:
+                    continue
+                h = dep.handler
+                kind = ('out' if h in (f.prune_conv_out_channels, f.prune_linear_out_channels) else
+                        'in' if h in (f.prune_conv_in_channels, f.prune_linear_in_channels) else
+                        'gn' if h == f.prune_groupnorm_out_channels else
+                        'ln' if h == f.prune_layernorm_out_channels else 'other')
+                rng = []
+                for i in sorted(idxs):
+                    if rng and rng[-1][1] == i:
+                        rng[-1][1] = i + 1
+                    else:
+                        rng.append([i, i + 1])
+                mem.append([names[mod], kind, rng])
+            table.append(dict(ch_groups=int(pr.get_channel_groups(g)), members=mem))
+        m.zero_grad()
+        y = m(x, t, context=ctx)
+        loss = (y - noise).square().mean(dim=(1, 2, 3)).mean()
+        loss.backward()
+        P = dict(m.named_parameters())
+        stats = {n: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())] for n, p in P.items()}
+        shapes = {n: list(p.shape) for n, p in P.items()}
+        arrays[tag + '::fwd_out'] = y.detach().numpy().copy()
+        arrays[tag + '::loss'] = np.array(float(loss))
+        st = next(n for n in P if n.endswith('.transformer_blocks.0.attn1.to_q.weight'))[:-len('.transformer_blocks.0.attn1.to_q.weight')]
+        last = 'transformer_blocks.%d' % (cfg.get('transformer_depth', 1) - 1)
+        for n in [st + '.transformer_blocks.0.attn1.to_q.weight', st + '.' + last + '.attn1.to_k.weight', st + '.' + last + '.attn2.to_q.weight',
+                  st + '.' + last + '.attn2.to_v.weight', st + '.' + last + '.norm2.weight', st + '.' + last + '.ff.net.0.proj.weight',
+                  'middle_block.1.' + last + '.attn1.to_v.weight', 'middle_block.1.proj_in.weight', 'input_blocks.0.0.weight']:
+            arrays[tag + '::grad::' + n] = P[n].grad.numpy().copy()
+        pr.current_step += 1
+        rec = []
+        for group in pr.DG.get_all_groups(ignored_layers=pr.ignored_layers, root_module_types=pr.root_module_types):
+            if not pr._check_sparsity(group):
+                continue
+            module, fn = group[0][0].target.module, group[0][0].handler
+            ch_groups = pr.get_channel_groups(group)
+            imp = pr.estimate_importance(group, ch_groups=ch_groups)
+            if imp is None:
+                continue
+            cur = pr.DG.get_out_channels(module)
+            n_pruned = cur - int(pr.layer_init_out_ch[module] * (1 - pr.get_target_sparsity(module)))
+            if pr.round_to:
+                n_pruned = n_pruned - (n_pruned % pr.round_to)
+            if n_pruned <= 0:
+                continue
+            if ch_groups > 1:
+                gs, per = cur // ch_groups, n_pruned // ch_groups
+                idxs = torch.cat([torch.argsort(imp[c * gs:(c + 1) * gs])[:per] + c * gs for c in range(ch_groups)], 0)
+            else:
+                idxs = torch.argsort(imp)[:(n_pruned // ch_groups)]
+            g2 = pr.DG.get_pruning_group(module, fn, idxs.tolist())
+            ok = pr.DG.check_pruning_group(g2)
+            rec.append(dict(root=names[module], ch_groups=int(ch_groups), cur=int(cur), n_pruned=int(n_pruned),
+                            pruned=sorted(int(i) for i in idxs.tolist()), score=gc.f32_to_b64(imp.detach().float().numpy()), ok=bool(ok)))
+            if ok:
+                g2.prune()
+        with torch.no_grad():
+            y2 = m(x, t, context=ctx)
+        arrays[tag + '::fwd_after'] = y2.numpy().copy()
+        rec_all[tag] = dict(cfg=cfg, context_tokens=L_ctx, shapes=shapes, grad_stats=stats, groups=table, prune=rec,
+                            heads={names[mod]: int(mod.heads) for mod in m.modules() if isinstance(mod, CrossAttention)},
+                            shapes_after={n: list(p.shape) for n, p in m.named_parameters()},
+                            params_after=sum(p.numel() for p in m.parameters()))
+        print(tag, 'groups', len(table), 'pruned groups', len(rec), 'loss', float(loss), 'params after', rec_all[tag]['params_after'])
+    json.dump(rec_all, open(os.path.join(HERE, 'ldm_heads.json'), 'w'))
+    np.savez(os.path.join(HERE, 'ldm_heads.npz'), **arrays)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'heads':
+    ldm_heads()
+    sys.exit(0)
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'driver':
     ldm_driver()
     sys.exit(0)

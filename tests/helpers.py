@@ -49,7 +49,7 @@ def relerr(a, ref):
 
 
 def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ignored=('conv_out',), gn_groups=None,
-                        round_to=None, mode='sum_sq'):
+                        round_to=None, mode='sum_sq', channel_groups=None):
     """Run the oracle's score / select / slice arithmetic over the PRODUCT's group enumeration (host logic that is
     itself pinned against the reference's group tables).  P/G: {name: tensor} dicts, modified in place.
     Returns a list of dict(root, ch_groups, score, pruned, margin)."""
@@ -68,6 +68,8 @@ def oracle_prune_replay(P, G, cfg, ratio, graph_mod, record=None, graph=None, ig
         if score is None:
             continue
         ch_groups = (gn_groups or cfg['norm_num_groups']) if any(k == 'gn' for _, k, _ in mem) else 1
+        if ch_groups == 1 and channel_groups:          # metapruner.py get_channel_groups: the first member listed in channel_groups
+            ch_groups = next((channel_groups[n] for n, _, _ in mem if n in channel_groups), 1)      # (prune_ldm.py:78-82: heads)
         cur = P[root + '.weight'].shape[0]
         pruned = R.select_pruned(score, cur, init_out[root], ratio, ch_groups, round_to)
         if not pruned:

@@ -1270,6 +1270,104 @@ def test_ldm_prune_flow_on_mocked_kernels(mocked, monkeypatch):
     assert {n: list(p.shape) for n, p in fresh.named_parameters()} == fx['shapes_after']
 
 
+def _ldm_heads_case(tag):
+    from oracle import ldm_ref as L
+    rec = load_json('ldm_heads.json')[tag]
+    cfg = rec['cfg']
+    S = L.ldm_param_shapes(cfg)
+    P = {n: torch.from_numpy(gc.det_param(n, s, 9)).requires_grad_(True) for n, s in S.items()}
+    x = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 31))
+    ctx = torch.from_numpy(gc.det_noise((2, rec['context_tokens'], cfg['context_dim']), 32))
+    noise = torch.from_numpy(gc.det_noise((2, 3, 16, 16), 33))
+    return rec, cfg, S, P, (x, ctx, noise, torch.tensor([7, 640]))
+
+
+@pytest.mark.parametrize('tag', ['h2d2', 'hc16_L3'])
+def test_ldm_multi_head_and_depth_oracle_matches_reference(tag):
+    """Round 6: the LDM UNet family beyond cin256-v2 -- `num_heads` > 1 / `num_head_channels` (openaimodel.py:542-549; heads split as
+    'b n (h d) -> (b h) n d', attention.py:177) and `transformer_depth` > 1 (attention.py:253-254) -- oracle/ldm_ref.py against the
+    reference's own UNetModel (make_golden_ldm.py heads): parameter table, forward, loss, gradients, and the group table of the
+    product's LdmGraph against the vendored torch_pruning's (with its head channel groups)."""
+    from oracle import ldm_ref as L
+    G = pkg('graph')
+    rec, cfg, S, P, (x, ctx, noise, t) = _ldm_heads_case(tag)
+    g = load_npz('ldm_heads.npz')
+    assert {n: list(s) for n, s in S.items()} == rec['shapes']
+    y = L.ldm_unet_forward(P, cfg, x, t, ctx)
+    assert float((y.detach() - torch.from_numpy(g[tag + '::fwd_out'])).abs().max()) < 1e-6
+    loss = (y - noise).square().mean(dim=(1, 2, 3)).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[tag + '::loss'])) < 1e-6
+    n_full = 0
+    for k in g.files:
+        if k.startswith(tag + '::grad::'):
+            ref = g[k]
+            assert relerr(P[k.split('::grad::')[1]].grad, ref) < 1e-5 or float(np.abs(ref).max()) == 0.0, k
+            n_full += 1
+    assert n_full == 9
+    for n, (s_, a) in rec['grad_stats'].items():
+        assert abs(float(P[n].grad.double().abs().sum()) - a) <= 2e-5 * a + 1e-8 * P[n].numel(), n
+    groups = list(G.all_groups(G.LdmGraph(cfg), lambda: G.ChannelView(S), ('out', 'out.0', 'out.1', 'out.2')))
+    assert len(groups) == len(rec['groups'])
+    heads = {n: h for n, h in rec['heads'].items()}
+    for ref, (root, mem) in zip(rec['groups'], groups):
+        assert ref['members'][0][0] == root
+        assert {(m[0], m[1]): gc.expand(m[2]) for m in ref['members']} == {(m.name, m.kind): m.idxs for m in mem}, root
+        # the reference's channel groups: 32 for groups with a GroupNorm member, the head count for to_q / to_k / to_v groups
+        mine = 32 if any(m.kind == 'gn' for m in mem) else next((heads[m.name.rsplit('.', 1)[0]] for m in mem
+                                                                  if m.name.rsplit('.', 1)[-1] in ('to_q', 'to_k', 'to_v')), 1)
+        assert mine == ref['ch_groups'], root
+
+
+@pytest.mark.parametrize('tag', ['h2d2', 'hc16_L3'])
+def test_ldm_multi_head_prune_masks_match_reference(tag, mocked):
+    """Vendored Taylor scores + masks with head channel groups (prune_ldm.py:78-82: every head loses the same number of its own
+    lowest-scored channels) for the multi-head / deeper LDM UNets: the oracle's arithmetic over the oracle's gradients, then the
+    product's MagnitudePruner on the product's UNetModel (mocked kernels) -- records, shapes and parameter count after."""
+    from oracle import ldm_ref as L
+    G = pkg('graph')
+    ldm, pruning = pkg('ldm'), pkg('pruning')
+    rec, cfg, S, P, (x, ctx, noise, t) = _ldm_heads_case(tag)
+    g = load_npz('ldm_heads.npz')
+    loss = (L.ldm_unet_forward(P, cfg, x, t, ctx) - noise).square().mean(dim=(1, 2, 3)).mean()
+    loss.backward()
+    Pd = {n: p.detach().clone() for n, p in P.items()}
+    Gd = {n: p.grad.clone() for n, p in P.items()}
+    cg = {a + s_: h for a, h in rec['heads'].items() for s_ in ('.to_q', '.to_k', '.to_v')}
+    mine = oracle_prune_replay(Pd, Gd, cfg, 0.3, G, graph=G.LdmGraph(cfg), ignored=('out', 'out.0', 'out.1', 'out.2'),
+                               gn_groups=32, round_to=2, channel_groups=cg)
+    ref_nonempty = [r for r in rec['prune'] if r['pruned']]
+    assert len(mine) == len(ref_nonempty) and any(r['ch_groups'] not in (1, 32) for r in ref_nonempty)
+    for a, ref in zip(mine, ref_nonempty):
+        assert a['root'] == ref['root'] and a['ch_groups'] == ref['ch_groups'], (a['root'], ref['root'])
+        assert relerr(a['score'], gc.b64_to_f32(ref['score'])) < 1e-5, ref['root']
+        assert a['pruned'] == ref['pruned'], (ref['root'], a['margin'])
+    assert {n: list(t_.shape) for n, t_ in Pd.items()} == rec['shapes_after']
+    with torch.no_grad():
+        y2 = L.ldm_unet_forward(Pd, cfg, x, t, ctx)
+    assert float((y2 - torch.from_numpy(g[tag + '::fwd_after'])).abs().max()) < 1e-5
+    # the product's pruner over the product's model
+    model = ldm.UNetModel(**cfg)
+    gc.det_init_(model, 9)
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == rec['shapes']
+    for n, p in model.named_parameters():
+        p.grad = P[n].grad.clone()
+    channel_groups = {}
+    for name, m in model.named_modules():
+        if isinstance(m, ldm.CrossAttention):
+            assert m.heads == rec['heads'][name]
+            channel_groups[m.to_q] = channel_groups[m.to_k] = channel_groups[m.to_v] = m.heads
+    pr = pruning.MagnitudePruner(model, None, importance=pruning.TaylorImportance(), iterative_steps=1,
+                                 channel_groups=channel_groups, ch_sparsity=0.3, ignored_layers=[model.out], round_to=2)
+    for grp in pr.step(interactive=True):
+        grp.prune()
+    assert [r[0] for r in pr.records] == [r['root'] for r in rec['prune']]
+    assert [r[1] for r in pr.records] == [r['ch_groups'] for r in rec['prune']]
+    assert [r[3] for r in pr.records] == [r['pruned'] for r in rec['prune']]
+    assert {n: list(p.shape) for n, p in model.named_parameters()} == rec['shapes_after']
+    assert sum(p.numel() for p in model.parameters()) == rec['params_after']
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # round 2: dropout masks, LR schedules, DDPM ancestral sampling, long accumulation, torch_pruning-shaped groups
 # ------------------------------------------------------------------------------------------------------------------
