@@ -457,7 +457,7 @@ def _pmc_traffic(config_name, dom):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate runs of
     THIS config's bench command, aggregated by tools/pmc_aggregate.py; KB -> bytes; they cannot run inside this process).  Read from
     the newest profiles/round*_pmc_bench_traffic[_<config>].json whose `_config` equals the config being timed and whose recorded
-    hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip + csrc/wgrad2d.hip) equals today's; anything else = null.
+    hash of the contraction kernels' sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip + csrc/wgrad2d.hip + the two *_kloop.inc) equals today's; anything else = null.
     FETCH_SIZE is uncalibrated for 4-byte-per-lane buffer loads on gfx950 (MI355X_MICROARCH.md, HBM section)."""
     import glob
     import hashlib
@@ -466,7 +466,7 @@ def _pmc_traffic(config_name, dom):
         cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))
         if not cand:
             return None, dict(file=None, reason='no PMC pass of config %r under profiles/' % config_name)
-        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'wgrad2d.hip'))
+        src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'winograd2d_kloop.inc', 'wgrad2d.hip', 'wgrad2d_kloop.inc'))
         blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()          # the contraction kernels' sources, concatenated
         pm = json.load(open(cand[-1]))
         measured_on, measured_cfg = pm.get('_gemm_hip_blob'), pm.get('_config', 'cifar256')

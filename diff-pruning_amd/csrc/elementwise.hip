@@ -952,73 +952,60 @@ struct PackBatch {
     int n;
     dp_pack_item it[DP_PACK_BATCH];
 };
+// One thread per (k, m) element of the operand: it reads the layer's taps for that (output, input) channel pair ONCE (36 bytes for a
+// 3x3 weight) and writes every tap / Winograd position of it -- the stores of a wavefront are m-contiguous for each of them.  (Round
+// 6: the first version ran one thread per OUTPUT element and re-read the nine taps for each of the 12 / 16 positions: 114 us per
+// launch of 64 layers of the pruned CIFAR UNet.)  The expressions per output are those of pack_weight_kernel (gemm.hip),
+// pack_weight_wino_kernel (winograd.hip) and pack_weight_wino2d_kernel (winograd2d.hip): same bits.
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch b) {
     int i = 0;
     while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
     const dp_pack_item& it = b.it[i];
     const long long step = (long long)it.nblk * 256;
-    if (it.mode >= 4) {      // Winograd F(2x2, 3x3) operand of a 3x3 weight (same element map and arithmetic as pack_weight_wino2d_kernel, winograd2d.hip)
-        const int wm = it.mode - 4;
-        const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
-        const long long total = 16ll * K * it.ld;
-        for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
-            const int m = (int)(e % it.ld);
-            const long long rk = e / it.ld;
-            const int k = (int)(rk % K);
-            const int pos = (int)(rk / K);
-            const int i = pos >> 2, j = pos & 3;
-            float v = 0.f;
-            if (m < Mv) {
-                const float* w = wm == 0 ? it.W + ((long long)m * it.Ci + k) * 9 : it.W + ((long long)k * it.Ci + m) * 9;
-                float gg[3][3];
+    const int wm = it.mode & 1, kind = it.mode >> 1;             // kind 0: taps as they are, 1: F(2, 3) operand, 2: F(2x2, 3x3) operand
+    const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
+    const int ld = it.ld, taps = it.taps;
+    const long long nkm = (long long)K * ld;
+    float* __restrict__ dst = it.dst;
+    for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < nkm; e += step) {
+        const int m = (int)(e % ld);
+        const int k = (int)(e / ld);
+        const bool ok = m < Mv;
+        const float* w = it.W + (wm == 0 ? ((long long)m * it.Ci + k) : ((long long)k * it.Ci + m)) * taps;
+        if (kind == 0) {
+            for (int tap = 0; tap < taps; ++tap)
+                dst[((long long)tap * K + k) * ld + m] = ok ? (wm == 0 ? w[tap] : w[taps - 1 - tap]) : 0.f;
+            continue;
+        }
+        float g[9];
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+        for (int t = 0; t < 9; ++t) g[t] = ok ? w[t] : 0.f;
+        if (kind == 1) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) gg[a][c] = wm == 0 ? w[a * 3 + c] : w[(2 - a) * 3 + (2 - c)];
-                float t[3];
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = wm == 0 ? ky : 2 - ky;
+                const float g0 = wm == 0 ? g[r * 3] : g[r * 3 + 2], g1 = g[r * 3 + 1], g2 = wm == 0 ? g[r * 3 + 2] : g[r * 3];
+                const float v[4] = {g0, ((g0 + g1) + g2) * 0.5f, ((g0 - g1) + g2) * 0.5f, g2};
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    t[c] = i == 0 ? gg[0][c] : i == 1 ? ((gg[0][c] + gg[1][c]) + gg[2][c]) * 0.5f : i == 2 ? ((gg[0][c] - gg[1][c]) + gg[2][c]) * 0.5f : gg[2][c];
-                v = j == 0 ? t[0] : j == 1 ? ((t[0] + t[1]) + t[2]) * 0.5f : j == 2 ? ((t[0] - t[1]) + t[2]) * 0.5f : t[2];
+                for (int pos = 0; pos < 4; ++pos) dst[((long long)(ky * 4 + pos) * K + k) * ld + m] = ok ? v[pos] : 0.f;
             }
-            it.dst[e] = v;
+            continue;
         }
-        return;
-    }
-    if (it.mode >= 2) {      // Winograd F(2, 3) operand of a 3x3 weight (same element map as pack_weight_wino_kernel, winograd.hip)
-        const int wm = it.mode - 2;
-        const int K = wm == 0 ? it.Ci : it.Co, Mv = wm == 0 ? it.Co : it.Ci;
-        const long long total = 12ll * K * it.ld;
-        for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
-            const int m = (int)(e % it.ld);
-            const long long rk = e / it.ld;
-            const int k = (int)(rk % K);
-            const int kp = (int)(rk / K);
-            const int ky = kp >> 2, pos = kp & 3;
-            float v = 0.f;
-            if (m < Mv) {
-                const float* w = wm == 0 ? it.W + ((long long)m * it.Ci + k) * 9 + ky * 3 : it.W + ((long long)k * it.Ci + m) * 9 + (2 - ky) * 3;
-                const float g0 = wm == 0 ? w[0] : w[2], g1 = w[1], g2 = wm == 0 ? w[2] : w[0];
-                v = pos == 0 ? g0 : pos == 1 ? ((g0 + g1) + g2) * 0.5f : pos == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
-            }
-            it.dst[e] = v;
+        float gg[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gg[a][c] = wm == 0 ? g[a * 3 + c] : g[(2 - a) * 3 + (2 - c)];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float t[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                t[c] = ii == 0 ? gg[0][c] : ii == 1 ? ((gg[0][c] + gg[1][c]) + gg[2][c]) * 0.5f : ii == 2 ? ((gg[0][c] - gg[1][c]) + gg[2][c]) * 0.5f : gg[2][c];
+            const float v[4] = {t[0], ((t[0] + t[1]) + t[2]) * 0.5f, ((t[0] - t[1]) + t[2]) * 0.5f, t[2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[((long long)(ii * 4 + j) * K + k) * ld + m] = ok ? v[j] : 0.f;
         }
-        return;
-    }
-    const int K = it.mode == 0 ? it.Ci : it.Co;
-    const int Mv = it.mode == 0 ? it.Co : it.Ci;
-    const long long total = (long long)it.taps * K * it.ld;
-    for (long long e = (long long)((int)blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += step) {
-        const int m = (int)(e % it.ld);
-        const long long rk = e / it.ld;
-        const int k = (int)(rk % K);
-        const int tap = (int)(rk / K);
-        float v = 0.f;
-        if (m < Mv) {
-            if (it.mode == 0) v = it.W[((long long)m * it.Ci + k) * it.taps + tap];
-            else              v = it.W[((long long)k * it.Ci + m) * it.taps + (it.taps - 1 - tap)];
-        }
-        it.dst[e] = v;
     }
 }
 extern "C" int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stream) {
@@ -1031,9 +1018,9 @@ extern "C" int dp_pack_weight_batch(const dp_pack_item* items, int n, void* stre
             dp_pack_item& it = b.it[i];
             if (it.Co <= 0 || it.Ci <= 0 || it.taps <= 0 || it.ld <= 0 || it.mode < 0 || it.mode > 5) return (int)hipErrorInvalidValue;
             if (it.mode >= 2 && it.taps != 9) return (int)hipErrorInvalidValue;
-            const long long total = (long long)(it.mode >= 4 ? 16 : it.mode >= 2 ? 12 : it.taps) * ((it.mode & 1) == 0 ? it.Ci : it.Co) * it.ld;
-            long long nb = (total + 1023) / 1024;
-            if (nb > 512) nb = 512;
+            const long long total = (long long)((it.mode & 1) == 0 ? it.Ci : it.Co) * it.ld;        // one thread per (k, m)
+            long long nb = (total + 255) / 256;
+            if (nb > 1024) nb = 1024;
             it.blk0 = blocks;
             it.nblk = (int)nb;
             blocks += (int)nb;

@@ -89,6 +89,7 @@ class _Packs:
     def __init__(self):
         self._c = {}
         self.pin_depth = 0
+        self.lazy = {}                # (name, ('up', class, 0 | 1)) / (prefix, 'qkv') asked for so far: prepare_packs() batches them
 
     def get(self, name, w, mode):
         key = (name, mode)
@@ -103,6 +104,7 @@ class _Packs:
         elif isinstance(mode, tuple) and mode[0] == 'wino2d':  # ('wino2d', 0 | 1): Winograd F(2x2, 3x3) operand (ops.pack_weight_wino2d)
             buf, ld = ops.pack_weight_wino2d(w, mode[1])
         elif isinstance(mode, tuple) and mode[0] == 'up':      # ('up', class, 0 | 1): class kernel of an upsample convolution
+            self.lazy[(name, mode)] = True
             weff = self.get_weff(name, w)
             buf, ld = ops.pack_weight(weff[mode[1]], mode[2])
         elif isinstance(mode, tuple):             # ('s2', ph, pw, pad): one parity class of a stride-2 dgrad (ops.conv_dgrad_s2)
@@ -318,15 +320,20 @@ class UNetEngine:
         key = (pre + '.__qkv__', 0)
         hit = self.packs._c.get(key)
         if hit is None:
-            ws = [self.P[pre + n + '.weight'] for n in ('.to_q', '.to_k', '.to_v')]
-            w = torch.cat(ws, 0).contiguous()
-            b = (torch.cat([self.P[pre + n + '.bias'] for n in ('.to_q', '.to_k', '.to_v')], 0).contiguous()
-                 if (pre + '.to_q.bias') in self.P else None)        # the LDM transformer's projections are bias-free
+            self.packs.lazy[(pre, 'qkv')] = True
+            w, b, sizes = self._qkv_cat(pre)
             wp, ld = ops.pack_weight(w, 0)
             wd, ldd = ops.pack_weight(w, 1)
-            hit = (wp, ld, b, wd, ldd, tuple(x.shape[0] for x in ws))
+            hit = (wp, ld, b, wd, ldd, sizes)
             self.packs._c[key] = hit
         return hit
+
+    def _qkv_cat(self, pre):
+        ws = [self.P[pre + n + '.weight'] for n in ('.to_q', '.to_k', '.to_v')]
+        w = torch.cat(ws, 0).contiguous()
+        b = (torch.cat([self.P[pre + n + '.bias'] for n in ('.to_q', '.to_k', '.to_v')], 0).contiguous()
+             if (pre + '.to_q.bias') in self.P else None)            # the LDM transformer's projections are bias-free
+        return w, b, tuple(x.shape[0] for x in ws)
 
     def prepare_packs(self):
         """Pack every conv / linear weight in both operand layouts now (needed before hipGraph capture: packing
@@ -350,9 +357,35 @@ class UNetEngine:
                             self.packs.get(name[:-7], w, mode)                     # (a packer without modes 4 / 5: one launch each)
                         else:
                             todo.append((name[:-7], w, mode))
-        if hasattr(ops, 'pack_weight_batch') and todo and all(w.is_contiguous() for _, w, _ in todo):
-            for (name, w, mode), (buf, ld) in zip(todo, ops.pack_weight_batch([(w, mode) for _, w, mode in todo])):
+        # operands that are packed from a DERIVED tensor and were asked for in an earlier pass: the four class kernels of an upsample
+        # convolution (both layouts) and the concatenated q | k | v projections of an attention block
+        derived = []                                  # (finish(buf, ld), source tensor, mode 0 | 1)
+        if hasattr(ops, 'pack_weight_batch') and getattr(ops, 'PACK_BATCH_DERIVED', True):
+            qkv_parts = {}
+            for (name, what) in list(self.packs.lazy):
+                if what == 'qkv':
+                    key = (name + '.__qkv__', 0)
+                    if key in self.packs._c or (name + '.to_q.weight') not in self.P:
+                        continue
+                    w, b, sizes = self._qkv_cat(name)
+                    qkv_parts[key] = [None, None, b, None, None, sizes]
+                    for m in (0, 1):
+                        derived.append((lambda buf, ld, key=key, m=m: qkv_parts[key].__setitem__(slice(3 * m, 3 * m + 2), [buf, ld]), w, m))
+                else:
+                    w = self.P.get(name + '.weight')
+                    if w is None or self.packs.has(name, w, what):
+                        continue
+                    weff = self.packs.get_weff(name, w)
+                    derived.append((lambda buf, ld, name=name, w=w, what=what: self.packs.put(name, w, what, buf, ld), weff[what[1]], what[2]))
+        if hasattr(ops, 'pack_weight_batch') and (todo or derived) and all(w.is_contiguous() for _, w, _ in todo):
+            packed = ops.pack_weight_batch([(w, mode) for _, w, mode in todo] + [(w, m) for _, w, m in derived])
+            for (name, w, mode), (buf, ld) in zip(todo, packed):
                 self.packs.put(name, w, mode, buf, ld)
+            for (finish, _, _), (buf, ld) in zip(derived, packed[len(todo):]):
+                finish(buf, ld)
+            if derived:
+                for key, parts in qkv_parts.items():
+                    self.packs._c[key] = tuple(parts)
         else:
             for name, w, mode in todo:
                 self.packs.get(name, w, mode)

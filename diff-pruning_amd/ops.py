@@ -230,11 +230,26 @@ SPLITK_FOLD_MAX = int(os.environ.get('DP_SPLITK_FOLD_MAX', '4'))
 _tc_cache = {}
 
 
+_tc_arena = None          # while a CapturedCall records: {'bufs': live buffers, stream handle: [current buffer, next free counter]}
+
+
 def _tile_counters(n, device):
     """Zeroed per-tile counters for dp_conv_gemm's in-kernel split-K reduction: one buffer per (device, stream) -- every
-    launch leaves them zero again, launches of one stream are ordered; a fresh one inside a stream capture (see _workspace)."""
+    launch leaves them zero again, launches of one stream are ordered; inside a stream capture every launch gets counters of its
+    own (a replay may run two of them at once on its two streams): slices of ONE zeroed buffer per CapturedCall (a fresh
+    torch.zeros per launch was 18 fill kernels per replayed sampling forward), which stays referenced until the capture ends."""
     if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        n = max(n, 1)
+        if _tc_arena is None:                         # a capture that is not a CapturedCall
+            return torch.zeros(n, dtype=torch.int32, device=device)
+        # (per stream: the fill that zeroes a buffer is recorded on the stream whose launches use it)
+        slot = _tc_arena.setdefault((device.index, _stream().value), [None, 0])
+        cur, off = slot
+        if cur is None or off + n > cur.numel():
+            cur, off = torch.zeros(max(n, 1 << 15), dtype=torch.int32, device=device), 0
+            _tc_arena['bufs'].append(cur)
+        slot[0], slot[1] = cur, off + ((n + 31) & ~31)
+        return cur[off:off + n]
     key = (device.index if device.index is not None else torch.cuda.current_device(), _stream().value)
     t = _tc_cache.get(key)
     if t is None or t.numel() < n:
@@ -406,6 +421,7 @@ def wino2d_wanted(M, C_sources, N, H, W, spec):
     return ks >= 2 and tiles * ks >= WINO2D_MIN_TILES // 2
 
 
+PACK_BATCH_DERIVED = os.environ.get('DP_PACK_BATCH_DERIVED', '1') != '0'   # upsample class kernels and q | k | v concatenations join the batched packer (engine.prepare_packs)
 PACK_BATCH_WINO2D = os.environ.get('DP_PACK_BATCH_WINO2D', '1') != '0'     # dp_pack_weight_batch takes the F(2x2, 3x3) operands (modes 4 / 5)
 
 
@@ -1667,8 +1683,13 @@ class CapturedCall:
             native = True
         except TypeError:                              # a torch without keep_graph: no raw graph to read back
             g, native = torch.cuda.CUDAGraph(), False
-        with torch.cuda.graph(g):
-            self.result = fn()
+        global _tc_arena
+        saved_arena, _tc_arena = _tc_arena, {'bufs': []}
+        try:
+            with torch.cuda.graph(g):
+                self.result = fn()
+        finally:
+            _tc_arena = saved_arena
         self.graph, self.replay, self.side_stream = g, None, side_stream
         if native:
             try:

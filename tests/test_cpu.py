@@ -2345,12 +2345,12 @@ def test_lsun_ffhq_lmdb_datasets(tmp_path):
 
 def test_committed_pmc_traffic_was_measured_on_these_kernel_sources():
     """`roofline.traffic` on the bench line comes from committed rocprofv3 --pmc passes (they cannot run inside bench.py): the newest
-    file of every config must carry the hash of TODAY's contraction-kernel sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip + csrc/wgrad2d.hip) and its own
+    file of every config must carry the hash of TODAY's contraction-kernel sources (csrc/gemm.hip + csrc/winograd.hip + csrc/winograd2d.hip + csrc/wgrad2d.hip + the two *_kloop.inc) and its own
     config name, or bench.py reports `traffic: null` (bench._pmc_traffic) -- this test makes a stale file a red CPU suite, not a silent null."""
     import glob
     import hashlib
     import json
-    src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'wgrad2d.hip'))
+    src = b''.join(open(os.path.join(ROOT, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'winograd2d_kloop.inc', 'wgrad2d.hip', 'wgrad2d_kloop.inc'))
     blob = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
     for sfx, cfg in (('', 'cifar256'), ('_c4_finetune', 'c4_finetune'), ('_ldm', 'ldm')):
         cand = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_bench_traffic%s.json' % sfx)))

@@ -39,7 +39,7 @@ def main():
     # stamp the source the counters were measured on: bench.py refuses the numbers once csrc/gemm.hip, csrc/winograd.hip or csrc/winograd2d.hip has changed
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = b''.join(open(os.path.join(root, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'wgrad2d.hip'))
+    src = b''.join(open(os.path.join(root, 'diff-pruning_amd', 'csrc', f), 'rb').read() for f in ('gemm.hip', 'winograd.hip', 'winograd2d.hip', 'winograd2d_kloop.inc', 'wgrad2d.hip', 'wgrad2d_kloop.inc'))
     res['_gemm_hip_blob'] = hashlib.sha1(b'blob %d\0' % len(src) + src).hexdigest()
     res['_config'] = config
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
