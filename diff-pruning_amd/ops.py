@@ -794,6 +794,7 @@ WGRAD_WINO_MIN_WORK = int(os.environ.get('DP_WGRAD_WINO_MIN_WORK', '512'))      
 
 
 WGRAD_WINO2D = os.environ.get('DP_WGRAD_WINO2D', '1') not in ('0', '')
+WGRAD_WINO2D_BLOCKS = int(os.environ.get('DP_WGRAD_WINO2D_BLOCKS', '1024'))     # target workgroups per launch (two resident per CU)
 WGRAD_WINO2D_MIN_FILL = float(os.environ.get('DP_WGRAD_WINO2D_MIN_FILL', '0.7'))     # Cout x Cin against its 64 x 32 tiles
 
 
@@ -815,7 +816,7 @@ def _conv_wgrad_wino2d(dy, x, x2, gw, spec, alpha, accumulate, sd, s1, s2):
     p.M, p.C, p.NCOLS, p.ntaps, p.P = Cout, Cin, Cin, 9, P
     tiles = -(-Cout // 64) * (-(-C1 // 32) + (-(-(Cin - C1) // 32) if x2 is not None else 0))
     nt = P // 64                                       # K tiles of 16 tiles = 64 pixels
-    splits = max(1, min(WGRAD_BLOCKS // tiles, nt // 4))
+    splits = max(1, min(WGRAD_WINO2D_BLOCKS // tiles, nt // 4))
     tps = -(-nt // splits)
     splits = -(-nt // tps)
     p.batches, p.splits, p.p_per_split, p.tile, p.batched = 1, splits, tps * 64, 0, 0
