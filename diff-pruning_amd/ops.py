@@ -794,7 +794,11 @@ WGRAD_WINO_MIN_WORK = int(os.environ.get('DP_WGRAD_WINO_MIN_WORK', '512'))      
 
 
 WGRAD_WINO2D = os.environ.get('DP_WGRAD_WINO2D', '1') not in ('0', '')
-WGRAD_WINO2D_BLOCKS = int(os.environ.get('DP_WGRAD_WINO2D_BLOCKS', '1024'))     # target workgroups per launch (two resident per CU)
+# target workgroups per F(3x3, 2x2) launch: ONE round of the two resident per CU.  [measured, round 6, profiles/round6_wgrad2d_blocks.txt,
+# batch 256, incl. the reduction launch, against 1024 (two rounds: twice the epilogues, twice the partials to write and to reduce):
+# 128 -> 128 @ 32 x 32 0.379 -> 0.358 ms, 256 -> 256 @ 16 x 16 0.335 -> 0.326, @ 8 x 8 0.107 -> 0.095, 96 -> 96 @ 32 x 32 0.281 -> 0.254,
+# 192 -> 192 @ 16 x 16 0.215 -> 0.200; 768 and 1536 (one and a half / three rounds) lose to both]
+WGRAD_WINO2D_BLOCKS = int(os.environ.get('DP_WGRAD_WINO2D_BLOCKS', '512'))
 WGRAD_WINO2D_MIN_FILL = float(os.environ.get('DP_WGRAD_WINO2D_MIN_FILL', '0.7'))     # Cout x Cin against its 64 x 32 tiles
 
 
