@@ -59,14 +59,21 @@ constexpr int W2_BT = 32;                      // 2x2 tiles per workgroup (128 o
 // 4-row patch belong to the neighbouring segments (or are the image border) and come through a small extra tile [k][patch row][side][4].
 // TAIL (M % 64 in 1 .. 32, e.g. the pruned models' 96-wide layers): the workgroups of the last row tile have no second row block --
 // they run the K loop without its MFMAs and A fragments (half the matrix work of that tile instead of multiplying zeros).
-template <int W2_BK, int OCC, bool SEG, bool TAIL>
+// BMT: output channels per workgroup, 64 (two row blocks of 32: 128 accumulators) or 32 (one block: 64 accumulators, 93 registers and 32 KB
+// of LDS = FIVE workgroups per CU).  The 32-row form re-loads and re-transforms the input tile for every 32 rows and is 5-7 % slower than the
+// 64-row form on full tiles, but on the 65 .. 96-row layers of the pruned models (one full + one half-empty 64-row tile) it is 17-19 %
+// faster than even the tail instantiation: its short K tiles (8 MFMAs per wavefront) are covered by five resident workgroups instead of
+// three [measured, round 6, profiles/round6_wino2d_m32.txt].
+template <int W2_BK, int OCC, bool SEG, bool TAIL, int BMT = 64>
 __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
+    constexpr int W2_BM = BMT;                     // (shadows the namespace constant)
+    constexpr int NBLK = BMT / 32;                 // row blocks of 32 output channels
     constexpr int W2_A_SZ = 16 * W2_BK * W2_BM;    // [pos][k][m] floats (32 KB at BK = 8)
     constexpr int W2_B_SZ = W2_BK * 64 * 4;        // [k][4 patch rows][tile row][W] floats, tile rows x W = 64 (8 KB at BK = 8)
     constexpr int W2_H_SZ = SEG ? 256 : 0;         // halo columns of a segment: [k][patch row][left | right][4 floats], one wave instruction
     constexpr int W2_STAGE = W2_A_SZ + W2_B_SZ + W2_H_SZ;
     // the epilogue's exchange buffer reuses this memory: 64 KB at once when the K loop's buffers hold it, else 32 KB in two passes
-    __shared__ __attribute__((aligned(16))) float smem[(2 * W2_STAGE > 8192) ? 2 * W2_STAGE : 8192];
+    __shared__ __attribute__((aligned(16))) float smem[(2 * W2_STAGE > 8192) ? 2 * W2_STAGE : 8192];       // (8192 floats: one row block's exchange)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,11 +106,13 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
     const int rows_all = p.NPIX >> lw;                 // N * H
 
     // ---- A loader: 16-byte chunk e = tid + 256 j of [pos 16][k 8][m 64]
-    unsigned a_voff[W2_BK];
+    constexpr int NJA = W2_BK * W2_BM / 64;         // 16-byte chunks per thread: 16 positions x BK channels x BM / 4 chunks over 256 threads
+    constexpr int MCH = W2_BM / 4;                  // chunks per (position, channel) row
+    unsigned a_voff[NJA];
 #pragma unroll
-    for (int j = 0; j < W2_BK; ++j) {
+    for (int j = 0; j < NJA; ++j) {
         const int e = tid + 256 * j;
-        const int pos = e / (16 * W2_BK), k = (e >> 4) % W2_BK, m = m0 + 4 * (e & 15);
+        const int pos = e / (MCH * W2_BK), k = (e / MCH) % W2_BK, m = m0 + 4 * (e % MCH);
         a_voff[j] = (m < p.lda) ? (unsigned)(((pos * C + k) * p.lda + m) * 4) : DPW2_OOB;
     }
     const __amdgpu_buffer_rsrc_t rA = dpw2_rsrc(p.A, p.a_bytes);
@@ -144,7 +153,7 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
     auto dma_tile = [&](int buf, int ch) {
         const unsigned a_soff = (unsigned)(ch * W2_BK) * (unsigned)p.lda * 4u;
 #pragma unroll
-        for (int j = 0; j < W2_BK; ++j) {
+        for (int j = 0; j < NJA; ++j) {
             unsigned o = a_voff[j];
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (dpw2_lds_void*)(ldsA + buf * W2_STAGE + 1024 * j), 16, (int)o, (int)a_soff, 0, 0);
@@ -169,11 +178,11 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NBLK];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NBLK; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
@@ -199,11 +208,11 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (TAIL && m0 + 32 >= p.M) {
+    if (NBLK == 1 || (TAIL && m0 + 32 >= p.M)) {
 #define W2_NT 1
 #include "winograd2d_kloop.inc"
 #undef W2_NT
-    } else {
+    } else if (NBLK == 2) {
 #define W2_NT 2
 #include "winograd2d_kloop.inc"
 #undef W2_NT
@@ -214,8 +223,9 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
     //      The K loop's buffers are free (every wavefront is past its last barrier).  PASSES = 1: both row blocks at once, 64 KB,
     //      wavefront w finishes row block w >> 1, registers 8 (w & 1) .. + 7.  PASSES = 2 (the 40 KB variant): one row block per pass,
     //      32 KB, wavefront w finishes registers 4 w .. 4 w + 3 of it.
-    constexpr int PASSES = (2 * W2_STAGE >= 16384) ? 1 : 2;
-    constexpr int NR = 8 / PASSES;                     // accumulator registers (= output rows) a wavefront finishes per pass
+    constexpr int PASSES = (NBLK == 1 || 2 * W2_STAGE >= 16384) ? 1 : 2;
+    constexpr int BPP = NBLK / PASSES;                 // row blocks exchanged per pass
+    constexpr int NR = 4 * BPP;                        // accumulator registers (= output rows) a wavefront finishes per pass
     float* zbuf = smem;
     // the lane's tile coordinates once more, from a laundered lane id: nothing of the epilogue's addressing stays live across the K
     // loop (the 40 KB variant runs at the 168-register cap of three workgroups per CU and would spill it)
@@ -236,20 +246,20 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
     for (int pass = 0; pass < PASSES; ++pass) {
         if (pass) __syncthreads();                     // the previous pass's reads are done
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NBLK; ++t) {
             if (PASSES == 2 && t != pass) continue;
             const int tz = PASSES == 2 ? 0 : t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                zbuf[(((wave * 2 + 0) * (2 / PASSES) + tz) * 16 + r) * 64 + lane] = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
-                zbuf[(((wave * 2 + 1) * (2 / PASSES) + tz) * 16 + r) * 64 + lane] = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
+                zbuf[(((wave * 2 + 0) * BPP + tz) * 16 + r) * 64 + lane] = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
+                zbuf[(((wave * 2 + 1) * BPP + tz) * 16 + r) * 64 + lane] = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
             }
         }
         __syncthreads();
         if (!tile_ok) continue;
-        const int t_o = PASSES == 2 ? pass : (wave >> 1);
+        const int t_o = PASSES == 2 ? pass : (wave * NR) >> 4;           // (two blocks at once: wave >> 1, registers 8 (wave & 1) ..)
         const int tz_o = PASSES == 2 ? 0 : t_o;
-        const int r_o = PASSES == 2 ? 4 * wave : 8 * (wave & 1);
+        const int r_o = (wave * NR) & 15;
         if (ksplit) {
 #pragma unroll
             for (int q8 = 0; q8 < NR; ++q8) {
@@ -259,7 +269,7 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * (2 / PASSES) + tz_o) * 16 + r) * 64 + lane];
+                    for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * BPP + tz_o) * 16 + r) * 64 + lane];
                 if (m >= p.M) continue;
                 float* o = wsb + (long long)m * p.NPIX;
                 *reinterpret_cast<float2*>(o) = make_float2((z[0][0] + z[1][0]) + z[2][0], (z[0][1] + z[1][1]) + z[2][1]);
@@ -309,7 +319,7 @@ __device__ __forceinline__ void conv_wino2d_body(const dp_conv_gemm_params& p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * (2 / PASSES) + tz_o) * 16 + r) * 64 + lane];
+                for (int q = 0; q < 2; ++q) z[i][q] = zbuf[(((i * 2 + q) * BPP + tz_o) * 16 + r) * 64 + lane];
             float y00 = p.alpha * ((z[0][0] + z[1][0]) + z[2][0]), y01 = p.alpha * ((z[0][1] + z[1][1]) + z[2][1]);
             float y10 = p.alpha * ((z[1][0] - z[2][0]) - z[3][0]), y11 = p.alpha * ((z[1][1] - z[2][1]) - z[3][1]);
             if (p.bias) { y00 += tb[q8]; y01 += tb[q8]; y10 += tb[q8]; y11 += tb[q8]; }
@@ -333,6 +343,10 @@ __global__ __launch_bounds__(256, OCC) void conv_wino2d_kernel(const dp_conv_gem
 template <int W2_BK, int OCC, bool SEG>
 __global__ __launch_bounds__(256, OCC) void conv_wino2d_tail_kernel(const dp_conv_gemm_params p) {
     conv_wino2d_body<W2_BK, OCC, SEG, true>(p);
+}
+template <int W2_BK, int OCC, bool SEG>
+__global__ __launch_bounds__(256, OCC) void conv_wino2d_m32_kernel(const dp_conv_gemm_params p) {
+    conv_wino2d_body<W2_BK, OCC, SEG, false, 32>(p);
 }
 
 // Shapes the kernel takes: 3x3, stride 1, pad 1, no upsampling, W a power of two in 4 .. 256 (128 output pixels = whole image rows of
@@ -358,6 +372,15 @@ extern "C" int dp_conv_wino2d(const dp_conv_gemm_params* pp, void* stream) {
     if (p.M <= 0 || p.NPIX <= 0) return 0;
     if (!wino2d_ok(p)) return (int)hipErrorInvalidValue;
     dim3 grid((p.NPIX + 127) / 128, (p.M + W2_BM - 1) / W2_BM, p.ksplit > 1 ? p.ksplit : 1);
+    // 32-row tiles for the big grids of layers with at most 96 output rows that leave a half-empty 64-row tile (DP_WINO2D_M32=0: never,
+    // =2: every big grid -- measurements only)
+    static const int m32 = [] { const char* e = getenv("DP_WINO2D_M32"); return e ? atoi(e) : 1; }();
+    if (p.g.Wo <= 64 && p.ksplit <= 1 && (long long)grid.x * grid.y > 512 &&
+        (m32 == 2 || (m32 == 1 && p.M <= 96 && (p.M & 63) >= 1 && (p.M & 63) <= 32))) {
+        grid.y = (p.M + 31) / 32;
+        DP_LAUNCH((conv_wino2d_m32_kernel<4, 5, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        return DP_LAUNCH_CHECK();
+    }
     // K tiles of 4 channels (40 KB of LDS, 164 VGPRs: three workgroups per CU) for grids beyond one round of two per CU, K tiles
     // of 8 (80 KB, two per CU, half the barriers) for the small and the split-K grids.  [measured, round 6,
     // profiles/round6_wino2d_variants.txt, batch 256: 256 -> 256 @ 16 x 16 0.329 -> 0.307 ms, 128 -> 128 @ 32 x 32 0.367 -> 0.350,

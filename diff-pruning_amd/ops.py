@@ -470,6 +470,10 @@ def _wino2d_name(p):
     wgs = -(-p.NPIX // 128) * -(-p.M // 64) * max(int(p.ksplit), 1)
     forced = os.environ.get('DP_WINO2D_VARIANT')
     v = int(forced) if forced not in (None, '') else (1 if (p.ksplit <= 1 and wgs > 512) else 0)
+    m32 = os.environ.get('DP_WINO2D_M32', '1')
+    if p.g.Wo <= 64 and p.ksplit <= 1 and -(-p.NPIX // 128) * -(-p.M // 64) > 512 and (
+            m32 == '2' or (m32 == '1' and p.M <= 96 and 1 <= (p.M & 63) <= 32)):
+        return 'conv_wino2d_m32_kernel<4, 5, false>'     # 32-row tiles, five workgroups per CU (the 65 .. 96-row layers of pruned models)
     k = 'conv_wino2d_tail_kernel' if _wino2d_tail(p.M) else 'conv_wino2d_kernel'
     if p.g.Wo > 64:
         return k + '<4, 2, true>'                        # 2 x 64-pixel segments (images wider than 64 pixels)

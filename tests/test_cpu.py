@@ -2162,7 +2162,7 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
         pytest.skip('hipcc not available')
     csrc = os.path.join(ROOT, 'diff-pruning_amd', 'csrc')
     want = {'gemm.hip': ('conv_gemm_fast_kernel', 'nt_gemm_fast_kernel'), 'winograd.hip': ('conv_wino_kernel', 'wgrad_wino_kernel'),
-            'winograd43.hip': ('conv_wino43_kernel',), 'winograd2d.hip': ('conv_wino2d_kernel', 'conv_wino2d_tail_kernel'),
+            'winograd43.hip': ('conv_wino43_kernel',), 'winograd2d.hip': ('conv_wino2d_kernel', 'conv_wino2d_tail_kernel', 'conv_wino2d_m32_kernel'),
             'wgrad2d.hip': ('wgrad_wino2d_kernel', 'wgrad_wino2d_tail_kernel')}
     checked = 0
     for src, kernels in want.items():
@@ -2205,7 +2205,7 @@ def test_k_loops_carry_no_compiler_inserted_vmcnt0(tmp_path):
                 assert not bad, (fname, 'compiler-inserted s_waitcnt vmcnt(0) between the barrier and the hand-placed wait of a K tile', bad)
                 assert not any('scratch_' in t for t in seg), (fname, 'scratch access inside the K loop')
                 checked += 1
-    assert checked >= 26, checked            # (+ 2 K loops in each of the 3 + 3 tail instantiations of the two 2-D kernels)  6 fast-conv + 4 fast-wgrad + 5 Winograd-conv + 2 Winograd-wgrad + 1 F(2x2, 3x3) instantiations
+    assert checked >= 27, checked            # (+ 2 K loops in each of the 3 + 3 tail instantiations of the two 2-D kernels)  6 fast-conv + 4 fast-wgrad + 5 Winograd-conv + 2 Winograd-wgrad + 1 F(2x2, 3x3) instantiations
 
 
 def test_winograd_refuses_activations_within_a_row_of_2gib():

@@ -1210,7 +1210,8 @@ def test_conv_winograd_f23_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cou
 @pytest.mark.parametrize('N,C1,C2,Cout,H', [(8, 128, 0, 128, 32), (4, 256, 128, 128, 32), (16, 256, 0, 256, 16), (64, 256, 0, 256, 8),
                                              (256, 96, 0, 192, 4), (3, 24, 8, 40, 16), (5, 64, 0, 70, 8), (7, 16, 0, 16, 64), (3, 128, 0, 64, 8),
                                              (1, 8, 0, 16, 4), (2, 256, 0, 128, (6, 16)), (1, 32, 0, 48, 256), (2, 16, 8, 64, 128), (3, 8, 0, 16, (4, 128)),
-                                             (1, 128, 0, 128, 128), (64, 96, 0, 96, 32), (8, 96, 0, 96, 32), (4, 64, 0, 160, 16), (1, 32, 0, 96, 128)],
+                                             (1, 128, 0, 128, 128), (64, 96, 0, 96, 32), (8, 96, 0, 96, 32), (4, 64, 0, 160, 16), (1, 32, 0, 96, 128),
+                                             (70, 64, 0, 80, 32), (128, 32, 0, 24, 32), (40, 96, 96, 96, 32)],
                          ids=str)
 def test_conv_winograd_f2x2_3x3_matches_fp64(ops, report, monkeypatch, N, C1, C2, Cout, H):
     """dp_conv_wino2d (3x3 / stride 1 / pad 1 as a TWO-dimensional Winograd F(2x2, 3x3) implicit GEMM, csrc/winograd2d.hip) against the
