@@ -101,7 +101,7 @@ def _nt_name(p):
         return 'nt_gemm_fast_kernel<%d, %s>' % (4 if p.tile == 0 else 3, 'true' if p.X2 else 'false')
     t = 0 if p.tile == 3 else p.tile
     straddle = bool(p.X2) and (p.g.c_split % _TILES[t][1]) != 0
-    return 'nt_gemm_kernel<%s, %s>' % (_TILE_NAMES[t], 'true' if straddle else 'false')
+    return 'nt_gemm_kernel<%s, %s, false>' % (_TILE_NAMES[t], 'true' if straddle else 'false')     # (rocprofv3 prints the defaulted MERGE argument)
 
 
 def _chk_act(x):
