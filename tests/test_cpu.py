@@ -1366,6 +1366,17 @@ def test_ldm_multi_head_prune_masks_match_reference(tag, mocked):
     assert [r[3] for r in pr.records] == [r['pruned'] for r in rec['prune']]
     assert {n: list(p.shape) for n, p in model.named_parameters()} == rec['shapes_after']
     assert sum(p.numel() for p in model.parameters()) == rec['params_after']
+    # the pruned multi-head / deeper model survives the pickle-free checkpoint (config incl. num_head_channels / transformer_depth,
+    # history replay with the head channel groups)
+    import tempfile
+    ckpt = pkg('checkpoint')
+    with tempfile.TemporaryDirectory() as d:
+        ckpt.save_pruned(model, d, pr.pruning_history())
+        back = ckpt.load_pruned(d)
+    sd = model.state_dict()
+    assert all(torch.equal(v, sd[k]) for k, v in back.state_dict().items()) and len(back.state_dict()) == len(sd)
+    assert back.config['transformer_depth'] == cfg.get('transformer_depth', 1)
+    assert [m.heads for m in back.modules() if isinstance(m, ldm.CrossAttention)] == [m.heads for m in model.modules() if isinstance(m, ldm.CrossAttention)]
 
 
 # ------------------------------------------------------------------------------------------------------------------
